@@ -1,0 +1,138 @@
+/*
+ * psoap_gp.h -- C ABI of the MI355X (gfx950) Gaussian-process likelihood library.
+ *
+ * This is the drop-in boundary for PSOAP's dense GP hot path.  The reference has
+ * no FFI: the path sits behind Python functions taking NumPy arrays
+ * (psoap/covariance.py, psoap/matrix_functions.pyx).  Each entry point below
+ * names the reference interface it replaces (paths relative to the reference
+ * tree).  Host code (the psoap_amd Python package, or a maintainer's ctypes stub -- see
+ * INTEGRATION.md) binds these symbols; there are no torch types, only plain
+ * pointers and sizes.  All arrays are C-contiguous fp64 on the HOST unless a
+ * parameter is documented as device-resident.
+ *
+ * Return value: 0 on success, non-zero on a runtime/HIP error (message via
+ * psoap_last_error()).  Numerical failure is NOT an error: a non positive-
+ * definite matrix or a negative amp/l yields -inf in the output, exactly like
+ * psoap/covariance.py:317-318,326-327.
+ *
+ * Threading: a handle may be used by one host thread at a time.  HIP is
+ * initialised lazily by the first call in the calling process (safe after
+ * fork(), as psoap/sample_parallel.py:258-278 requires).
+ */
+#ifndef PSOAP_GP_H
+#define PSOAP_GP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct psoap_chunk psoap_chunk; /* opaque per-chunk device state */
+
+/* ---- library ---------------------------------------------------------------- */
+int psoap_version(void);
+const char *psoap_last_error(void);
+int psoap_device_count(int *count);
+
+/* ---- per-chunk handle ---------------------------------------------------------
+ * Replaces the per-chunk state of Worker.initialize (psoap/sample_parallel.py:
+ * 126-166): fl, sigma and the N x N scratch matrix V11 (:163) live on the device
+ * for the life of the handle; max_batch matrices are pre-allocated so that
+ * max_batch proposals can be evaluated concurrently. */
+int psoap_chunk_create(psoap_chunk **out, int device, int N, const double *fl,
+                       const double *sigma, int max_batch);
+int psoap_chunk_destroy(psoap_chunk *h);
+int psoap_chunk_set_data(psoap_chunk *h, const double *fl, const double *sigma);
+/* Observed-frame grid for the device-side Doppler shift
+ * (replicate_wls, psoap/data.py:40-63): lwl[N], epoch[N] in [0, n_epochs). */
+int psoap_chunk_set_grid(psoap_chunk *h, const double *lwl, const int32_t *epoch,
+                         int n_epochs);
+
+/* ---- lnlike -------------------------------------------------------------------
+ * lnlike_f / lnlike_f_g / lnlike_f_g_h (psoap/covariance.py:299-376), c = 1,2,3.
+ *   lwl : (c, N) rest-frame ln-wavelengths (the *lwls splat of
+ *         sample_parallel.py:193); gp : (amp_0, l_0, amp_1, l_1, ...).
+ *   out : -0.5 * (r^T K^-1 r + logdet K), r = fl - mu_GP; -inf conventions above. */
+int psoap_lnlike(psoap_chunk *h, int c, const double *lwl, const double *gp,
+                 double mu_GP, double *out);
+/* B proposals at once: lwl (B, c, N), gp (B, 2c), out (B).  B <= max_batch. */
+int psoap_lnlike_batch(psoap_chunk *h, int B, int c, const double *lwl,
+                       const double *gp, double mu_GP, double *out);
+
+/* Split-phase form of psoap_lnlike_batch: upload (H2D, async), eval (kernels
+ * only, async), fetch (sync + D2H of B doubles).  bench.py times eval+fetch with
+ * the proposals already resident in HBM. */
+int psoap_batch_upload(psoap_chunk *h, int B, int c, const double *lwl,
+                       const double *gp, double mu_GP);
+/* Same, but the Doppler shift runs on the device: vel (B, c, n_epochs) km/s,
+ * lwl_c = lwl - vel[c, epoch]/c_kms (psoap/data.py:37,61).  Needs set_grid. */
+int psoap_batch_upload_velocities(psoap_chunk *h, int B, int c, const double *vel,
+                                  const double *gp, double mu_GP);
+int psoap_batch_eval(psoap_chunk *h);
+int psoap_batch_fetch(psoap_chunk *h, double *out);
+int psoap_chunk_sync(psoap_chunk *h);
+
+/* ---- kernel-matrix fills --------------------------------------------------------
+ * fill_V11_f / fill_V11_f_g / fill_V11_f_g_h (psoap/matrix_functions.pyx:19-59,
+ * 99-146,149-201): full symmetric (N,N) matrix written IN PLACE into the
+ * caller's host array; sigma == NULL -> no noise term (the pyx contract);
+ * sigma != NULL fuses V11[diag] += sigma**2 (covariance.py:322). */
+int psoap_fill_sym(int device, int c, int N, const double *lwl, const double *gp,
+                   const double *sigma, double *out);
+/* fill_V12_f (psoap/matrix_functions.pyx:61-96): out (M,N),
+ * out[i,j] = amp^2 exp(p (lwl_col[j]-lwl_row[i])^2), M = len(lwl_row). */
+int psoap_fill_cross(int device, int M, int N, const double *lwl_row,
+                     const double *lwl_col, double amp, double l, double *out);
+
+/* ---- predict --------------------------------------------------------------------
+ * mode 0: joint conditional of the c components -- predict_f_g
+ *         (covariance.py:81-148), predict_f_g_h (:190-251):
+ *         mu (c*M), Sigma (c*M, c*M); mean offset fl - 1.0 (:140,:248).
+ * mode 1: conditional of the sum -- predict_f_g_sum (:151-187; 1e-8 nugget,
+ *         offset fl - 1.0), predict_f_g_h_sum (:253-297; offset fl - mu_c[0],
+ *         M == N): mu (M), Sigma (M, M).  mu_c[0] is mu_fg / mu_fgh.
+ * mode 2: single component predict_f (:25-54) with the evidently intended
+ *         N = len(lwl_predict) (the reference raises NameError at :38):
+ *         offset fl - mu_c[0].
+ * lwl (c,N), lwl_pred (c,M); Sigma_out may be NULL (get_Sigma=False, :145-148).
+ * status_out: 0 ok, 1 data covariance not positive definite (the reference
+ * raises LinAlgError there; outputs are then NaN). */
+int psoap_predict(int device, int mode, int c, int N, int M, const double *lwl,
+                  const double *fl, const double *sigma, const double *lwl_pred,
+                  const double *mu_c, const double *gp, double *mu_out,
+                  double *Sigma_out, int *status_out);
+
+/* ---- measurement ----------------------------------------------------------------
+ * With profiling on, every kernel launch of psoap_batch_eval is bracketed by
+ * hipEvents on its own stream (single stream group, so launches serialise);
+ * get_timings returns per-kernel-class totals of the LAST eval. */
+enum {
+    PSOAP_K_FILL = 0,
+    PSOAP_K_PANEL_UPDATE = 1, /* MFMA f64 left-looking panel update (dominant) */
+    PSOAP_K_POTRF = 2,
+    PSOAP_K_TRSM = 3,
+    PSOAP_K_MISC = 4,
+    PSOAP_K_CLASSES = 5
+};
+typedef struct {
+    double ms[PSOAP_K_CLASSES];      /* summed device time per class */
+    int64_t launches[PSOAP_K_CLASSES];
+    double flops[PSOAP_K_CLASSES];   /* executed flops per class (MFMA classes) */
+    double bytes[PSOAP_K_CLASSES];   /* algorithmic HBM bytes per class (fill) */
+    double total_ms;                 /* first launch -> last launch, event time */
+} psoap_timings;
+int psoap_chunk_set_profiling(psoap_chunk *h, int enabled);
+int psoap_chunk_get_timings(psoap_chunk *h, psoap_timings *t);
+/* Number of concurrent stream groups a batch is split into (default 2). */
+int psoap_chunk_set_stream_groups(psoap_chunk *h, int groups);
+
+/* fp64 MFMA / HBM micro-benchmarks used to state the measured peaks beside the
+ * spec peaks in bench.py (results in TFLOP/s and GB/s). */
+int psoap_microbench_mfma_f64(int device, double *tflops);
+int psoap_microbench_hbm(int device, double *write_gbs, double *copy_gbs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSOAP_GP_H */

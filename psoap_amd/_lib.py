@@ -1,0 +1,104 @@
+"""ctypes binding of include/psoap_gp.h.  No CPU fallback: if the HIP library is
+missing or a call fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+from .build import LIB_PATH
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_vp = ctypes.c_void_p
+
+K_CLASSES = 5
+K_NAMES = ("fill", "panel_update", "potrf", "trsm", "misc")
+
+
+class Timings(ctypes.Structure):
+    _fields_ = [("ms", ctypes.c_double * K_CLASSES),
+                ("launches", ctypes.c_int64 * K_CLASSES),
+                ("flops", ctypes.c_double * K_CLASSES),
+                ("bytes", ctypes.c_double * K_CLASSES),
+                ("total_ms", ctypes.c_double)]
+
+
+class PsoapError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); this table is also what tests check against the header
+SIGNATURES = {
+    "psoap_version": (ctypes.c_int, []),
+    "psoap_last_error": (ctypes.c_char_p, []),
+    "psoap_device_count": (ctypes.c_int, [_ip]),
+    "psoap_chunk_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_int]),
+    "psoap_chunk_destroy": (ctypes.c_int, [_vp]),
+    "psoap_chunk_set_data": (ctypes.c_int, [_vp, _dp, _dp]),
+    "psoap_chunk_set_grid": (ctypes.c_int, [_vp, _dp, _i32p, ctypes.c_int]),
+    "psoap_lnlike": (ctypes.c_int, [_vp, ctypes.c_int, _dp, _dp, ctypes.c_double, _dp]),
+    "psoap_lnlike_batch": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double, _dp]),
+    "psoap_batch_upload": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double]),
+    "psoap_batch_upload_velocities": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double]),
+    "psoap_batch_eval": (ctypes.c_int, [_vp]),
+    "psoap_batch_fetch": (ctypes.c_int, [_vp, _dp]),
+    "psoap_chunk_sync": (ctypes.c_int, [_vp]),
+    "psoap_fill_sym": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp]),
+    "psoap_fill_cross": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double,
+                                        ctypes.c_double, _dp]),
+    "psoap_predict": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp,
+                                     _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "psoap_chunk_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "psoap_chunk_get_timings": (ctypes.c_int, [_vp, ctypes.POINTER(Timings)]),
+    "psoap_chunk_set_stream_groups": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "psoap_microbench_mfma_f64": (ctypes.c_int, [ctypes.c_int, _dp]),
+    "psoap_microbench_hbm": (ctypes.c_int, [ctypes.c_int, _dp, _dp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libpsoap_gp.so (built by psoap_amd.build).  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PsoapError(
+            f"{LIB_PATH} not found: build it with `python -m psoap_amd.build` "
+            "(hipcc, gfx950).  There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().psoap_last_error()
+        raise PsoapError(f"{what}: {msg.decode() if msg else 'error'} (rc={rc})")
+
+
+def dptr(a: np.ndarray):
+    return a.ctypes.data_as(_dp)
+
+
+def as_f64(a, shape=None) -> np.ndarray:
+    out = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and out.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {out.shape}")
+    return out
+
+
+def default_device() -> int:
+    """PSOAP_DEVICE, else LOCAL_RANK (one process per GPU), else 0."""
+    for key in ("PSOAP_DEVICE", "LOCAL_RANK"):
+        if key in os.environ:
+            return int(os.environ[key])
+    return 0

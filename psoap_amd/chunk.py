@@ -1,0 +1,141 @@
+"""Persistent per-chunk device state and batched likelihood evaluation.
+
+Host-side counterpart of ``Worker.initialize`` / ``Worker.lnprob``
+(/root/reference/psoap/sample_parallel.py:126-198): ``fl`` and ``sigma`` stay
+resident in HBM, ``max_batch`` scratch matrices replace the single ``V11``
+(:163), and a whole batch of proposals is evaluated per call.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import K_NAMES, Timings, as_f64, check, dptr
+
+
+class ChunkHandle:
+    def __init__(self, fl, sigma, max_batch: int = 1, device: int | None = None):
+        self._L = _lib.load()
+        self.fl = as_f64(fl)
+        self.sigma = as_f64(sigma, self.fl.shape)
+        if self.fl.ndim != 1:
+            raise ValueError("fl and sigma must be 1-D")
+        self.N = int(self.fl.shape[0])
+        self.max_batch = int(max_batch)
+        self.device = _lib.default_device() if device is None else int(device)
+        self._h = ctypes.c_void_p()
+        check(self._L.psoap_chunk_create(ctypes.byref(self._h), self.device, self.N, dptr(self.fl),
+                                         dptr(self.sigma), self.max_batch), "psoap_chunk_create")
+        self._B = 0
+        self.n_epochs = 0
+
+    # -- lifetime -----------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.psoap_chunk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- configuration --------------------------------------------------------------
+    def set_data(self, fl, sigma):
+        self.fl = as_f64(fl, (self.N,))
+        self.sigma = as_f64(sigma, (self.N,))
+        check(self._L.psoap_chunk_set_data(self._h, dptr(self.fl), dptr(self.sigma)), "psoap_chunk_set_data")
+
+    def set_grid(self, lwl, epoch_index, n_epochs: int):
+        """Observed-frame ln-wavelengths + epoch of every pixel, for device-side Doppler shifts."""
+        lwl = as_f64(lwl, (self.N,))
+        ep = np.ascontiguousarray(epoch_index, dtype=np.int32)
+        if ep.shape != (self.N,):
+            raise ValueError("epoch_index must have shape (N,)")
+        check(self._L.psoap_chunk_set_grid(self._h, dptr(lwl), ep.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                           int(n_epochs)), "psoap_chunk_set_grid")
+        self.n_epochs = int(n_epochs)
+
+    def set_stream_groups(self, groups: int):
+        check(self._L.psoap_chunk_set_stream_groups(self._h, int(groups)), "psoap_chunk_set_stream_groups")
+
+    def set_profiling(self, enabled: bool):
+        check(self._L.psoap_chunk_set_profiling(self._h, int(bool(enabled))), "psoap_chunk_set_profiling")
+
+    # -- evaluation -----------------------------------------------------------------
+    def lnlike(self, lwls, gp, mu_GP: float = 1.0) -> float:
+        lwls = as_f64(np.atleast_2d(lwls))
+        c = lwls.shape[0]
+        lwls = as_f64(lwls, (c, self.N))
+        gp = as_f64(gp, (2 * c,))
+        out = np.empty(1)
+        check(self._L.psoap_lnlike(self._h, c, dptr(lwls), dptr(gp), float(mu_GP), dptr(out)), "psoap_lnlike")
+        return float(out[0])
+
+    def lnlike_batch(self, lwls, gps, mu_GP: float = 1.0) -> np.ndarray:
+        lwls = as_f64(lwls)
+        if lwls.ndim != 3 or lwls.shape[2] != self.N:
+            raise ValueError("lwls must have shape (B, c, N)")
+        B, c, _ = lwls.shape
+        gps = as_f64(gps, (B, 2 * c))
+        out = np.empty(B)
+        check(self._L.psoap_lnlike_batch(self._h, B, c, dptr(lwls), dptr(gps), float(mu_GP), dptr(out)),
+              "psoap_lnlike_batch")
+        return out
+
+    def upload(self, lwls, gps, mu_GP: float = 1.0):
+        lwls = as_f64(lwls)
+        B, c, _ = lwls.shape
+        lwls = as_f64(lwls, (B, c, self.N))
+        gps = as_f64(gps, (B, 2 * c))
+        check(self._L.psoap_batch_upload(self._h, B, c, dptr(lwls), dptr(gps), float(mu_GP)), "psoap_batch_upload")
+        self._B = B
+
+    def upload_velocities(self, velocities, gps, mu_GP: float = 1.0):
+        vel = as_f64(velocities)
+        if vel.ndim != 3 or vel.shape[2] != self.n_epochs:
+            raise ValueError("velocities must have shape (B, c, n_epochs); call set_grid first")
+        B, c, _ = vel.shape
+        gps = as_f64(gps, (B, 2 * c))
+        check(self._L.psoap_batch_upload_velocities(self._h, B, c, dptr(vel), dptr(gps), float(mu_GP)),
+              "psoap_batch_upload_velocities")
+        self._B = B
+
+    def eval(self):
+        check(self._L.psoap_batch_eval(self._h), "psoap_batch_eval")
+
+    def fetch(self) -> np.ndarray:
+        out = np.empty(self._B)
+        check(self._L.psoap_batch_fetch(self._h, dptr(out)), "psoap_batch_fetch")
+        return out
+
+    def sync(self):
+        check(self._L.psoap_chunk_sync(self._h), "psoap_chunk_sync")
+
+    def timings(self) -> dict:
+        t = Timings()
+        check(self._L.psoap_chunk_get_timings(self._h, ctypes.byref(t)), "psoap_chunk_get_timings")
+        out = {"total_ms": t.total_ms}
+        for k, name in enumerate(K_NAMES):
+            out[name] = {"ms": t.ms[k], "launches": int(t.launches[k]), "flops": t.flops[k], "bytes": t.bytes[k]}
+        return out
+
+
+def microbench(device: int | None = None) -> dict:
+    L = _lib.load()
+    dev = _lib.default_device() if device is None else device
+    tf = ctypes.c_double()
+    w = ctypes.c_double()
+    c = ctypes.c_double()
+    check(L.psoap_microbench_mfma_f64(dev, ctypes.byref(tf)), "psoap_microbench_mfma_f64")
+    check(L.psoap_microbench_hbm(dev, ctypes.byref(w), ctypes.byref(c)), "psoap_microbench_hbm")
+    return {"mfma_f64_tflops": tf.value, "hbm_write_gbs": w.value, "hbm_copy_gbs": c.value}

@@ -1,0 +1,175 @@
+// fill_kernels.hpp -- squared-exponential kernel-matrix fill (HBM-write-bound).
+//
+// Replaces the Cython loops of the reference's psoap/matrix_functions.pyx:
+//   fill_V11_f :19-59, fill_V11_f_g :99-146, fill_V11_f_g_h :149-201 (symmetric, C = 1,2,3)
+//   fill_V12_f :61-96 (rectangular)
+// and fuses `V11[diag] += sigma**2` (psoap/covariance.py:322,344,367).
+//
+// Layout: one 256-thread workgroup per 128 x 128 tile.  The tile's row
+// ln-wavelengths (C vectors x 128) are staged in LDS and read back as wave-uniform
+// broadcasts; each lane keeps the ln-wavelengths of its two adjacent columns in
+// registers, so a wave writes one full 1 KiB row segment per store instruction
+// (16 B per lane, coalesced).  Arithmetic mirrors the reference exactly
+// (no FMA contraction in p*r*r and in the component sum), so the only
+// difference from libm is the device exp().
+#pragma once
+#include "common.hpp"
+
+namespace psoap {
+
+struct GpDev {      // per-matrix hyper-parameters prepared on the device
+    double a2[3];   // amp^2                       (pyx:28)
+    double p2[3];   // -0.5 * c_kms^2 / l^2        (pyx:29)
+};
+
+__device__ inline void load_gp(const double* __restrict__ gp, int C, GpDev& g)
+{
+#pragma clang fp contract(off)
+    for (int c = 0; c < 3; ++c) {
+        if (c < C) {
+            double amp = gp[2 * c], l = gp[2 * c + 1];
+            g.a2[c] = amp * amp;
+            g.p2[c] = -0.5 * (C_KMS * C_KMS) / (l * l);
+        } else {
+            g.a2[c] = 0.0;
+            g.p2[c] = 0.0;
+        }
+    }
+}
+
+template <int C>
+__device__ __forceinline__ double kern_elem(const double (&xi)[C], const double (&xj)[C], const GpDev& g)
+{
+#pragma clang fp contract(off)
+    double cov = 0.0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        double r = xj[c] - xi[c];
+        double t = g.a2[c] * exp(g.p2[c] * r * r);
+        cov = (c == 0) ? t : cov + t;
+    }
+    return cov;
+}
+
+// Symmetric fill of a batch of padded matrices.
+//   Kbase + b*mat_stride : (Npad x ld) row-major; rows/cols >= N become identity
+//   lwl  : (B, C, N) device;  gp : (B, 2C) device;  sigma : (N) device or nullptr
+//   upper_only != 0: only tiles with tj >= ti are written (Cholesky input);
+//   otherwise grid.x spans all P*P tiles (full symmetric matrix, fill_V11_* contract).
+template <int C>
+__global__ __launch_bounds__(256) void k_fill_sym(double* __restrict__ Kbase, size_t mat_stride, int ld, int N,
+                                                  int P, const double* __restrict__ lwl,
+                                                  const double* __restrict__ gp,
+                                                  const double* __restrict__ sigma, int upper_only)
+{
+    __shared__ double xrow[C][NB];
+    __shared__ double srow[NB];
+    const int b = blockIdx.y;
+    int ti, tj;
+    if (upper_only) {
+        decode_upper(blockIdx.x, P, ti, tj);
+    } else {
+        ti = blockIdx.x / P;
+        tj = blockIdx.x % P;
+    }
+    const int tid = threadIdx.x;
+    const int i0 = ti * NB, j0 = tj * NB;
+    const double* lw = lwl + (size_t)b * C * N;
+    GpDev g;
+    load_gp(gp + (size_t)b * 2 * C, C, g);
+    double dsum = g.a2[0];
+    {
+#pragma clang fp contract(off)
+        for (int c = 1; c < C; ++c) dsum = dsum + g.a2[c];
+    }
+
+    if (tid < NB) {
+        int i = i0 + tid;
+#pragma unroll
+        for (int c = 0; c < C; ++c) xrow[c][tid] = (i < N) ? lw[(size_t)c * N + i] : 0.0;
+        double s = (sigma != nullptr && i < N) ? sigma[i] : 0.0;
+        srow[tid] = s * s;
+    }
+    const int col2 = tid & 63, w = tid >> 6;
+    const int ja = j0 + 2 * col2, jb = ja + 1;
+    double xa[C], xb[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        xa[c] = (ja < N) ? lw[(size_t)c * N + ja] : 0.0;
+        xb[c] = (jb < N) ? lw[(size_t)c * N + jb] : 0.0;
+    }
+    __syncthreads();
+
+    double* Km = Kbase + (size_t)b * mat_stride;
+#pragma unroll 4
+    for (int it = 0; it < NB / 4; ++it) {
+        const int r = w + 4 * it;
+        const int i = i0 + r;
+        double xi[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) xi[c] = xrow[c][r];
+        d2 v;
+        if (i < N) {
+            double va = (ja < N) ? kern_elem<C>(xi, xa, g) : 0.0;
+            double vb = (jb < N) ? kern_elem<C>(xi, xb, g) : 0.0;
+            // diagonal rule (pyx:56-57,144,201) + noise (covariance.py:322)
+            if (ja == i) va = dsum + srow[r];
+            if (jb == i) vb = dsum + srow[r];
+            v.x = va;
+            v.y = vb;
+        } else {
+            v.x = (ja == i) ? 1.0 : 0.0;
+            v.y = (jb == i) ? 1.0 : 0.0;
+        }
+        *reinterpret_cast<d2*>(Km + (size_t)i * ld + ja) = v;
+    }
+}
+
+// Rectangular cross fill (pyx:61-96): out (M x ld), out[i,j] = a2 * exp(p2 * (xcol[j]-xrow[i])^2).
+// grid.x = tiles over columns, grid.y = tiles over rows.
+__global__ __launch_bounds__(256) void k_fill_cross(double* __restrict__ out, int ld, int M, int Ncol,
+                                                    const double* __restrict__ xrow_g,
+                                                    const double* __restrict__ xcol_g, double amp, double l)
+{
+    __shared__ double xrow[NB];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.y * NB, j0 = blockIdx.x * NB;
+    GpDev g;
+    double gp[2] = {amp, l};
+    load_gp(gp, 1, g);
+    if (tid < NB) xrow[tid] = (i0 + tid < M) ? xrow_g[i0 + tid] : 0.0;
+    const int col2 = tid & 63, w = tid >> 6;
+    const int ja = j0 + 2 * col2, jb = ja + 1;
+    double xa[1], xb[1];
+    xa[0] = (ja < Ncol) ? xcol_g[ja] : 0.0;
+    xb[0] = (jb < Ncol) ? xcol_g[jb] : 0.0;
+    __syncthreads();
+    if (ja >= ld) return;
+#pragma unroll 4
+    for (int it = 0; it < NB / 4; ++it) {
+        const int r = w + 4 * it;
+        const int i = i0 + r;
+        if (i >= M) break;
+        double xi[1] = {xrow[r]};
+        d2 v;
+        v.x = (ja < Ncol) ? kern_elem<1>(xi, xa, g) : 0.0;
+        v.y = (jb < Ncol) ? kern_elem<1>(xi, xb, g) : 0.0;
+        *reinterpret_cast<d2*>(out + (size_t)i * ld + ja) = v;
+    }
+}
+
+// Device-side Doppler shift (replicate_wls + lredshift, psoap/data.py:37,61):
+//   lwl_out[b,c,i] = lwl[i] + (-vel[b,c,epoch[i]]) / c_kms
+__global__ void k_doppler_shift(double* __restrict__ lwl_out, const double* __restrict__ lwl,
+                                const int32_t* __restrict__ epoch, const double* __restrict__ vel, int N,
+                                int n_epochs, int BC)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int bc = blockIdx.y;
+    if (i < N && bc < BC) {
+        double v = vel[(size_t)bc * n_epochs + epoch[i]];
+        lwl_out[(size_t)bc * N + i] = lwl[i] + (-v) / C_KMS;
+    }
+}
+
+}  // namespace psoap

@@ -1,0 +1,112 @@
+// gemm_core.hpp -- the fp64 MFMA tile engine shared by every blocked kernel.
+//
+// One 256-thread workgroup (4 waves as 2 x 2) accumulates a 128 x 128 tile
+//     acc[m][n] += sum_k Aop[k][m] * Bop[k][n]
+// where both operands are "k-major" strips in global memory: row k is 128
+// contiguous doubles (1 KiB) at Aop + k*lda.  That is how an upper Cholesky
+// factor stored row-major presents its block columns, so no transposes are ever
+// materialised.  K must be a multiple of KB (16).
+//
+// Pipeline per KB-chunk: 8 x global_load_dwordx4 per thread into registers for
+// chunk c+1 (one wave covers one full 1 KiB row per instruction) -> 64 x
+// v_mfma_f64_16x16x4_f64 per wave on chunk c out of LDS -> ds_write_b128 of
+// chunk c+1 into the other LDS buffer -> one barrier.  LDS rows are padded to
+// 144 doubles so the four k-rows of a fragment read land on disjoint banks.
+//
+// Fragment maps (cdna_hip_programming.md section 3, f64 16x16x4):
+//   A lane l: A[i = l&15][k = l>>4];  B lane l: B[k = l>>4][j = l&15]
+//   D lane l, reg r: D[row = (l>>4) + 4r][col = l&15]
+// Each wave owns a 64 x 64 sub-tile = 4 x 4 MFMA tiles = 16 accumulators (128 VGPRs).
+#pragma once
+#include "common.hpp"
+
+namespace psoap {
+
+struct Tile {
+    d4 acc[4][4];
+    __device__ __forceinline__ void zero()
+    {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = d4{0.0, 0.0, 0.0, 0.0};
+    }
+};
+
+struct Staging {
+    d2 a[4], b[4];
+};
+
+__device__ __forceinline__ void stage_load(Staging& s, const double* __restrict__ A, size_t lda,
+                                           const double* __restrict__ B, size_t ldb, int k, int tid)
+{
+    const int col2 = tid & 63, row0 = tid >> 6;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const size_t row = (size_t)(k + row0 + 4 * it);
+        s.a[it] = *reinterpret_cast<const d2*>(A + row * lda + 2 * col2);
+        s.b[it] = *reinterpret_cast<const d2*>(B + row * ldb + 2 * col2);
+    }
+}
+
+__device__ __forceinline__ void stage_store(const Staging& s, double* sA, double* sB, int tid)
+{
+    const int col2 = tid & 63, row0 = tid >> 6;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        *reinterpret_cast<d2*>(sA + (row0 + 4 * it) * LDS_LD + 2 * col2) = s.a[it];
+        *reinterpret_cast<d2*>(sB + (row0 + 4 * it) * LDS_LD + 2 * col2) = s.b[it];
+    }
+}
+
+__device__ __forceinline__ void tile_mma_chunk(Tile& t, const double* sA, const double* sB, int wr, int wc,
+                                               int lane)
+{
+    const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < KB / 4; ++ks) {
+        double a[4], b[4];
+        const double* pa = sA + (ks * 4 + fk) * LDS_LD + wr * 64 + fr;
+        const double* pb = sB + (ks * 4 + fk) * LDS_LD + wc * 64 + fr;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = pa[m * 16];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) b[n] = pb[n * 16];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                t.acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], t.acc[m][n], 0, 0, 0);
+    }
+}
+
+// smem: GEMM_LDS_BYTES of dynamic LDS.  All 256 threads must call this.
+__device__ __forceinline__ void tile_gemm_tn(Tile& t, const double* __restrict__ A, size_t lda,
+                                             const double* __restrict__ B, size_t ldb, int K, double* smem)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    double* sA[2] = {smem, smem + 2 * KB * LDS_LD};
+    double* sB[2] = {smem + KB * LDS_LD, smem + 3 * KB * LDS_LD};
+    if (K <= 0) return;
+    Staging s;
+    stage_load(s, A, lda, B, ldb, 0, tid);
+    stage_store(s, sA[0], sB[0], tid);
+    __syncthreads();
+    const int nchunk = K / KB;
+    for (int c = 0; c < nchunk; ++c) {
+        const int cur = c & 1;
+        const bool more = (c + 1 < nchunk);
+        if (more) stage_load(s, A, lda, B, ldb, (c + 1) * KB, tid);
+        tile_mma_chunk(t, sA[cur], sB[cur], wr, wc, lane);
+        if (more) stage_store(s, sA[cur ^ 1], sB[cur ^ 1], tid);
+        __syncthreads();
+    }
+}
+
+// element coordinates of accumulator (m, n, reg) inside the 128 x 128 tile
+__device__ __forceinline__ int tile_row(int wr, int m, int lane, int r) { return wr * 64 + m * 16 + (lane >> 4) + 4 * r; }
+__device__ __forceinline__ int tile_col(int wc, int n, int lane) { return wc * 64 + n * 16 + (lane & 15); }
+
+}  // namespace psoap

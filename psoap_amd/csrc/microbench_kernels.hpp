@@ -1,0 +1,109 @@
+// microbench_kernels.hpp -- measured ceilings quoted next to the spec peaks in bench.py:
+// back-to-back v_mfma_f64_16x16x4_f64 issue rate and streaming HBM write / copy bandwidth.
+#pragma once
+#include <string>
+
+#include "common.hpp"
+
+namespace psoap {
+
+// Every SIMD of every CU issues independent fp64 MFMAs from registers (4 accumulator
+// chains per wave, 2 waves per SIMD).  2048 flop per instruction.
+__global__ __launch_bounds__(512) void k_mfma_f64_peak(double* out, int iters)
+{
+    const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    d4 acc0 = {0, 0, 0, 0}, acc1 = {1, 1, 1, 1}, acc2 = {2, 2, 2, 2}, acc3 = {3, 3, 3, 3};
+    for (int i = 0; i < iters; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc3, 0, 0, 0);
+    }
+    d4 s = acc0 + acc1 + acc2 + acc3;
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678) out[0] = s[0];  // keep the chain alive
+}
+
+__global__ void k_stream_write(d2* __restrict__ dst, size_t n2, double v)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    d2 val = {v, v};
+    for (; i < n2; i += stride) dst[i] = val;
+}
+
+__global__ void k_stream_copy(d2* __restrict__ dst, const d2* __restrict__ src, size_t n2)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n2; i += stride) dst[i] = src[i];
+}
+
+#define MB_TRY(expr)                                                              \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) {                                                   \
+            err = std::string(#expr) + ": " + hipGetErrorString(_e);              \
+            return 1;                                                             \
+        }                                                                         \
+    } while (0)
+
+inline int microbench_mfma(double* tflops, std::string& err)
+{
+    hipDeviceProp_t prop;
+    int dev = 0;
+    MB_TRY(hipGetDevice(&dev));
+    MB_TRY(hipGetDeviceProperties(&prop, dev));
+    const int blocks = prop.multiProcessorCount * 2;  // 2 x 512 threads = 4 waves per SIMD
+    const int iters = 20000;
+    double* d = nullptr;
+    MB_TRY(hipMalloc(&d, 64));
+    hipEvent_t e0, e1;
+    MB_TRY(hipEventCreate(&e0));
+    MB_TRY(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_mfma_f64_peak, dim3(blocks), dim3(512), 0, 0, d, 1000);  // warm-up
+    MB_TRY(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_mfma_f64_peak, dim3(blocks), dim3(512), 0, 0, d, iters);
+    MB_TRY(hipEventRecord(e1, 0));
+    MB_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MB_TRY(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = (double)blocks * 8 /*waves*/ * iters * 4.0 * 2048.0;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d);
+    return 0;
+}
+
+inline int microbench_hbm(double* write_gbs, double* copy_gbs, std::string& err)
+{
+    const size_t bytes = (size_t)2 << 30;  // 2 GiB per buffer: far beyond the 256 MiB Infinity Cache
+    d2 *a = nullptr, *b = nullptr;
+    MB_TRY(hipMalloc(&a, bytes));
+    MB_TRY(hipMalloc(&b, bytes));
+    const size_t n2 = bytes / sizeof(d2);
+    hipEvent_t e0, e1;
+    MB_TRY(hipEventCreate(&e0));
+    MB_TRY(hipEventCreate(&e1));
+    float ms = 0.f;
+    hipLaunchKernelGGL(k_stream_write, dim3(2048), dim3(256), 0, 0, a, n2, 1.0);
+    MB_TRY(hipEventRecord(e0, 0));
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_stream_write, dim3(2048), dim3(256), 0, 0, b, n2, 2.0);
+    MB_TRY(hipEventRecord(e1, 0));
+    MB_TRY(hipEventSynchronize(e1));
+    MB_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *write_gbs = 5.0 * bytes / (ms * 1e-3) / 1e9;
+    MB_TRY(hipEventRecord(e0, 0));
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_stream_copy, dim3(2048), dim3(256), 0, 0, b, a, n2);
+    MB_TRY(hipEventRecord(e1, 0));
+    MB_TRY(hipEventSynchronize(e1));
+    MB_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *copy_gbs = 5.0 * 2.0 * bytes / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    return 0;
+}
+
+}  // namespace psoap

@@ -1,0 +1,301 @@
+// predict_kernels.hpp -- GP conditional mean / covariance (the predict_* family).
+//
+// Reference (psoap/covariance.py): predict_f :25-54, predict_f_g :81-148,
+// predict_f_g_sum :151-187, predict_f_g_h :190-251, predict_f_g_h_sum :253-297.
+//
+// All of them are   mu = m0 + Cx B^-1 (fl - off),   Sigma = A - Cx B^-1 Cx^T
+// with B the noisy data covariance.  On the device B = U^T U is factored by the same
+// left-looking kernels as the likelihood, with Cx^T appended to B as extra column tiles
+// ([B | Cx^T], Npad x (Npad + Rpad)): the panel update and the strip solve then turn those
+// columns into W = U^-T Cx^T in place, the right-hand side r = fl - off becomes z = U^-T r,
+// and
+//     mu = m0 + W^T z            (k_gemv_t, deterministic two-stage reduction)
+//     Sigma = A - W^T W          (k_syrk_sub, fp64 MFMA tiles, K = Npad)
+// so no explicit inverse or second triangular solve is needed.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "chol_kernels.hpp"
+#include "fill_kernels.hpp"
+
+namespace psoap {
+
+struct GpHost {
+    double v[6];
+};
+
+// out[i][col0 + j] = sum_{c<C} a_c^2 exp(p_c (xcol_c[j] - xrow_c[i])^2),  i < nrows, j < ncols
+// (fill_V12_f semantics, pyx:61-96, summed over components left to right as the reference
+// sums V12_f + V12_g (+ V12_h), covariance.py:171,279).  With sym_diag the i == j entries
+// follow the fill_V11_f diagonal rule plus `nugget` (pyx:56-57; covariance.py:165).
+// Scalar stores: column offsets in the predict layout are not 16-byte aligned.
+template <int C>
+__global__ __launch_bounds__(256) void k_fill_region(double* __restrict__ out, size_t ld, int col0, int nrows,
+                                                     int ncols, const double* __restrict__ xrow, size_t xrow_stride,
+                                                     const double* __restrict__ xcol, size_t xcol_stride, GpHost gph,
+                                                     int sym_diag, double nugget)
+{
+    __shared__ double xr[C][NB];
+    const int tid = threadIdx.x;
+    const int i0 = blockIdx.y * NB, j0 = blockIdx.x * NB;
+    GpDev g;
+    load_gp(gph.v, C, g);
+    double dsum = g.a2[0];
+    {
+#pragma clang fp contract(off)
+        for (int c = 1; c < C; ++c) dsum = dsum + g.a2[c];
+    }
+    if (tid < NB) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) xr[c][tid] = (i0 + tid < nrows) ? xrow[c * xrow_stride + i0 + tid] : 0.0;
+    }
+    const int col = tid & 127, half = tid >> 7;
+    const int j = j0 + col;
+    double xj[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) xj[c] = (j < ncols) ? xcol[c * xcol_stride + j] : 0.0;
+    __syncthreads();
+    if (j >= ncols) return;
+    for (int it = 0; it < NB / 2; ++it) {
+        const int r = half + 2 * it;
+        const int i = i0 + r;
+        if (i >= nrows) break;
+        double xi[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) xi[c] = xr[c][r];
+        double v = kern_elem<C>(xi, xj, g);
+        if (sym_diag && i == j) {
+#pragma clang fp contract(off)
+            v = dsum + nugget;
+        }
+        out[(size_t)i * ld + col0 + j] = v;
+    }
+}
+
+// S tile (ti, tj) -= sum_k W[k][128 ti + .] W[k][128 tj + .]   (all tiles; Sigma is returned in full)
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_sub(const double* __restrict__ W, size_t ldw, int K,
+                                                             double* __restrict__ S, size_t lds)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    Tile t;
+    t.zero();
+    tile_gemm_tn(t, W + (size_t)NB * ti, ldw, W + (size_t)NB * tj, ldw, K, smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* p = S + (size_t)(NB * ti + tile_row(wr, m, lane, r)) * lds + NB * tj + tile_col(wc, n, lane);
+                *p = *p - t.acc[m][n][r];
+            }
+}
+
+// partial[s][q] = sum_{k in slab s} W[k][q] z[k];  slabs of 256 rows, 128 columns per block
+__global__ __launch_bounds__(256) void k_gemv_t_partial(const double* __restrict__ W, size_t ldw, int K, int ncols,
+                                                        const double* __restrict__ z, double* __restrict__ partial)
+{
+    __shared__ double red[128];
+    const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const int q = blockIdx.x * 128 + col;
+    const int k0 = blockIdx.y * 256;
+    double s = 0.0;
+    if (q < ncols) {
+        for (int k = k0 + half; k < k0 + 256 && k < K; k += 2) s = fma(W[(size_t)k * ldw + q], z[k], s);
+    }
+    if (half == 1) red[col] = s;
+    __syncthreads();
+    if (half == 0 && q < ncols) partial[(size_t)blockIdx.y * ncols + q] = s + red[col];
+}
+
+__global__ void k_gemv_finish(const double* __restrict__ partial, int nslab, int ncols,
+                              const double* __restrict__ m0, double* __restrict__ mu)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ncols) return;
+    double s = 0.0;
+    for (int k = 0; k < nslab; ++k) s += partial[(size_t)k * ncols + q];
+    mu[q] = m0[q] + s;
+}
+
+__global__ void k_zero(double* __restrict__ p, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = 0.0;
+}
+
+inline hipError_t predict_configure_kernels()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_sub), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)GEMM_LDS_BYTES);
+}
+
+#define PR_TRY(expr)                                                 \
+    do {                                                             \
+        hipError_t _e = (expr);                                      \
+        if (_e != hipSuccess) {                                      \
+            err = std::string(#expr) + ": " + hipGetErrorString(_e); \
+            rc = 1;                                                  \
+            goto done;                                               \
+        }                                                            \
+    } while (0)
+
+template <int C>
+static void launch_region(double* out, size_t ld, int col0, int nrows, int ncols, const double* xrow, size_t xrs,
+                          const double* xcol, size_t xcs, const GpHost& g, int sym, double nug)
+{
+    dim3 grid((ncols + NB - 1) / NB, (nrows + NB - 1) / NB);
+    hipLaunchKernelGGL(k_fill_region<C>, grid, dim3(256), 0, 0, out, ld, col0, nrows, ncols, xrow, xrs, xcol, xcs, g,
+                       sym, nug);
+}
+
+static void launch_region_c(int C, double* out, size_t ld, int col0, int nrows, int ncols, const double* xrow,
+                            size_t xrs, const double* xcol, size_t xcs, const GpHost& g, int sym, double nug)
+{
+    if (C == 1) launch_region<1>(out, ld, col0, nrows, ncols, xrow, xrs, xcol, xcs, g, sym, nug);
+    else if (C == 2) launch_region<2>(out, ld, col0, nrows, ncols, xrow, xrs, xcol, xcs, g, sym, nug);
+    else launch_region<3>(out, ld, col0, nrows, ncols, xrow, xrs, xcol, xcs, g, sym, nug);
+}
+
+// mode 0: components (predict_f_g / predict_f_g_h); 1: sum (predict_f_g_sum / _h_sum); 2: predict_f
+inline int predict_run(int mode, int c, int N, int M, const double* lwl, const double* fl, const double* sigma,
+                       const double* lwl_pred, const double* mu_c, const double* gp, double* mu_out,
+                       double* Sigma_out, int* status, std::string& err)
+{
+    int rc = 0;
+    const int Npad = round_up(N, NB), P = Npad / NB;
+    const bool transposed_mean = (mode == 1 && c == 3);  // covariance.py:294 uses V12.T in the mean
+    if (transposed_mean && M != N) {
+        err = "predict_f_g_h_sum is only defined for len(lwl_predict) == len(lwl) (covariance.py:294)";
+        return 2;
+    }
+    const int Rq = (mode == 0) ? c * M : M;             // columns of W that feed Sigma
+    const int Rq_pad = round_up(Rq, NB);
+    const int Rx = transposed_mean ? N : 0;             // extra block holding U^-T V12 for the :294 mean
+    const int Rx_pad = round_up(Rx, NB);
+    const int Rtot_pad = Rq_pad + Rx_pad;
+    const size_t ld = (size_t)Npad + Rtot_pad;
+    const int Mt = Rtot_pad / NB;
+    const double offset = (mode == 0 || (mode == 1 && c == 2)) ? 1.0 : mu_c[0];  // :140,:184,:248 vs :52,:294
+    const int nslab = (Npad + 255) / 256;
+
+    double *dK = nullptr, *dW = nullptr, *dR = nullptr, *dLwl = nullptr, *dPred = nullptr, *dFl = nullptr,
+           *dSig = nullptr, *dGp = nullptr, *dS = nullptr, *dMu = nullptr, *dM0 = nullptr, *dPart = nullptr,
+           *dOut = nullptr;
+    MatAcc* dAcc = nullptr;
+    std::vector<double> m0(Rq);
+    MatAcc hacc;
+    GpHost gall;
+    for (int k = 0; k < 6; ++k) gall.v[k] = (k < 2 * c) ? gp[k] : 0.0;
+
+    PR_TRY(hipMalloc(&dK, sizeof(double) * (size_t)Npad * ld));
+    PR_TRY(hipMalloc(&dW, sizeof(double) * NB * NB));
+    PR_TRY(hipMalloc(&dR, sizeof(double) * Npad));
+    PR_TRY(hipMalloc(&dAcc, sizeof(MatAcc)));
+    PR_TRY(hipMalloc(&dLwl, sizeof(double) * (size_t)c * N));
+    PR_TRY(hipMalloc(&dPred, sizeof(double) * (size_t)c * M));
+    PR_TRY(hipMalloc(&dFl, sizeof(double) * N));
+    PR_TRY(hipMalloc(&dSig, sizeof(double) * N));
+    PR_TRY(hipMalloc(&dGp, sizeof(double) * 6));
+    PR_TRY(hipMalloc(&dMu, sizeof(double) * Rq_pad));
+    PR_TRY(hipMalloc(&dM0, sizeof(double) * Rq_pad));
+    PR_TRY(hipMalloc(&dPart, sizeof(double) * (size_t)nslab * (Rtot_pad)));
+    PR_TRY(hipMalloc(&dOut, sizeof(double)));
+    PR_TRY(hipMemcpy(dLwl, lwl, sizeof(double) * (size_t)c * N, hipMemcpyHostToDevice));
+    PR_TRY(hipMemcpy(dPred, lwl_pred, sizeof(double) * (size_t)c * M, hipMemcpyHostToDevice));
+    PR_TRY(hipMemcpy(dFl, fl, sizeof(double) * N, hipMemcpyHostToDevice));
+    PR_TRY(hipMemcpy(dSig, sigma, sizeof(double) * N, hipMemcpyHostToDevice));
+    PR_TRY(hipMemcpy(dGp, gp, sizeof(double) * 2 * c, hipMemcpyHostToDevice));
+
+    // [B | Cx^T]: zero the appended columns (padding rows/cols must be exact zeros), fill B's upper tiles
+    hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, 0, dK, (size_t)Npad * ld);
+    {
+        dim3 grid(P * (P + 1) / 2, 1);
+        if (c == 1) hipLaunchKernelGGL(k_fill_sym<1>, grid, dim3(256), 0, 0, dK, (size_t)0, (int)ld, N, P, dLwl, dGp, dSig, 1);
+        else if (c == 2) hipLaunchKernelGGL(k_fill_sym<2>, grid, dim3(256), 0, 0, dK, (size_t)0, (int)ld, N, P, dLwl, dGp, dSig, 1);
+        else hipLaunchKernelGGL(k_fill_sym<3>, grid, dim3(256), 0, 0, dK, (size_t)0, (int)ld, N, P, dLwl, dGp, dSig, 1);
+    }
+    PR_TRY(hipGetLastError());
+    if (mode == 0) {
+        // C = vstack(V12_f, V12_g, ..) (:136,:246): column block k of Cx^T is component k alone
+        for (int k = 0; k < c; ++k) {
+            GpHost g1;
+            g1.v[0] = gp[2 * k];
+            g1.v[1] = gp[2 * k + 1];
+            launch_region<1>(dK, ld, Npad + k * M, N, M, dLwl + (size_t)k * N, 0, dPred + (size_t)k * M, 0, g1, 0, 0.0);
+        }
+    } else {
+        // V12 = V12_f + V12_g (+ V12_h) (:171,:279); predict_f's single V12 (:39-40) is the C = 1 case
+        launch_region_c(c, dK, ld, Npad, N, M, dLwl, (size_t)N, dPred, (size_t)M, gall, 0, 0.0);
+        if (transposed_mean)  // rows indexed by the prediction grid, columns by the data grid (M == N)
+            launch_region_c(c, dK, ld, Npad + Rq_pad, N, N, dPred, (size_t)M, dLwl, (size_t)N, gall, 0, 0.0);
+    }
+    PR_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_init_rhs, dim3((Npad + 255) / 256, 1), dim3(256), 0, 0, dR, Npad, N, dFl, offset, dAcc);
+    PR_TRY(hipGetLastError());
+
+    for (int p = 0; p < P; ++p) {
+        const int k0 = p * NB;
+        const int ntile = P - p + Mt;
+        if (p > 0)
+            hipLaunchKernelGGL(k_panel_update, dim3(ntile, 1), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dK, (size_t)0,
+                               (int)ld, k0);
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), 0, 0, dK, (size_t)0, (int)ld, k0, dW, dR, Npad, dAcc);
+        if (ntile > 1)
+            hipLaunchKernelGGL(k_trsm_strip, dim3(ntile - 1, 1), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dK, (size_t)0,
+                               (int)ld, k0, dW, dR, Npad);
+        PR_TRY(hipGetLastError());
+    }
+    PR_TRY(hipMemcpy(&hacc, dAcc, sizeof(MatAcc), hipMemcpyDeviceToHost));
+    *status = (hacc.info != 0.0) ? 1 : 0;
+
+    // mean: m0 + W^T z  (W is the block that matches the reference's orientation for this mode)
+    for (int q = 0; q < Rq; ++q) m0[q] = (mode == 0) ? mu_c[q / M] : mu_c[0];
+    PR_TRY(hipMemcpy(dM0, m0.data(), sizeof(double) * Rq, hipMemcpyHostToDevice));
+    {
+        const double* Wmean = dK + Npad + (transposed_mean ? Rq_pad : 0);
+        hipLaunchKernelGGL(k_gemv_t_partial, dim3((Rq + 127) / 128, nslab), dim3(256), 0, 0, Wmean, ld, Npad, Rq, dR,
+                           dPart);
+        hipLaunchKernelGGL(k_gemv_finish, dim3((Rq + 255) / 256), dim3(256), 0, 0, dPart, nslab, Rq, dM0, dMu);
+        PR_TRY(hipGetLastError());
+    }
+    PR_TRY(hipMemcpy(mu_out, dMu, sizeof(double) * Rq, hipMemcpyDeviceToHost));
+
+    if (Sigma_out) {
+        const int St = Rq_pad / NB;
+        PR_TRY(hipMalloc(&dS, sizeof(double) * (size_t)Rq_pad * Rq_pad));
+        hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, 0, dS, (size_t)Rq_pad * Rq_pad);
+        if (mode == 0) {
+            // A = blockdiag(V11_f_predict, V11_g_predict, ..)  (:124-125,:234-236)
+            for (int k = 0; k < c; ++k) {
+                GpHost g1;
+                g1.v[0] = gp[2 * k];
+                g1.v[1] = gp[2 * k + 1];
+                launch_region<1>(dS + (size_t)k * M * Rq_pad, (size_t)Rq_pad, k * M, M, M, dPred + (size_t)k * M, 0,
+                                 dPred + (size_t)k * M, 0, g1, 1, 0.0);
+            }
+        } else {
+            // V11 = sum of the component priors; 1e-8 nugget only in the two-component sum (:165 vs :271)
+            const double nug = (mode == 1 && c == 2) ? 1e-8 : 0.0;
+            launch_region_c(c, dS, (size_t)Rq_pad, 0, M, M, dPred, (size_t)M, dPred, (size_t)M, gall, 1, nug);
+        }
+        PR_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_syrk_sub, dim3(St, St), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dK + Npad, ld, Npad, dS,
+                           (size_t)Rq_pad);
+        PR_TRY(hipGetLastError());
+        PR_TRY(hipMemcpy2D(Sigma_out, sizeof(double) * Rq, dS, sizeof(double) * Rq_pad, sizeof(double) * Rq, Rq,
+                           hipMemcpyDeviceToHost));
+    }
+    PR_TRY(hipDeviceSynchronize());
+done:
+    (void)hipFree(dK); (void)hipFree(dW); (void)hipFree(dR); (void)hipFree(dAcc); (void)hipFree(dLwl); (void)hipFree(dPred); (void)hipFree(dFl);
+    (void)hipFree(dSig); (void)hipFree(dGp); (void)hipFree(dS); (void)hipFree(dMu); (void)hipFree(dM0); (void)hipFree(dPart); (void)hipFree(dOut);
+    return rc;
+}
+
+}  // namespace psoap

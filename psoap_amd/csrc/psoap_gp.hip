@@ -1,0 +1,520 @@
+// psoap_gp.hip -- C ABI (include/psoap_gp.h) over the gfx950 kernels.
+// Host side only: device memory, streams, launch sequencing, error mapping.
+#include "../../include/psoap_gp.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "chol_kernels.hpp"
+#include "fill_kernels.hpp"
+#include "microbench_kernels.hpp"
+#include "predict_kernels.hpp"
+
+using namespace psoap;
+
+static thread_local std::string g_err;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            char _buf[512];                                                                        \
+            snprintf(_buf, sizeof _buf, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                     __LINE__);                                                                    \
+            g_err = _buf;                                                                          \
+            return 1;                                                                              \
+        }                                                                                          \
+    } while (0)
+
+#define FAIL(msg)                \
+    do {                         \
+        g_err = std::string(msg); \
+        return 2;                \
+    } while (0)
+
+static const int MAX_GROUPS = 8;
+
+struct psoap_chunk {
+    int device = 0;
+    int N = 0, Npad = 0, ld = 0, P = 0;
+    int max_batch = 0;
+    size_t mat_stride = 0;
+    // resident data
+    double* dFl = nullptr;
+    double* dSigma = nullptr;
+    double* dGrid = nullptr;
+    int32_t* dEpoch = nullptr;
+    int n_epochs = 0;
+    // workspaces
+    double* dK = nullptr;    // max_batch x Npad x ld
+    double* dWt = nullptr;   // max_batch x 128 x 128
+    double* dR = nullptr;    // max_batch x Npad
+    MatAcc* dAcc = nullptr;  // max_batch
+    double* dLwl = nullptr;  // max_batch x 3 x N
+    double* dGp = nullptr;   // max_batch x 6
+    double* dVel = nullptr;  // max_batch x 3 x n_epochs
+    double* dOut = nullptr;  // max_batch
+    // pinned host staging
+    double* hLwl = nullptr;
+    double* hGp = nullptr;
+    double* hVel = nullptr;
+    double* hOut = nullptr;
+    // current batch
+    int B = 0, C = 0;
+    double mu = 1.0;
+    std::vector<char> neg;  // per-proposal: a hyper-parameter was negative -> -inf
+    // execution
+    int groups = 2;
+    hipStream_t streams[MAX_GROUPS] = {};
+    hipEvent_t evUpload = nullptr;
+    hipEvent_t evDone[MAX_GROUPS] = {};
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> evPool;
+    struct Rec {
+        int cls;
+        int e0, e1;
+        double flops, bytes;
+    };
+    std::vector<Rec> recs;
+    psoap_timings last = {};
+};
+
+static int set_dev(const psoap_chunk* h) { HIP_TRY(hipSetDevice(h->device)); return 0; }
+
+extern "C" int psoap_version(void) { return 1; }
+extern "C" const char* psoap_last_error(void) { return g_err.c_str(); }
+
+extern "C" int psoap_device_count(int* count)
+{
+    HIP_TRY(hipGetDeviceCount(count));
+    return 0;
+}
+
+static int configure_kernels()
+{
+    static bool done = false;
+    if (done) return 0;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel_update),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_strip),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
+    HIP_TRY(predict_configure_kernels());
+    done = true;
+    return 0;
+}
+
+extern "C" int psoap_chunk_create(psoap_chunk** out, int device, int N, const double* fl, const double* sigma,
+                                  int max_batch)
+{
+    if (!out || N <= 0 || max_batch <= 0 || !fl || !sigma) FAIL("psoap_chunk_create: bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    if (configure_kernels()) return 1;
+    psoap_chunk* h = new psoap_chunk();
+    h->device = device;
+    h->N = N;
+    h->Npad = round_up(N, NB);
+    h->ld = h->Npad;
+    h->P = h->Npad / NB;
+    h->max_batch = max_batch;
+    h->mat_stride = (size_t)h->Npad * h->ld;
+    const size_t nb = (size_t)max_batch;
+    HIP_TRY(hipMalloc(&h->dFl, sizeof(double) * N));
+    HIP_TRY(hipMalloc(&h->dSigma, sizeof(double) * N));
+    HIP_TRY(hipMalloc(&h->dK, sizeof(double) * nb * h->mat_stride));
+    HIP_TRY(hipMalloc(&h->dWt, sizeof(double) * nb * NB * NB));
+    HIP_TRY(hipMalloc(&h->dR, sizeof(double) * nb * h->Npad));
+    HIP_TRY(hipMalloc(&h->dAcc, sizeof(MatAcc) * nb));
+    HIP_TRY(hipMalloc(&h->dLwl, sizeof(double) * nb * 3 * N));
+    HIP_TRY(hipMalloc(&h->dGp, sizeof(double) * nb * 6));
+    HIP_TRY(hipMalloc(&h->dOut, sizeof(double) * nb));
+    HIP_TRY(hipHostMalloc(&h->hLwl, sizeof(double) * nb * 3 * N));
+    HIP_TRY(hipHostMalloc(&h->hGp, sizeof(double) * nb * 6));
+    HIP_TRY(hipHostMalloc(&h->hOut, sizeof(double) * nb));
+    for (int g = 0; g < MAX_GROUPS; ++g) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->streams[g], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&h->evDone[g], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&h->evUpload, hipEventDisableTiming));
+    HIP_TRY(hipMemcpy(h->dFl, fl, sizeof(double) * N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->dSigma, sigma, sizeof(double) * N, hipMemcpyHostToDevice));
+    *out = h;
+    return 0;
+}
+
+extern "C" int psoap_chunk_destroy(psoap_chunk* h)
+{
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(h->dFl); (void)hipFree(h->dSigma); (void)hipFree(h->dGrid); (void)hipFree(h->dEpoch);
+    (void)hipFree(h->dK); (void)hipFree(h->dWt); (void)hipFree(h->dR); (void)hipFree(h->dAcc);
+    (void)hipFree(h->dLwl); (void)hipFree(h->dGp); (void)hipFree(h->dVel); (void)hipFree(h->dOut);
+    (void)hipHostFree(h->hLwl); (void)hipHostFree(h->hGp); (void)hipHostFree(h->hVel); (void)hipHostFree(h->hOut);
+    for (int g = 0; g < MAX_GROUPS; ++g) {
+        if (h->streams[g]) (void)hipStreamDestroy(h->streams[g]);
+        if (h->evDone[g]) (void)hipEventDestroy(h->evDone[g]);
+    }
+    if (h->evUpload) (void)hipEventDestroy(h->evUpload);
+    for (auto e : h->evPool) (void)hipEventDestroy(e);
+    delete h;
+    return 0;
+}
+
+extern "C" int psoap_chunk_set_data(psoap_chunk* h, const double* fl, const double* sigma)
+{
+    if (!h || !fl || !sigma) FAIL("psoap_chunk_set_data: bad arguments");
+    if (set_dev(h)) return 1;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h->dFl, fl, sizeof(double) * h->N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->dSigma, sigma, sizeof(double) * h->N, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int psoap_chunk_set_grid(psoap_chunk* h, const double* lwl, const int32_t* epoch, int n_epochs)
+{
+    if (!h || !lwl || !epoch || n_epochs <= 0) FAIL("psoap_chunk_set_grid: bad arguments");
+    for (int i = 0; i < h->N; ++i)
+        if (epoch[i] < 0 || epoch[i] >= n_epochs) FAIL("psoap_chunk_set_grid: epoch index out of range");
+    if (set_dev(h)) return 1;
+    HIP_TRY(hipDeviceSynchronize());
+    if (!h->dGrid) HIP_TRY(hipMalloc(&h->dGrid, sizeof(double) * h->N));
+    if (!h->dEpoch) HIP_TRY(hipMalloc(&h->dEpoch, sizeof(int32_t) * h->N));
+    if (h->dVel) { HIP_TRY(hipFree(h->dVel)); h->dVel = nullptr; }
+    if (h->hVel) { HIP_TRY(hipHostFree(h->hVel)); h->hVel = nullptr; }
+    HIP_TRY(hipMalloc(&h->dVel, sizeof(double) * (size_t)h->max_batch * 3 * n_epochs));
+    HIP_TRY(hipHostMalloc(&h->hVel, sizeof(double) * (size_t)h->max_batch * 3 * n_epochs));
+    h->n_epochs = n_epochs;
+    HIP_TRY(hipMemcpy(h->dGrid, lwl, sizeof(double) * h->N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->dEpoch, epoch, sizeof(int32_t) * h->N, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int psoap_chunk_set_stream_groups(psoap_chunk* h, int groups)
+{
+    if (!h || groups < 1 || groups > MAX_GROUPS) FAIL("psoap_chunk_set_stream_groups: 1 <= groups <= 8");
+    h->groups = groups;
+    return 0;
+}
+
+extern "C" int psoap_chunk_set_profiling(psoap_chunk* h, int enabled)
+{
+    if (!h) FAIL("null handle");
+    h->profiling = enabled != 0;
+    return 0;
+}
+
+static int stage_gp(psoap_chunk* h, int B, int c, const double* gp, double mu_GP)
+{
+    if (B < 1 || B > h->max_batch) FAIL("batch size outside [1, max_batch]");
+    if (c < 1 || c > 3) FAIL("number of components must be 1, 2 or 3");
+    h->B = B;
+    h->C = c;
+    h->mu = mu_GP;
+    h->neg.assign(B, 0);
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < 2 * c; ++k)
+            if (gp[(size_t)b * 2 * c + k] < 0.0) h->neg[b] = 1;  // covariance.py:317,339,362
+    memcpy(h->hGp, gp, sizeof(double) * (size_t)B * 2 * c);
+    return 0;
+}
+
+extern "C" int psoap_batch_upload(psoap_chunk* h, int B, int c, const double* lwl, const double* gp, double mu_GP)
+{
+    if (!h || !lwl || !gp) FAIL("psoap_batch_upload: bad arguments");
+    if (set_dev(h)) return 1;
+    // staging buffers are reused: the previous batch must have been consumed
+    HIP_TRY(hipStreamSynchronize(h->streams[0]));
+    if (int rc = stage_gp(h, B, c, gp, mu_GP)) return rc;
+    const size_t nl = (size_t)B * c * h->N;
+    memcpy(h->hLwl, lwl, sizeof(double) * nl);
+    hipStream_t s = h->streams[0];
+    HIP_TRY(hipMemcpyAsync(h->dLwl, h->hLwl, sizeof(double) * nl, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->dGp, h->hGp, sizeof(double) * (size_t)B * 2 * c, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(h->evUpload, s));
+    return 0;
+}
+
+extern "C" int psoap_batch_upload_velocities(psoap_chunk* h, int B, int c, const double* vel, const double* gp,
+                                             double mu_GP)
+{
+    if (!h || !vel || !gp) FAIL("psoap_batch_upload_velocities: bad arguments");
+    if (!h->dGrid) FAIL("psoap_batch_upload_velocities: call psoap_chunk_set_grid first");
+    if (set_dev(h)) return 1;
+    HIP_TRY(hipStreamSynchronize(h->streams[0]));
+    if (int rc = stage_gp(h, B, c, gp, mu_GP)) return rc;
+    const size_t nv = (size_t)B * c * h->n_epochs;
+    memcpy(h->hVel, vel, sizeof(double) * nv);
+    hipStream_t s = h->streams[0];
+    HIP_TRY(hipMemcpyAsync(h->dVel, h->hVel, sizeof(double) * nv, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->dGp, h->hGp, sizeof(double) * (size_t)B * 2 * c, hipMemcpyHostToDevice, s));
+    dim3 grid((h->N + 255) / 256, B * c);
+    hipLaunchKernelGGL(k_doppler_shift, grid, dim3(256), 0, s, h->dLwl, h->dGrid, h->dEpoch, h->dVel, h->N,
+                       h->n_epochs, B * c);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->evUpload, s));
+    return 0;
+}
+
+// ---- profiling helpers ------------------------------------------------------------------
+static int prof_begin(psoap_chunk* h, hipStream_t s, int cls, double flops, double bytes)
+{
+    if (!h->profiling) return 0;
+    size_t need = h->recs.size() * 2 + 2;
+    while (h->evPool.size() < need) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        h->evPool.push_back(e);
+    }
+    psoap_chunk::Rec r;
+    r.cls = cls;
+    r.e0 = (int)h->recs.size() * 2;
+    r.e1 = r.e0 + 1;
+    r.flops = flops;
+    r.bytes = bytes;
+    h->recs.push_back(r);
+    HIP_TRY(hipEventRecord(h->evPool[r.e0], s));
+    return 0;
+}
+static int prof_end(psoap_chunk* h, hipStream_t s)
+{
+    if (!h->profiling) return 0;
+    HIP_TRY(hipEventRecord(h->evPool[h->recs.back().e1], s));
+    return 0;
+}
+
+template <int C>
+static void launch_fill(psoap_chunk* h, hipStream_t s, int b0, int nb, int upper_only)
+{
+    const int tiles = upper_only ? h->P * (h->P + 1) / 2 : h->P * h->P;
+    hipLaunchKernelGGL(k_fill_sym<C>, dim3(tiles, nb), dim3(256), 0, s, h->dK + (size_t)b0 * h->mat_stride,
+                       h->mat_stride, h->ld, h->N, h->P, h->dLwl + (size_t)b0 * C * h->N,
+                       h->dGp + (size_t)b0 * 2 * C, h->dSigma, upper_only);
+}
+
+extern "C" int psoap_batch_eval(psoap_chunk* h)
+{
+    if (!h || h->B < 1) FAIL("psoap_batch_eval: nothing uploaded");
+    if (set_dev(h)) return 1;
+    const int B = h->B, C = h->C, N = h->N, P = h->P;
+    const int G = h->profiling ? 1 : (h->groups < B ? h->groups : B);
+    h->recs.clear();
+    int gb0[MAX_GROUPS + 1];
+    for (int g = 0; g <= G; ++g) gb0[g] = (int)((long long)B * g / G);
+
+    // stage 0 per group: wait for the upload, fill K (upper tiles), r = fl - mu, clear accumulators
+    for (int g = 0; g < G; ++g) {
+        hipStream_t s = h->streams[g];
+        const int b0 = gb0[g], nb = gb0[g + 1] - gb0[g];
+        if (g != 0) HIP_TRY(hipStreamWaitEvent(s, h->evUpload, 0));
+        const double fbytes = (double)nb * (4.0 * N * (N + 1.0) + 8.0 * (C + 1.0) * N);
+        if (prof_begin(h, s, PSOAP_K_FILL, 0.0, fbytes)) return 1;
+        if (C == 1) launch_fill<1>(h, s, b0, nb, 1);
+        else if (C == 2) launch_fill<2>(h, s, b0, nb, 1);
+        else launch_fill<3>(h, s, b0, nb, 1);
+        HIP_TRY(hipGetLastError());
+        if (prof_end(h, s)) return 1;
+        if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
+        hipLaunchKernelGGL(k_init_rhs, dim3((h->Npad + 255) / 256, nb), dim3(256), 0, s,
+                           h->dR + (size_t)b0 * h->Npad, h->Npad, N, h->dFl, h->mu, h->dAcc + b0);
+        HIP_TRY(hipGetLastError());
+        if (prof_end(h, s)) return 1;
+    }
+    // panels, round-robin over the stream groups so their phases interleave on the device
+    for (int p = 0; p < P; ++p) {
+        const int k0 = p * NB;
+        const int ntile = P - p;
+        for (int g = 0; g < G; ++g) {
+            hipStream_t s = h->streams[g];
+            const int b0 = gb0[g], nb = gb0[g + 1] - gb0[g];
+            double* Kg = h->dK + (size_t)b0 * h->mat_stride;
+            if (p > 0) {
+                if (prof_begin(h, s, PSOAP_K_PANEL_UPDATE, 2.0 * NB * NB * (double)k0 * ntile * nb, 0.0)) return 1;
+                hipLaunchKernelGGL(k_panel_update, dim3(ntile, nb), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Kg,
+                                   h->mat_stride, h->ld, k0);
+                HIP_TRY(hipGetLastError());
+                if (prof_end(h, s)) return 1;
+            }
+            if (prof_begin(h, s, PSOAP_K_POTRF, 0.0, 0.0)) return 1;
+            hipLaunchKernelGGL(k_potrf_diag, dim3(nb), dim3(512), 0, s, Kg, h->mat_stride, h->ld, k0,
+                               h->dWt + (size_t)b0 * NB * NB, h->dR + (size_t)b0 * h->Npad, h->Npad, h->dAcc + b0);
+            HIP_TRY(hipGetLastError());
+            if (prof_end(h, s)) return 1;
+            if (ntile > 1) {
+                if (prof_begin(h, s, PSOAP_K_TRSM, 2.0 * NB * NB * (double)NB * (ntile - 1) * nb, 0.0)) return 1;
+                hipLaunchKernelGGL(k_trsm_strip, dim3(ntile - 1, nb), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Kg,
+                                   h->mat_stride, h->ld, k0, h->dWt + (size_t)b0 * NB * NB,
+                                   h->dR + (size_t)b0 * h->Npad, h->Npad);
+                HIP_TRY(hipGetLastError());
+                if (prof_end(h, s)) return 1;
+            }
+        }
+    }
+    // finalize per group; group 0's stream gathers the others and does the D2H
+    for (int g = 0; g < G; ++g) {
+        hipStream_t s = h->streams[g];
+        const int b0 = gb0[g], nb = gb0[g + 1] - gb0[g];
+        if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
+        hipLaunchKernelGGL(k_finalize, dim3((nb + 63) / 64), dim3(64), 0, s, h->dAcc + b0, h->dOut + b0, nb);
+        HIP_TRY(hipGetLastError());
+        if (prof_end(h, s)) return 1;
+        if (g != 0) {
+            HIP_TRY(hipEventRecord(h->evDone[g], s));
+            HIP_TRY(hipStreamWaitEvent(h->streams[0], h->evDone[g], 0));
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(h->hOut, h->dOut, sizeof(double) * B, hipMemcpyDeviceToHost, h->streams[0]));
+    return 0;
+}
+
+static int collect_timings(psoap_chunk* h)
+{
+    psoap_timings t;
+    memset(&t, 0, sizeof t);
+    if (h->profiling && !h->recs.empty()) {
+        for (auto& r : h->recs) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, h->evPool[r.e0], h->evPool[r.e1]));
+            t.ms[r.cls] += ms;
+            t.launches[r.cls] += 1;
+            t.flops[r.cls] += r.flops;
+            t.bytes[r.cls] += r.bytes;
+        }
+        float tot = 0.f;
+        HIP_TRY(hipEventElapsedTime(&tot, h->evPool[h->recs.front().e0], h->evPool[h->recs.back().e1]));
+        t.total_ms = tot;
+    }
+    h->last = t;
+    return 0;
+}
+
+extern "C" int psoap_batch_fetch(psoap_chunk* h, double* out)
+{
+    if (!h || !out || h->B < 1) FAIL("psoap_batch_fetch: bad arguments");
+    if (set_dev(h)) return 1;
+    HIP_TRY(hipStreamSynchronize(h->streams[0]));
+    if (collect_timings(h)) return 1;
+    for (int b = 0; b < h->B; ++b) out[b] = h->neg[b] ? -INFINITY : h->hOut[b];
+    return 0;
+}
+
+extern "C" int psoap_chunk_sync(psoap_chunk* h)
+{
+    if (!h) FAIL("null handle");
+    if (set_dev(h)) return 1;
+    for (int g = 0; g < MAX_GROUPS; ++g) HIP_TRY(hipStreamSynchronize(h->streams[g]));
+    return 0;
+}
+
+extern "C" int psoap_chunk_get_timings(psoap_chunk* h, psoap_timings* t)
+{
+    if (!h || !t) FAIL("bad arguments");
+    *t = h->last;
+    return 0;
+}
+
+extern "C" int psoap_lnlike_batch(psoap_chunk* h, int B, int c, const double* lwl, const double* gp, double mu_GP,
+                                  double* out)
+{
+    if (int rc = psoap_batch_upload(h, B, c, lwl, gp, mu_GP)) return rc;
+    bool all_neg = true;
+    for (int b = 0; b < B; ++b) all_neg = all_neg && h->neg[b];
+    if (all_neg) {  // covariance.py:317-318: -inf before any work
+        for (int b = 0; b < B; ++b) out[b] = -INFINITY;
+        return 0;
+    }
+    if (int rc = psoap_batch_eval(h)) return rc;
+    return psoap_batch_fetch(h, out);
+}
+
+extern "C" int psoap_lnlike(psoap_chunk* h, int c, const double* lwl, const double* gp, double mu_GP, double* out)
+{
+    return psoap_lnlike_batch(h, 1, c, lwl, gp, mu_GP, out);
+}
+
+// ---- fills (matrix_functions drop-ins) ------------------------------------------------------
+extern "C" int psoap_fill_sym(int device, int c, int N, const double* lwl, const double* gp, const double* sigma,
+                              double* out)
+{
+    if (c < 1 || c > 3 || N <= 0 || !lwl || !gp || !out) FAIL("psoap_fill_sym: bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    const int Npad = round_up(N, NB), P = Npad / NB;
+    double *dK = nullptr, *dLwl = nullptr, *dGp = nullptr, *dSig = nullptr;
+    HIP_TRY(hipMalloc(&dK, sizeof(double) * (size_t)Npad * Npad));
+    HIP_TRY(hipMalloc(&dLwl, sizeof(double) * (size_t)c * N));
+    HIP_TRY(hipMalloc(&dGp, sizeof(double) * 6));
+    HIP_TRY(hipMemcpy(dLwl, lwl, sizeof(double) * (size_t)c * N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dGp, gp, sizeof(double) * 2 * c, hipMemcpyHostToDevice));
+    if (sigma) {
+        HIP_TRY(hipMalloc(&dSig, sizeof(double) * N));
+        HIP_TRY(hipMemcpy(dSig, sigma, sizeof(double) * N, hipMemcpyHostToDevice));
+    }
+    dim3 grid(P * P, 1);
+    if (c == 1)
+        hipLaunchKernelGGL(k_fill_sym<1>, grid, dim3(256), 0, 0, dK, (size_t)0, Npad, N, P, dLwl, dGp, dSig, 0);
+    else if (c == 2)
+        hipLaunchKernelGGL(k_fill_sym<2>, grid, dim3(256), 0, 0, dK, (size_t)0, Npad, N, P, dLwl, dGp, dSig, 0);
+    else
+        hipLaunchKernelGGL(k_fill_sym<3>, grid, dim3(256), 0, 0, dK, (size_t)0, Npad, N, P, dLwl, dGp, dSig, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy2D(out, sizeof(double) * N, dK, sizeof(double) * Npad, sizeof(double) * N, N,
+                        hipMemcpyDeviceToHost));
+    (void)hipFree(dK); (void)hipFree(dLwl); (void)hipFree(dGp); (void)hipFree(dSig);
+    return 0;
+}
+
+extern "C" int psoap_fill_cross(int device, int M, int N, const double* lwl_row, const double* lwl_col, double amp,
+                                double l, double* out)
+{
+    if (M <= 0 || N <= 0 || !lwl_row || !lwl_col || !out) FAIL("psoap_fill_cross: bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    const int ld = round_up(N, 2);
+    double *dO = nullptr, *dRow = nullptr, *dCol = nullptr;
+    HIP_TRY(hipMalloc(&dO, sizeof(double) * (size_t)M * ld));
+    HIP_TRY(hipMalloc(&dRow, sizeof(double) * M));
+    HIP_TRY(hipMalloc(&dCol, sizeof(double) * N));
+    HIP_TRY(hipMemcpy(dRow, lwl_row, sizeof(double) * M, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dCol, lwl_col, sizeof(double) * N, hipMemcpyHostToDevice));
+    dim3 grid((N + NB - 1) / NB, (M + NB - 1) / NB);
+    hipLaunchKernelGGL(k_fill_cross, grid, dim3(256), 0, 0, dO, ld, M, N, dRow, dCol, amp, l);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy2D(out, sizeof(double) * N, dO, sizeof(double) * ld, sizeof(double) * N, M,
+                        hipMemcpyDeviceToHost));
+    (void)hipFree(dO); (void)hipFree(dRow); (void)hipFree(dCol);
+    return 0;
+}
+
+// ---- predict ---------------------------------------------------------------------------------
+extern "C" int psoap_predict(int device, int mode, int c, int N, int M, const double* lwl, const double* fl,
+                             const double* sigma, const double* lwl_pred, const double* mu_c, const double* gp,
+                             double* mu_out, double* Sigma_out, int* status_out)
+{
+    if (mode < 0 || mode > 2 || c < 1 || c > 3 || N <= 0 || M <= 0 || !lwl || !fl || !sigma || !lwl_pred || !mu_c ||
+        !gp || !mu_out)
+        FAIL("psoap_predict: bad arguments");
+    if (mode == 2 && c != 1) FAIL("psoap_predict: mode 2 (predict_f) needs c == 1");
+    HIP_TRY(hipSetDevice(device));
+    if (configure_kernels()) return 1;
+    int status = 0;
+    int rc = predict_run(mode, c, N, M, lwl, fl, sigma, lwl_pred, mu_c, gp, mu_out, Sigma_out, &status, g_err);
+    if (status_out) *status_out = status;
+    return rc;
+}
+
+// ---- micro-benchmarks -----------------------------------------------------------------------
+extern "C" int psoap_microbench_mfma_f64(int device, double* tflops)
+{
+    HIP_TRY(hipSetDevice(device));
+    return microbench_mfma(tflops, g_err);
+}
+
+extern "C" int psoap_microbench_hbm(int device, double* write_gbs, double* copy_gbs)
+{
+    HIP_TRY(hipSetDevice(device));
+    return microbench_hbm(write_gbs, copy_gbs, g_err);
+}

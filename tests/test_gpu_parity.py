@@ -1,0 +1,269 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the
+golden vectors generated from the reference.  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+from psoap_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+# tolerance contract: |dlnp| <= 1e-10 * max(1, |lnp|); fills <= 4 ulp
+LNP_RTOL = 1e-10
+FILL_ULP = 4
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+    b = np.ascontiguousarray(b, dtype=np.float64).view(np.int64)
+    return np.abs(a - b)
+
+
+def lnp_close(got, want):
+    return abs(got - want) <= LNP_RTOL * max(1.0, abs(want))
+
+
+@pytest.fixture(scope="module")
+def mf():
+    from psoap_amd import matrix_functions
+    return matrix_functions
+
+
+@pytest.fixture(scope="module")
+def cov():
+    from psoap_amd import covariance
+    yield covariance
+    covariance.release_handles()
+
+
+# ------------------------------------------------------------------------------ fills
+def test_fill_golden(golden, mf):
+    c, ne, npx, seed, M = golden["fill_meta"]
+    ch = syn.make_chunk(c, ne, npx, seed=seed)
+    N = ch.N
+    gp = syn.GP_BASE[3]
+    m = np.empty((N, N))
+    mf.fill_V11_f(m, ch.lwls[0], *gp[:2])
+    assert ulp_diff(m, golden["fill_f"]).max() <= FILL_ULP
+    assert np.array_equal(m, m.T)
+    mf.fill_V11_f_g(m, ch.lwls[0], ch.lwls[1], *gp[:4])
+    assert ulp_diff(m, golden["fill_f_g"]).max() <= FILL_ULP
+    mf.fill_V11_f_g_h(m, *ch.lwls, *gp)
+    assert ulp_diff(m, golden["fill_f_g_h"]).max() <= FILL_ULP
+    assert np.array_equal(np.diag(m), np.diag(golden["fill_f_g_h"]))   # diagonal rule is exact
+    pred = np.linspace(ch.lwls[0].min(), ch.lwls[0].max(), M)
+    r = np.empty((M, N))
+    mf.fill_V12_f(r, pred, ch.lwls[0], *gp[:2])
+    assert ulp_diff(r, golden["fill_cross_40xN"]).max() <= FILL_ULP
+    r = np.empty((N, M))
+    mf.fill_V12_f(r, ch.lwls[1], pred, *gp[2:4])
+    assert ulp_diff(r, golden["fill_cross_Nx40"]).max() <= FILL_ULP
+
+
+@pytest.mark.parametrize("c,ne,npx", [(1, 3, 43), (2, 5, 77), (3, 9, 100), (2, 1, 1), (1, 2, 64)])
+def test_fill_vs_oracle_ragged(oracle, mf, c, ne, npx):
+    ch = syn.make_chunk(c, ne, npx, seed=900 + npx, masked_fraction=0.1 if npx > 10 else 0.0)
+    N = ch.N
+    gp = syn.GP_BASE[c]
+    want = np.empty((N, N))
+    oracle.fill_sym(want, ch.lwls, gp)
+    got = np.full((N, N), np.nan)
+    [mf.fill_V11_f, mf.fill_V11_f_g, mf.fill_V11_f_g_h][c - 1](got, *ch.lwls, *gp)
+    assert ulp_diff(got, want).max() <= FILL_ULP
+    # rectangular, odd sizes, non-contiguous target
+    M = max(1, N // 3)
+    pred = np.linspace(ch.lwls[0].min(), ch.lwls[0].max(), M)
+    want = np.empty((M, N))
+    oracle.fill_V12_f(want, pred, ch.lwls[0], gp[0], gp[1])
+    big = np.full((M, 2 * N), np.nan)
+    view = big[:, ::2]
+    mf.fill_V12_f(view, pred, ch.lwls[0], gp[0], gp[1])
+    assert ulp_diff(np.ascontiguousarray(view), want).max() <= FILL_ULP
+
+
+def test_fill_mostly_bit_exact(oracle, mf):
+    """The arithmetic around exp() is contraction-free, so the only difference from the
+    reference is the device exp(): the large majority of entries must match bit for bit."""
+    ch = syn.make_chunk(2, 6, 100, seed=77)
+    want = np.empty((ch.N, ch.N))
+    oracle.fill_sym(want, ch.lwls, syn.GP_BASE[2])
+    got = np.empty_like(want)
+    mf.fill_V11_f_g(got, *ch.lwls, *syn.GP_BASE[2])
+    d = ulp_diff(got, want)
+    assert d.max() <= FILL_ULP
+    assert (d == 0).mean() > 0.5
+
+
+# ------------------------------------------------------------------------------ lnlike
+def _cases(golden):
+    for name, meta, val in zip(golden["lnlike_names"], golden["lnlike_meta"], golden["lnlike_vals"]):
+        c, ne, npx, seed, mf100, N = [int(x) for x in meta]
+        yield str(name), c, ne, npx, seed, mf100 / 100.0, N, float(val)
+
+
+def test_lnlike_golden_all_configs(golden, cov):
+    V11 = None
+    for name, c, ne, npx, seed, mfrac, N, val in _cases(golden):
+        ch = syn.make_chunk(c, ne, npx, seed=seed, masked_fraction=mfrac)
+        fn = [cov.lnlike_f, cov.lnlike_f_g, cov.lnlike_f_g_h][c - 1]
+        got = fn(V11, *ch.lwls, ch.fl, ch.sigma, *syn.GP_BASE[c])
+        assert lnp_close(got, val), (name, got, val, got - val)
+        cov.release_handles()
+
+
+def test_lnlike_dispatch_and_conventions(golden, cov):
+    ch = syn.make_chunk(2, 8, 32, seed=105)
+    assert cov.lnlike["SB2"] is cov.lnlike_f_g and cov.lnlike["ST2"] is cov.lnlike_f_g
+    assert cov.lnlike["SB1"] is cov.lnlike_f and cov.lnlike["ST1"] is cov.lnlike_f
+    assert cov.lnlike["ST3"] is cov.lnlike_f_g_h
+    V = np.empty((ch.N, ch.N))
+    v = cov.lnlike["SB2"](V, *ch.lwls, ch.fl, ch.sigma, *syn.GP_BASE[2], mu_GP=0.9)
+    assert lnp_close(v, float(golden["lnlike_mu0p9"]))
+    assert cov.lnlike_f(V, ch.lwls[0], ch.fl, ch.sigma, -0.2, 5.0) == -np.inf
+    assert cov.lnlike_f_g(V, *ch.lwls, ch.fl, ch.sigma, 0.2, 5.0, 0.1, -7.0) == -np.inf
+    assert cov.lnlike_f_g_h(V, *ch.lwls, ch.lwls[0], ch.fl, ch.sigma, 0.2, 5.0, 0.1, 7.0, -0.05, 6.0) == -np.inf
+    lw = ch.lwls.copy()
+    lw[:, 1] = lw[:, 0]
+    assert cov.lnlike_f_g(V, *lw, ch.fl, np.zeros_like(ch.sigma), *syn.GP_BASE[2]) == -np.inf   # not PD
+    v = cov.lnlike_f(V, ch.lwls[0], ch.fl, ch.sigma, 0.0, 5.0)
+    assert lnp_close(v, float(golden["lnlike_zero_amp"]))
+
+
+@pytest.mark.parametrize("N", [1, 2, 63, 127, 128, 129, 255, 257, 640])
+def test_lnlike_vs_oracle_edge_sizes(oracle, N):
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_chunk(2, 1, N, seed=4000 + N)
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=1) as h:
+        got = h.lnlike(ch.lwls, syn.GP_BASE[2])
+    want = oracle.lnlike(ch.lwls, ch.fl, ch.sigma, syn.GP_BASE[2])
+    assert lnp_close(got, want), (N, got, want)
+
+
+def test_batch_matches_singles_and_oracle(golden, oracle):
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_chunk(2, 6, 100, seed=321)          # N = 600
+    nw = 7
+    gps = syn.make_walkers(2, nw, seed=11)
+    gps[3, 1] = -1.0                                  # one rejected proposal inside the batch
+    lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, nw, seed=12))
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=8) as h:
+        for groups in (1, 2, 3):
+            h.set_stream_groups(groups)
+            got = h.lnlike_batch(lw, gps)
+            for w in range(nw):
+                want = oracle.lnlike(lw[w], ch.fl, ch.sigma, gps[w])
+                if w == 3:
+                    assert got[w] == -np.inf and want == -np.inf
+                else:
+                    assert lnp_close(got[w], want), (groups, w, got[w], want)
+        # determinism: same inputs, same bits
+        again = h.lnlike_batch(lw, gps)
+        assert np.array_equal(again, got)
+        # profiling mode (single group, per-launch events) gives the same numbers
+        h.set_profiling(True)
+        prof = h.lnlike_batch(lw, gps)
+        assert np.array_equal(prof, got)
+        t = h.timings()
+        assert t["panel_update"]["launches"] == 4 and t["potrf"]["launches"] == 5
+        h.set_profiling(False)
+
+
+def test_walker_batch_cfg3_golden(golden):
+    """BASELINE config 3 (SB2, N=6000): 4 walkers against values from the reference itself."""
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_config_chunk(3)
+    gps = syn.make_walkers(2, 4, seed=3500)
+    vels = syn.make_walker_velocities(ch, 4, seed=3501)
+    lw = syn.walker_lwls(ch, vels)
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=4) as h:
+        got = h.lnlike_batch(lw, gps)
+        for w in range(4):
+            assert lnp_close(got[w], golden["walkers_cfg3"][w]), (w, got[w], golden["walkers_cfg3"][w])
+        # device-side Doppler shift (replicate_wls on the GPU) must give the same answers
+        h.set_grid(ch.lwl, ch.epoch_index, ch.n_epochs)
+        h.upload_velocities(vels, gps)
+        h.eval()
+        got2 = h.fetch()
+        assert np.array_equal(got2, got)
+
+
+def test_full_size_properties():
+    """Size-independent properties at the metric's full size (N=6000, SB2):
+    (1) K = sigma^2 I (zero amplitudes) has the closed form -0.5*(|r|^2/s^2 + N log s^2);
+    (2) scaling fl-mu, sigma and amp by a changes lnp by exactly -N log a;
+    (3) permuting the pixels (a symmetric permutation of K) leaves lnp unchanged."""
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_config_chunk(3)
+    N = ch.N
+    gp = np.array(syn.GP_BASE[2])
+    r = ch.fl - 1.0
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=2) as h:
+        base = h.lnlike(ch.lwls, gp)
+        zero = h.lnlike(ch.lwls, [0.0, 5.0, 0.0, 7.0])
+        want0 = -0.5 * (np.sum(r * r / ch.sigma**2) + np.sum(np.log(ch.sigma**2)))
+        assert abs(zero - want0) <= 1e-10 * abs(want0)
+        a = 2.0   # power of two: the scaled problem is the same problem bit for bit
+        h.set_data(1.0 + a * r, a * ch.sigma)
+        scaled = h.lnlike(ch.lwls, gp * np.array([a, 1.0, a, 1.0]))
+        assert abs(scaled - (base - N * np.log(a))) <= 1e-10 * abs(base)
+        perm = np.random.default_rng(5).permutation(N)
+        h.set_data(ch.fl[perm], ch.sigma[perm])
+        permuted = h.lnlike(np.ascontiguousarray(ch.lwls[:, perm]), gp)
+        assert abs(permuted - base) <= 1e-10 * abs(base)
+
+
+# ------------------------------------------------------------------------------ predict
+def test_predict_golden_small(golden, cov):
+    c, ne, npx, seed, M, c2, ne2, npx2, seed2 = golden["pred_meta"]
+    ch = syn.make_chunk(c, ne, npx, seed=seed)
+    pg = np.linspace(ch.lwls[0].min(), ch.lwls[0].max(), M)
+    mu, Sig = cov.predict_f_g(ch.lwls[0], ch.lwls[1], ch.fl, ch.sigma, pg, pg, 0.0, 0.2, 5.0, 0.0, 0.1, 7.0)
+    np.testing.assert_allclose(mu, golden["pred_fg_mu"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(Sig, golden["pred_fg_Sigma"], rtol=0, atol=1e-9)
+    mu = cov.predict_f_g(ch.lwls[0], ch.lwls[1], ch.fl, ch.sigma, pg, pg + 1e-5, 0.3, 0.2, 5.0, 0.7, 0.1, 7.0,
+                         get_Sigma=False)
+    np.testing.assert_allclose(mu, golden["pred_fg_mu_only"], rtol=0, atol=1e-10)
+    mu, Sig = cov.predict_f_g_h(*ch.lwls, ch.fl, ch.sigma, pg, pg, pg, 0.0, 0.0, 0.0, *syn.GP_BASE[3])
+    np.testing.assert_allclose(mu, golden["pred_fgh_mu"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(Sig, golden["pred_fgh_Sigma"], rtol=0, atol=1e-9)
+    mu, Sig = cov.predict_f_g_sum(ch.lwls[0], ch.lwls[1], ch.fl, ch.sigma, pg, pg, 1.0, 0.2, 5.0, 0.1, 7.0)
+    np.testing.assert_allclose(mu, golden["pred_fg_sum_mu"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(Sig, golden["pred_fg_sum_Sigma"], rtol=0, atol=1e-9)
+    chq = syn.make_chunk(c2, ne2, npx2, seed=seed2)
+    mu, Sig = cov.predict_f_g_h_sum(*chq.lwls, chq.fl, chq.sigma, *chq.lwls, 1.0, *syn.GP_BASE[3])
+    np.testing.assert_allclose(mu, golden["pred_fgh_sum_mu"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(Sig, golden["pred_fgh_sum_Sigma"], rtol=0, atol=1e-9)
+
+
+def test_predict_golden_retrieve_shape(golden, cov):
+    c, ne, npx, seed, M = golden["predL_meta"]
+    ch = syn.make_chunk(c, ne, npx, seed=seed)
+    pg = np.linspace(ch.lwls[0].min(), ch.lwls[0].max(), M)
+    mu, Sig = cov.predict_f_g_h(*ch.lwls, ch.fl, ch.sigma, pg, pg, pg, 0.0, 0.0, 0.0, *syn.GP_BASE[3])
+    np.testing.assert_allclose(mu, golden["predL_fgh_mu"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(np.diag(Sig), golden["predL_fgh_diag"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(Sig[[0, 399, 400, 777, 1199]], golden["predL_fgh_rows"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(Sig, Sig.T, rtol=0, atol=1e-12)
+    mu, Sig = cov.predict_f_g(ch.lwls[0], ch.lwls[1], ch.fl, ch.sigma, pg, pg, 0.0, 0.2, 5.0, 0.0, 0.1, 7.0)
+    np.testing.assert_allclose(mu, golden["predL_fg_mu"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(np.diag(Sig), golden["predL_fg_diag"], rtol=0, atol=1e-9)
+
+
+def test_predict_sum_transposed_mean_and_predict_f(oracle, cov):
+    """predict_f_g_h_sum with M == N but *different* grids exercises the V12.T of
+    covariance.py:294; predict_f is checked against the oracle's c=1 conditional."""
+    ch = syn.make_chunk(3, 3, 50, seed=31)              # N = 150
+    pred = [w + 0.3 * 2.7 / syn.C_KMS for w in ch.lwls]
+    mu, Sig = cov.predict_f_g_h_sum(*ch.lwls, ch.fl, ch.sigma, *pred, 1.0, *syn.GP_BASE[3])
+    mu_o, Sig_o = oracle.predict_sum(ch.lwls, ch.fl, ch.sigma, pred, 1.0, syn.GP_BASE[3])
+    np.testing.assert_allclose(mu, mu_o, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(Sig, Sig_o, rtol=0, atol=1e-9)
+    with pytest.raises(ValueError):
+        cov.predict_f_g_h_sum(*ch.lwls, ch.fl, ch.sigma, *[p[:100] for p in pred], 1.0, *syn.GP_BASE[3])
+    pg = np.linspace(ch.lwls[0].min(), ch.lwls[0].max(), 77)
+    mu, Sig = cov.predict_f(ch.lwls[0], ch.fl, ch.sigma, pg, 0.2, 5.0, mu_GP=1.0)
+    # c=1 joint conditional with offset 1.0 and prior mean 1.0 is predict_f with mu_GP = 1
+    mu_o, Sig_o = oracle.predict_components(ch.lwls[:1], ch.fl, ch.sigma, [pg], [1.0], syn.GP_BASE[1])
+    np.testing.assert_allclose(mu, mu_o, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(Sig, Sig_o, rtol=0, atol=1e-9)
+    with pytest.raises(AssertionError, match="Input wavelengths must be the same length."):
+        cov.predict_f_g(ch.lwls[0], ch.lwls[1][:-1], ch.fl, ch.sigma, pg, pg, 0.0, 0.2, 5.0, 0.0, 0.1, 7.0)
