@@ -37,12 +37,11 @@ __global__ void k_init_rhs(double* __restrict__ R, int Npad, int N, const double
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_panel_update(double* __restrict__ Kbase, size_t mat_stride,
                                                                  int ld, int k0)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Km = Kbase + (size_t)blockIdx.y * mat_stride;
     const int j0 = k0 + NB * blockIdx.x;
     Tile t;
     t.zero();
-    tile_gemm_tn(t, Km + k0, (size_t)ld, Km + j0, (size_t)ld, k0, smem);
+    tile_gemm_tn(t, Km + k0, (size_t)ld, Km + j0, (size_t)ld, k0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 #pragma unroll
@@ -191,7 +190,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trsm_strip(double* __restri
                                                                int ld, int k0, const double* __restrict__ Wt,
                                                                double* __restrict__ Rbase, int Npad)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ double zk[NB];
     __shared__ double colsum[NB];
     const int bidx = blockIdx.y;
@@ -202,7 +200,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trsm_strip(double* __restri
     if (tid < NB) zk[tid] = Rv[k0 + tid];
     Tile t;
     t.zero();
-    tile_gemm_tn(t, Wt + (size_t)bidx * NB * NB, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld, NB, smem);
+    tile_gemm_tn(t, Wt + (size_t)bidx * NB * NB, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld, NB);
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     double part[4] = {0.0, 0.0, 0.0, 0.0};

@@ -49,29 +49,38 @@ __device__ __forceinline__ void stage_load(Staging& s, const double* __restrict_
     }
 }
 
-__device__ __forceinline__ void stage_store(const Staging& s, double* sA, double* sB, int tid)
+// All tile kernels share ONE dynamic LDS array and address it with integer offsets, so every
+// access stays in the LDS address space (ds_read/ds_write; a pointer that is selected at run
+// time degrades to flat_* accesses whose waits also drain the global prefetch).
+extern __shared__ __attribute__((aligned(16))) double psoap_smem[];
+
+constexpr int LDS_OPERAND = KB * LDS_LD;     // doubles per staged operand chunk
+constexpr int LDS_BUFFER = 2 * LDS_OPERAND;  // A chunk followed by B chunk
+
+__device__ __forceinline__ void stage_store(const Staging& s, int buf, int tid)
 {
     const int col2 = tid & 63, row0 = tid >> 6;
+    const int base = buf * LDS_BUFFER;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        *reinterpret_cast<d2*>(sA + (row0 + 4 * it) * LDS_LD + 2 * col2) = s.a[it];
-        *reinterpret_cast<d2*>(sB + (row0 + 4 * it) * LDS_LD + 2 * col2) = s.b[it];
+        const int off = base + (row0 + 4 * it) * LDS_LD + 2 * col2;
+        *reinterpret_cast<d2*>(&psoap_smem[off]) = s.a[it];
+        *reinterpret_cast<d2*>(&psoap_smem[off + LDS_OPERAND]) = s.b[it];
     }
 }
 
-__device__ __forceinline__ void tile_mma_chunk(Tile& t, const double* sA, const double* sB, int wr, int wc,
-                                               int lane)
+__device__ __forceinline__ void tile_mma_chunk(Tile& t, int buf, int wr, int wc, int lane)
 {
     const int fr = lane & 15, fk = lane >> 4;
+    const int baseA = buf * LDS_BUFFER + fk * LDS_LD + wr * 64 + fr;
+    const int baseB = buf * LDS_BUFFER + LDS_OPERAND + fk * LDS_LD + wc * 64 + fr;
 #pragma unroll
     for (int ks = 0; ks < KB / 4; ++ks) {
         double a[4], b[4];
-        const double* pa = sA + (ks * 4 + fk) * LDS_LD + wr * 64 + fr;
-        const double* pb = sB + (ks * 4 + fk) * LDS_LD + wc * 64 + fr;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a[m] = pa[m * 16];
+        for (int m = 0; m < 4; ++m) a[m] = psoap_smem[baseA + ks * 4 * LDS_LD + m * 16];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) b[n] = pb[n * 16];
+        for (int n = 0; n < 4; ++n) b[n] = psoap_smem[baseB + ks * 4 * LDS_LD + n * 16];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -80,27 +89,25 @@ __device__ __forceinline__ void tile_mma_chunk(Tile& t, const double* sA, const 
     }
 }
 
-// smem: GEMM_LDS_BYTES of dynamic LDS.  All 256 threads must call this.
+// Needs GEMM_LDS_BYTES of dynamic LDS at launch.  All 256 threads must call this.
 __device__ __forceinline__ void tile_gemm_tn(Tile& t, const double* __restrict__ A, size_t lda,
-                                             const double* __restrict__ B, size_t ldb, int K, double* smem)
+                                             const double* __restrict__ B, size_t ldb, int K)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    double* sA[2] = {smem, smem + 2 * KB * LDS_LD};
-    double* sB[2] = {smem + KB * LDS_LD, smem + 3 * KB * LDS_LD};
     if (K <= 0) return;
     Staging s;
     stage_load(s, A, lda, B, ldb, 0, tid);
-    stage_store(s, sA[0], sB[0], tid);
+    stage_store(s, 0, tid);
     __syncthreads();
     const int nchunk = K / KB;
     for (int c = 0; c < nchunk; ++c) {
         const int cur = c & 1;
         const bool more = (c + 1 < nchunk);
         if (more) stage_load(s, A, lda, B, ldb, (c + 1) * KB, tid);
-        tile_mma_chunk(t, sA[cur], sB[cur], wr, wc, lane);
-        if (more) stage_store(s, sA[cur ^ 1], sB[cur ^ 1], tid);
+        tile_mma_chunk(t, cur, wr, wc, lane);
+        if (more) stage_store(s, cur ^ 1, tid);
         __syncthreads();
     }
 }

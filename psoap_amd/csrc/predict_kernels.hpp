@@ -77,11 +77,10 @@ __global__ __launch_bounds__(256) void k_fill_region(double* __restrict__ out, s
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_sub(const double* __restrict__ W, size_t ldw, int K,
                                                              double* __restrict__ S, size_t lds)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     const int ti = blockIdx.y, tj = blockIdx.x;
     Tile t;
     t.zero();
-    tile_gemm_tn(t, W + (size_t)NB * ti, ldw, W + (size_t)NB * tj, ldw, K, smem);
+    tile_gemm_tn(t, W + (size_t)NB * ti, ldw, W + (size_t)NB * tj, ldw, K);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 #pragma unroll
