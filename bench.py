@@ -79,7 +79,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--walkers", type=int, default=N_WALKERS)
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config shape (3 = SB2 N=6000)")
-    ap.add_argument("--groups", type=int, default=2, help="concurrent stream groups per batch")
+    ap.add_argument("--groups", type=int, default=2, help="concurrent stream groups per batch (staged mode)")
+    ap.add_argument("--mode", default="dag", choices=["dag", "staged"], help="execution mode of the batch eval")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -111,6 +112,7 @@ def main():
 
     h = ChunkHandle(chunk.fl, chunk.sigma, max_batch=B, device=local_rank)
     h.set_stream_groups(args.groups)
+    h.set_mode(args.mode)
     h.upload(lwls, gps)          # proposals resident in HBM before the timed region
     h.sync()
 
@@ -146,9 +148,16 @@ def main():
     h.fetch()
     tm = h.timings()
     h.set_profiling(False)
-    pu = tm["panel_update"]
-    avg_ms = pu["ms"] / max(1, pu["launches"])
-    alg_per_launch = B * flops_panel_update(N) / max(1, pu["launches"])
+    mode = "dag" if tm["dag"]["launches"] > 0 else "staged"
+    if mode == "dag":
+        # one persistent launch does the whole factorisation + solve of the batch:
+        # algorithmic flops per launch = B x F(N)  
+        dom, dom_name = tm["dag"], "k_chol_dag (persistent tile DAG, v_mfma_f64_16x16x4_f64)"
+        alg_per_launch = B * flops_eval(N) / max(1, dom["launches"])
+    else:
+        dom, dom_name = tm["panel_update"], "k_panel_update (v_mfma_f64_16x16x4_f64)"
+        alg_per_launch = B * flops_panel_update(N) / max(1, dom["launches"])
+    avg_ms = dom["ms"] / max(1, dom["launches"])
     achieved = alg_per_launch / (avg_ms * 1e-3) / 1e12
     fill = tm["fill"]
 
@@ -162,14 +171,14 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"SB2 chunk 20 epochs x 300 px (N={N}), {B} walkers per step per GPU, "
                                    f"one chunk per GPU (BASELINE.json configs[2]; configs[3] at 8 GPUs)",
-                       "N": N, "components": c, "walkers": B, "chunks_per_gpu": 1, "stream_groups": args.groups,
+                       "N": N, "components": c, "walkers": B, "chunks_per_gpu": 1, "mode": args.mode, "stream_groups": args.groups,
                        "parallelism": f"chunk-sharded x{world}, RCCL all_gather of walker lnprobs"},
-            "roofline": {"bound": "mfma", "kernel": "k_panel_update (v_mfma_f64_16x16x4_f64)",
+            "roofline": {"bound": "mfma", "kernel": dom_name,
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_TFLOPS, "traffic": None,
-                         "launches_per_step": pu["launches"], "avg_launch_ms": avg_ms,
+                         "launches_per_step": dom["launches"], "avg_launch_ms": avg_ms,
                          "algorithmic_flops_per_launch": alg_per_launch,
-                         "executed_tflops": pu["flops"] / (pu["ms"] * 1e-3) / 1e12 if pu["ms"] > 0 else None,
+                         "executed_tflops": dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else None,
                          "measured_peak": mb["mfma_f64_tflops"]},
             "roofline_eval": {"bound": "mfma", "achieved": value / world * flops_eval(N) / 1e12,
                               "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
@@ -181,7 +190,7 @@ def main():
                               "frac": fill["bytes"] / (fill["ms"] * 1e-3) / 1e9 / 8000.0 if fill["ms"] > 0 else None,
                               "measured_write_peak": mb["hbm_write_gbs"]},
             "kernel_ms_profiled_step": {k: round(tm[k]["ms"], 3) for k in
-                                        ("fill", "panel_update", "potrf", "trsm", "misc")},
+                                        ("fill", "panel_update", "potrf", "trsm", "misc", "dag")},
             "profiled_step_total_ms": tm["total_ms"],
             "lnprob_walker0": float(total[0]),
         }

@@ -113,7 +113,8 @@ enum {
     PSOAP_K_POTRF = 2,
     PSOAP_K_TRSM = 3,
     PSOAP_K_MISC = 4,
-    PSOAP_K_CLASSES = 5
+    PSOAP_K_DAG = 5,          /* the persistent dependency-graph kernel (whole factorisation) */
+    PSOAP_K_CLASSES = 6
 };
 typedef struct {
     double ms[PSOAP_K_CLASSES];      /* summed device time per class */
@@ -124,8 +125,15 @@ typedef struct {
 } psoap_timings;
 int psoap_chunk_set_profiling(psoap_chunk *h, int enabled);
 int psoap_chunk_get_timings(psoap_chunk *h, psoap_timings *t);
-/* Number of concurrent stream groups a batch is split into (default 2). */
+/* Number of concurrent stream groups a batch is split into (staged mode; default 2). */
 int psoap_chunk_set_stream_groups(psoap_chunk *h, int groups);
+/* Execution mode of psoap_batch_eval: 1 (default) = one persistent dependency-graph kernel
+ * for the whole batched factorisation; 0 = staged, three kernels per 128-row panel. */
+int psoap_chunk_set_mode(psoap_chunk *h, int mode);
+
+/* Debug aid for the persistent kernel: the first call allocates a per-task timestamp log, later
+ * calls copy it out (4 x 100 MHz stamps per task, indexed by ticket). */
+int psoap_chunk_dag_tasklog(psoap_chunk *h, unsigned long long *out, long long max_tasks);
 
 /* fp64 MFMA / HBM micro-benchmarks used to state the measured peaks beside the
  * spec peaks in bench.py (results in TFLOP/s and GB/s). */

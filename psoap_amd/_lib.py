@@ -14,8 +14,8 @@ _ip = ctypes.POINTER(ctypes.c_int)
 _i32p = ctypes.POINTER(ctypes.c_int32)
 _vp = ctypes.c_void_p
 
-K_CLASSES = 5
-K_NAMES = ("fill", "panel_update", "potrf", "trsm", "misc")
+K_CLASSES = 6
+K_NAMES = ("fill", "panel_update", "potrf", "trsm", "misc", "dag")
 
 
 class Timings(ctypes.Structure):
@@ -54,6 +54,8 @@ SIGNATURES = {
     "psoap_chunk_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "psoap_chunk_get_timings": (ctypes.c_int, [_vp, ctypes.POINTER(Timings)]),
     "psoap_chunk_set_stream_groups": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "psoap_chunk_set_mode": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "psoap_chunk_dag_tasklog": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_longlong]),
     "psoap_microbench_mfma_f64": (ctypes.c_int, [ctypes.c_int, _dp]),
     "psoap_microbench_hbm": (ctypes.c_int, [ctypes.c_int, _dp, _dp]),
 }

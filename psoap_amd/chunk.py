@@ -68,6 +68,11 @@ class ChunkHandle:
     def set_stream_groups(self, groups: int):
         check(self._L.psoap_chunk_set_stream_groups(self._h, int(groups)), "psoap_chunk_set_stream_groups")
 
+    def set_mode(self, mode: str | int):
+        """"dag" (default): one persistent dependency-graph kernel; "staged": three kernels per panel."""
+        m = {"staged": 0, "dag": 1}.get(mode, mode)
+        check(self._L.psoap_chunk_set_mode(self._h, int(m)), "psoap_chunk_set_mode")
+
     def set_profiling(self, enabled: bool):
         check(self._L.psoap_chunk_set_profiling(self._h, int(bool(enabled))), "psoap_chunk_set_profiling")
 

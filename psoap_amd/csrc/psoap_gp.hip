@@ -5,12 +5,14 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <stddef.h>
 #include <string.h>
 
 #include <string>
 #include <vector>
 
 #include "chol_kernels.hpp"
+#include "dag_kernel.hpp"
 #include "fill_kernels.hpp"
 #include "microbench_kernels.hpp"
 #include "predict_kernels.hpp"
@@ -59,6 +61,12 @@ struct psoap_chunk {
     double* dGp = nullptr;   // max_batch x 6
     double* dVel = nullptr;  // max_batch x 3 x n_epochs
     double* dOut = nullptr;  // max_batch
+    char* dDag = nullptr;    // DagCtl followed by max_batch MatFlags (zeroed before every DAG launch)
+    unsigned int* hDagErr = nullptr;
+    int mode = 1;            // 1 = persistent DAG kernel, 0 = staged panels
+    int dag_grid = 0;
+    unsigned long long* dTlog = nullptr;  // optional per-task timestamps (debug)
+    long long tlog_tasks = 0;
     // pinned host staging
     double* hLwl = nullptr;
     double* hGp = nullptr;
@@ -104,6 +112,8 @@ static int configure_kernels()
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_strip),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
     HIP_TRY(predict_configure_kernels());
     done = true;
     return 0;
@@ -136,6 +146,19 @@ extern "C" int psoap_chunk_create(psoap_chunk** out, int device, int N, const do
     HIP_TRY(hipHostMalloc(&h->hLwl, sizeof(double) * nb * 3 * N));
     HIP_TRY(hipHostMalloc(&h->hGp, sizeof(double) * nb * 6));
     HIP_TRY(hipHostMalloc(&h->hOut, sizeof(double) * nb));
+    HIP_TRY(hipMalloc(&h->dDag, sizeof(DagCtl) + sizeof(MatFlags) * nb));
+    HIP_TRY(hipHostMalloc(&h->hDagErr, 64));
+    h->hDagErr[0] = 0;
+    {
+        int blocks_per_cu = 0;
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_chol_dag, GEMM_THREADS,
+                                                             GEMM_LDS_BYTES));
+        if (blocks_per_cu < 1) blocks_per_cu = 1;
+        if (blocks_per_cu > 2) blocks_per_cu = 2;
+        h->dag_grid = blocks_per_cu * prop.multiProcessorCount;
+    }
     for (int g = 0; g < MAX_GROUPS; ++g) {
         HIP_TRY(hipStreamCreateWithFlags(&h->streams[g], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&h->evDone[g], hipEventDisableTiming));
@@ -155,6 +178,7 @@ extern "C" int psoap_chunk_destroy(psoap_chunk* h)
     (void)hipFree(h->dFl); (void)hipFree(h->dSigma); (void)hipFree(h->dGrid); (void)hipFree(h->dEpoch);
     (void)hipFree(h->dK); (void)hipFree(h->dWt); (void)hipFree(h->dR); (void)hipFree(h->dAcc);
     (void)hipFree(h->dLwl); (void)hipFree(h->dGp); (void)hipFree(h->dVel); (void)hipFree(h->dOut);
+    (void)hipFree(h->dDag); (void)hipHostFree(h->hDagErr); (void)hipFree(h->dTlog);
     (void)hipHostFree(h->hLwl); (void)hipHostFree(h->hGp); (void)hipHostFree(h->hVel); (void)hipHostFree(h->hOut);
     for (int g = 0; g < MAX_GROUPS; ++g) {
         if (h->streams[g]) (void)hipStreamDestroy(h->streams[g]);
@@ -199,6 +223,33 @@ extern "C" int psoap_chunk_set_stream_groups(psoap_chunk* h, int groups)
 {
     if (!h || groups < 1 || groups > MAX_GROUPS) FAIL("psoap_chunk_set_stream_groups: 1 <= groups <= 8");
     h->groups = groups;
+    return 0;
+}
+
+// Debug: allocate a per-task timestamp log for the DAG kernel and read it back
+// (4 x 100 MHz stamps per task: start, updated, diagonal ready / factored, end).
+extern "C" int psoap_chunk_dag_tasklog(psoap_chunk* h, unsigned long long* out, long long max_tasks)
+{
+    if (!h) FAIL("null handle");
+    if (set_dev(h)) return 1;
+    const long long tasks = (long long)h->max_batch * h->P * (h->P + 1) / 2;
+    if (!h->dTlog) {
+        HIP_TRY(hipMalloc(&h->dTlog, sizeof(unsigned long long) * 4 * tasks));
+        HIP_TRY(hipMemset(h->dTlog, 0, sizeof(unsigned long long) * 4 * tasks));
+        h->tlog_tasks = tasks;
+        return 0;
+    }
+    if (out) {
+        const long long n = max_tasks < tasks ? max_tasks : tasks;
+        HIP_TRY(hipMemcpy(out, h->dTlog, sizeof(unsigned long long) * 4 * n, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+extern "C" int psoap_chunk_set_mode(psoap_chunk* h, int mode)
+{
+    if (!h || mode < 0 || mode > 1) FAIL("psoap_chunk_set_mode: mode must be 0 (staged) or 1 (dag)");
+    h->mode = mode;
     return 0;
 }
 
@@ -297,10 +348,51 @@ static void launch_fill(psoap_chunk* h, hipStream_t s, int b0, int nb, int upper
                        h->dGp + (size_t)b0 * 2 * C, h->dSigma, upper_only);
 }
 
+// One persistent launch for the whole batched factorisation (dag_kernel.hpp).
+static int eval_dag(psoap_chunk* h)
+{
+    const int B = h->B, C = h->C, N = h->N, P = h->P;
+    hipStream_t s = h->streams[0];
+    h->recs.clear();
+    const double fbytes = (double)B * (4.0 * N * (N + 1.0) + 8.0 * (C + 1.0) * N);
+    if (prof_begin(h, s, PSOAP_K_FILL, 0.0, fbytes)) return 1;
+    if (C == 1) launch_fill<1>(h, s, 0, B, 1);
+    else if (C == 2) launch_fill<2>(h, s, 0, B, 1);
+    else launch_fill<3>(h, s, 0, B, 1);
+    HIP_TRY(hipGetLastError());
+    if (prof_end(h, s)) return 1;
+    if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
+    hipLaunchKernelGGL(k_init_rhs, dim3((h->Npad + 255) / 256, B), dim3(256), 0, s, h->dR, h->Npad, N, h->dFl,
+                       h->mu, h->dAcc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(h->dDag, 0, sizeof(DagCtl) + sizeof(MatFlags) * (size_t)B, s));
+    if (prof_end(h, s)) return 1;
+    const long long tasks = (long long)B * P * (P + 1) / 2;
+    const int grid = (int)(tasks < h->dag_grid ? tasks : h->dag_grid);
+    // executed MFMA flops: left-looking updates + strip solves, full 128^3 tiles
+    double fl = 0.0;
+    for (int q = 0; q < P; ++q) fl += 2.0 * NB * NB * ((double)q * NB * (P - q) + (double)NB * (P - q - 1));
+    if (prof_begin(h, s, PSOAP_K_DAG, fl * B, 0.0)) return 1;
+    hipLaunchKernelGGL(k_chol_dag, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, h->dK, h->mat_stride, h->ld, P,
+                       B, h->dWt, h->dR, h->Npad, h->dAcc, reinterpret_cast<MatFlags*>(h->dDag + sizeof(DagCtl)),
+                       reinterpret_cast<DagCtl*>(h->dDag), h->dTlog);
+    HIP_TRY(hipGetLastError());
+    if (prof_end(h, s)) return 1;
+    if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
+    hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, h->dAcc, h->dOut, B);
+    HIP_TRY(hipGetLastError());
+    if (prof_end(h, s)) return 1;
+    HIP_TRY(hipMemcpyAsync(h->hOut, h->dOut, sizeof(double) * B, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h->hDagErr, h->dDag + offsetof(DagCtl, error), 4 * sizeof(unsigned int),
+                           hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
 extern "C" int psoap_batch_eval(psoap_chunk* h)
 {
     if (!h || h->B < 1) FAIL("psoap_batch_eval: nothing uploaded");
     if (set_dev(h)) return 1;
+    if (h->mode == 1) return eval_dag(h);
     const int B = h->B, C = h->C, N = h->N, P = h->P;
     const int G = h->profiling ? 1 : (h->groups < B ? h->groups : B);
     h->recs.clear();
@@ -399,6 +491,18 @@ extern "C" int psoap_batch_fetch(psoap_chunk* h, double* out)
     if (set_dev(h)) return 1;
     HIP_TRY(hipStreamSynchronize(h->streams[0]));
     if (collect_timings(h)) return 1;
+    if (h->mode == 1 && h->hDagErr[0] != 0) {
+        char buf[512];
+        int dbg[32] = {0};
+        (void)hipMemcpy(dbg, h->dDag, sizeof dbg, hipMemcpyDeviceToHost);
+        snprintf(buf, sizeof buf,
+                 "psoap_batch_fetch: a dependency wait in the DAG kernel timed out (results invalid); "
+                 "first failing wait: code=%u target=%u seen=%u; ticket=%d err=%d; matrix0 rows_done=%d "
+                 "potrf_done=%d cnt=%d",
+                 h->hDagErr[1], h->hDagErr[2], h->hDagErr[3], dbg[0], dbg[1], dbg[16], dbg[17], dbg[18]);
+        h->hDagErr[0] = 0;
+        FAIL(buf);
+    }
     for (int b = 0; b < h->B; ++b) out[b] = h->neg[b] ? -INFINITY : h->hOut[b];
     return 0;
 }

@@ -146,25 +146,52 @@ def test_batch_matches_singles_and_oracle(golden, oracle):
     gps[3, 1] = -1.0                                  # one rejected proposal inside the batch
     lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, nw, seed=12))
     with ChunkHandle(ch.fl, ch.sigma, max_batch=8) as h:
-        for groups in (1, 2, 3):
+        results = {}
+        for mode, groups in (("dag", 1), ("staged", 1), ("staged", 2), ("staged", 3)):
+            h.set_mode(mode)
             h.set_stream_groups(groups)
             got = h.lnlike_batch(lw, gps)
+            results[(mode, groups)] = got
             for w in range(nw):
                 want = oracle.lnlike(lw[w], ch.fl, ch.sigma, gps[w])
                 if w == 3:
                     assert got[w] == -np.inf and want == -np.inf
                 else:
-                    assert lnp_close(got[w], want), (groups, w, got[w], want)
-        # determinism: same inputs, same bits
-        again = h.lnlike_batch(lw, gps)
-        assert np.array_equal(again, got)
-        # profiling mode (single group, per-launch events) gives the same numbers
+                    assert lnp_close(got[w], want), (mode, groups, w, got[w], want)
+            # determinism: same inputs, same bits, every time
+            for _ in range(3):
+                assert np.array_equal(h.lnlike_batch(lw, gps), got)
+        # staged results do not depend on the stream grouping
+        assert np.array_equal(results[("staged", 1)], results[("staged", 3)])
+        # profiling mode (per-launch events) gives the same numbers
+        h.set_mode("staged")
         h.set_profiling(True)
         prof = h.lnlike_batch(lw, gps)
-        assert np.array_equal(prof, got)
+        assert np.array_equal(prof, results[("staged", 1)])
         t = h.timings()
         assert t["panel_update"]["launches"] == 4 and t["potrf"]["launches"] == 5
+        h.set_mode("dag")
+        prof = h.lnlike_batch(lw, gps)
+        assert np.array_equal(prof, results[("dag", 1)])
+        assert h.timings()["dag"]["launches"] == 1
         h.set_profiling(False)
+
+
+@pytest.mark.parametrize("mode", ["dag", "staged"])
+def test_modes_full_size_batch(golden, mode):
+    """Both execution modes at BASELINE config 3 with a batch that oversubscribes the persistent grid."""
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_config_chunk(3)
+    gps = syn.make_walkers(2, 4, seed=3500)
+    lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, 4, seed=3501))
+    reps = 3
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=4 * reps) as h:
+        h.set_mode(mode)
+        got = h.lnlike_batch(np.concatenate([lw] * reps), np.concatenate([gps] * reps))
+        for w in range(4 * reps):
+            assert lnp_close(got[w], golden["walkers_cfg3"][w % 4]), (mode, w, got[w])
+        # identical proposals in different batch slots give identical bits
+        assert np.array_equal(got[:4], got[4:8]) and np.array_equal(got[:4], got[8:])
 
 
 def test_walker_batch_cfg3_golden(golden):
