@@ -25,6 +25,7 @@
 // rows < q; it is split so that rows < q-1 are consumed before waiting for row q-1 (look-ahead).
 #pragma once
 #include "chol_kernels.hpp"
+#include "fill_kernels.hpp"
 
 namespace psoap {
 
@@ -116,20 +117,55 @@ __device__ __forceinline__ void dag_update(Tile& t, double* Km, int ld, int k0, 
     tile_gemm_tn(t, Km + (size_t)k1 * ld + k0, (size_t)ld, Km + (size_t)k1 * ld + j0, (size_t)ld, NB);
 }
 
-// C = C - acc for tile (k0, j0), MFMA accumulator layout
-__device__ __forceinline__ void dag_store_updated(const Tile& t, double* Km, int ld, int k0, int j0)
+// Fused kernel-matrix fill: tile (k0, j0) <- K(i, j) - acc, with K evaluated on the fly in the
+// MFMA accumulator layout (same arithmetic as k_fill_sym: squared-exponential sum, diagonal rule,
+// sigma^2 on the diagonal, identity padding).  The covariance matrix is therefore never
+// materialised in HBM: each tile is written exactly once, already updated.
+template <int C>
+__device__ __forceinline__ void dag_store_updated(const Tile& t, double* Km, int ld, int k0, int j0,
+                                                  const double* __restrict__ lw, const GpDev& g, double dsum,
+                                                  const double* __restrict__ sigma, int N)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
+    double xj[4][C];
+    int jj[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int n = 0; n < 4; ++n) {
+        jj[n] = j0 + tile_col(wc, n, lane);
+#pragma unroll
+        for (int c = 0; c < C; ++c) xj[n][c] = (jj[n] < N) ? lw[(size_t)c * N + jj[n]] : 0.0;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        double xi[4][C];
+        int ii[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ii[r] = k0 + tile_row(wr, m, lane, r);
+#pragma unroll
+            for (int c = 0; c < C; ++c) xi[r][c] = (ii[r] < N) ? lw[(size_t)c * N + ii[r]] : 0.0;
+        }
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                double* p = Km + (size_t)(k0 + tile_row(wr, m, lane, r)) * ld + j0 + tile_col(wc, n, lane);
-                *p = *p - t.acc[m][n][r];
+                const int i = ii[r], j = jj[n];
+                double v;
+                if (i < N && j < N) {
+                    if (i == j) {
+#pragma clang fp contract(off)
+                        const double sg = sigma[i];
+                        v = dsum + sg * sg;
+                    } else {
+                        v = kern_elem<C>(xi[r], xj[n], g);
+                    }
+                } else {
+                    v = (i == j) ? 1.0 : 0.0;
+                }
+                Km[(size_t)i * ld + j] = v - t.acc[m][n][r];
             }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -205,6 +241,9 @@ __device__ __forceinline__ void potrf256(double* Km, int ld, int k0, double* Wm,
     }
     if (tid < NB) rk[tid] = Rv[k0 + tid];
     int bad = 0;
+    // the factorisation is a latency-bound chain on the batch's critical path: let its waves win
+    // issue arbitration against the MFMA workgroup sharing the CU
+    __builtin_amdgcn_s_setprio(3);
     potrf256_phase<0>(M, rowbuf, dinv, ty, tx, bad);
     potrf256_phase<1>(M, rowbuf, dinv, ty, tx, bad);
     potrf256_phase<2>(M, rowbuf, dinv, ty, tx, bad);
@@ -213,6 +252,7 @@ __device__ __forceinline__ void potrf256(double* Km, int ld, int k0, double* Wm,
     potrf256_phase<5>(M, rowbuf, dinv, ty, tx, bad);
     potrf256_phase<6>(M, rowbuf, dinv, ty, tx, bad);
     potrf256_phase<7>(M, rowbuf, dinv, ty, tx, bad);
+    __builtin_amdgcn_s_setprio(0);
     __syncthreads();
 
     double logpart = 0.0, quadpart = 0.0;
@@ -310,10 +350,13 @@ __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, in
     }
 }
 
+template <int C>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, size_t mat_stride, int ld, int P, int B,
                                                              double* Wt, double* Rbase, int Npad, MatAcc* acc,
-                                                             MatFlags* flags, DagCtl* ctl,
-                                                             unsigned long long* tlog)
+                                                             MatFlags* flags, DagCtl* ctl, unsigned long long* tlog,
+                                                             const double* __restrict__ lwl,
+                                                             const double* __restrict__ gp,
+                                                             const double* __restrict__ sigma, int N)
 {
     __shared__ double rowbuf[2][NB];
     __shared__ double dinv[NB];
@@ -352,7 +395,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
 
         if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 0] = __builtin_amdgcn_s_memrealtime();
         dag_update(t, Km, ld, k0, j0, q, f, ctl);
-        dag_store_updated(t, Km, ld, k0, j0);
+        {
+            GpDev g;
+            load_gp(gp + (size_t)b * 2 * C, C, g);
+            double dsum = g.a2[0];
+            {
+#pragma clang fp contract(off)
+                for (int c = 1; c < C; ++c) dsum = dsum + g.a2[c];
+            }
+            dag_store_updated<C>(t, Km, ld, k0, j0, lwl + (size_t)b * C * N, g, dsum, sigma, N);
+        }
         dag_drain();  // the tile is re-read below in another layout by other waves of this block
         if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 1] = __builtin_amdgcn_s_memrealtime();
         if (j == q) {

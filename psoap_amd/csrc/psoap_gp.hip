@@ -112,7 +112,11 @@ static int configure_kernels()
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_strip),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag),
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag<3>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
     HIP_TRY(predict_configure_kernels());
     done = true;
@@ -153,7 +157,7 @@ extern "C" int psoap_chunk_create(psoap_chunk** out, int device, int N, const do
         int blocks_per_cu = 0;
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_chol_dag, GEMM_THREADS,
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_chol_dag<3>, GEMM_THREADS,
                                                              GEMM_LDS_BYTES));
         if (blocks_per_cu < 1) blocks_per_cu = 1;
         if (blocks_per_cu > 2) blocks_per_cu = 2;
@@ -354,13 +358,7 @@ static int eval_dag(psoap_chunk* h)
     const int B = h->B, C = h->C, N = h->N, P = h->P;
     hipStream_t s = h->streams[0];
     h->recs.clear();
-    const double fbytes = (double)B * (4.0 * N * (N + 1.0) + 8.0 * (C + 1.0) * N);
-    if (prof_begin(h, s, PSOAP_K_FILL, 0.0, fbytes)) return 1;
-    if (C == 1) launch_fill<1>(h, s, 0, B, 1);
-    else if (C == 2) launch_fill<2>(h, s, 0, B, 1);
-    else launch_fill<3>(h, s, 0, B, 1);
-    HIP_TRY(hipGetLastError());
-    if (prof_end(h, s)) return 1;
+    // no fill kernel: the DAG kernel evaluates the covariance tiles on the fly (dag_store_updated)
     if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
     hipLaunchKernelGGL(k_init_rhs, dim3((h->Npad + 255) / 256, B), dim3(256), 0, s, h->dR, h->Npad, N, h->dFl,
                        h->mu, h->dAcc);
@@ -373,9 +371,18 @@ static int eval_dag(psoap_chunk* h)
     double fl = 0.0;
     for (int q = 0; q < P; ++q) fl += 2.0 * NB * NB * ((double)q * NB * (P - q) + (double)NB * (P - q - 1));
     if (prof_begin(h, s, PSOAP_K_DAG, fl * B, 0.0)) return 1;
-    hipLaunchKernelGGL(k_chol_dag, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, h->dK, h->mat_stride, h->ld, P,
-                       B, h->dWt, h->dR, h->Npad, h->dAcc, reinterpret_cast<MatFlags*>(h->dDag + sizeof(DagCtl)),
-                       reinterpret_cast<DagCtl*>(h->dDag), h->dTlog);
+    {
+        MatFlags* fl_ = reinterpret_cast<MatFlags*>(h->dDag + sizeof(DagCtl));
+        DagCtl* ctl_ = reinterpret_cast<DagCtl*>(h->dDag);
+#define PSOAP_LAUNCH_DAG(CC)                                                                                     \
+    hipLaunchKernelGGL(k_chol_dag<CC>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, h->dK, h->mat_stride,   \
+                       h->ld, P, B, h->dWt, h->dR, h->Npad, h->dAcc, fl_, ctl_, h->dTlog, h->dLwl, h->dGp,       \
+                       h->dSigma, N)
+        if (C == 1) PSOAP_LAUNCH_DAG(1);
+        else if (C == 2) PSOAP_LAUNCH_DAG(2);
+        else PSOAP_LAUNCH_DAG(3);
+#undef PSOAP_LAUNCH_DAG
+    }
     HIP_TRY(hipGetLastError());
     if (prof_end(h, s)) return 1;
     if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
