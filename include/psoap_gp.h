@@ -134,6 +134,9 @@ int psoap_chunk_set_mode(psoap_chunk *h, int mode);
 /* Debug aid for the persistent kernel: the first call allocates a per-task timestamp log, later
  * calls copy it out (4 x 100 MHz stamps per task, indexed by ticket). */
 int psoap_chunk_dag_tasklog(psoap_chunk *h, unsigned long long *out, long long max_tasks);
+/* Debug aid: the persistent kernel's task list (16-byte records: type, q, j, S, b(u16), pa, pb,
+ * slot(u32), ctr(u32)) in ticket order; *n_tasks receives the list length. */
+int psoap_chunk_dag_tasks(psoap_chunk *h, void *out, long long max_tasks, long long *n_tasks);
 
 /* fp64 MFMA / HBM micro-benchmarks used to state the measured peaks beside the
  * spec peaks in bench.py (results in TFLOP/s and GB/s). */

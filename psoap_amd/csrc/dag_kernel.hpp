@@ -24,6 +24,8 @@
 // factored), cnt (finished tasks of the current block row).  The update of block row q reads
 // rows < q; it is split so that rows < q-1 are consumed before waiting for row q-1 (look-ahead).
 #pragma once
+#include <vector>
+
 #include "chol_kernels.hpp"
 #include "fill_kernels.hpp"
 
@@ -41,6 +43,26 @@ struct alignas(64) DagCtl {
     unsigned int error;
     unsigned int pad[14];
 };
+
+// One entry of the host-built task list (dag_build_tasks); the ticket is the index.
+//   PART : partial left-looking update of tile (q, j) over finished block rows [pa, pb); the
+//          128 x 128 partial sum goes to workspace slot `slot`, then arrive[ctr] += 1.
+//   DIAG / OFF : the final part [pa, pb) of the update, plus the S-1 partials of slots
+//          slot .. slot+S-2 (added in slot order once arrive[ctr] == S-1), then the tile's
+//          factorisation (DIAG) or strip solve (OFF).
+// Splitting along K serves two purposes: the diagonal tile of block row q+1 is pre-accumulated
+// over rows < q while block row q is still in flight (its final part is one panel long, so the
+// critical chain per block row is 128-row update -> in-block Cholesky), and the last block rows,
+// which have too few tiles to occupy the persistent grid, are cut into up to 8 parts per tile.
+enum : unsigned char { DAG_PART = 0, DAG_DIAG = 1, DAG_OFF = 2 };
+struct DagTask {
+    unsigned char type, q, j, S;
+    unsigned short b;
+    unsigned char pa, pb;
+    unsigned int slot;
+    unsigned int ctr;
+};
+static_assert(sizeof(DagTask) == 16, "DagTask is 16 bytes");
 
 constexpr long long DAG_MAX_SPINS = 2000000;  // x (s_sleep + atomic round trip) ~ seconds
 
@@ -102,29 +124,40 @@ __device__ __forceinline__ void dag_task_done(MatFlags* f, int q, int ntasks_row
     }
 }
 
-// left-looking update with look-ahead: rows [0, k0-128) need rows_done >= q-1, the last 128 need q
-__device__ __forceinline__ void dag_update(Tile& t, double* Km, int ld, int k0, int j0, int q, MatFlags* f,
+// left-looking update over finished block rows [pa, pb) with look-ahead: all but the last panel
+// need rows_done >= pb-1, the last one rows_done >= pb
+__device__ __forceinline__ void dag_update(Tile& t, double* Km, int ld, int k0, int j0, int pa, int pb, MatFlags* f,
                                            DagCtl* ctl)
 {
-    t.zero();
-    if (q == 0) return;
-    const int k1 = k0 - NB;
-    if (k1 > 0) {
-        dag_wait_ge(&f->rows_done, q - 1, ctl, 1u);
-        tile_gemm_tn(t, Km + k0, (size_t)ld, Km + j0, (size_t)ld, k1);
+    if (pb <= pa) return;
+    const bool diag = (k0 == j0);
+    if (pb - pa > 1) {
+        dag_wait_ge(&f->rows_done, pb - 1, ctl, 1u);
+        const size_t r0 = (size_t)pa * NB;
+        tile_gemm_tn(t, Km + r0 * ld + k0, (size_t)ld, Km + r0 * ld + j0, (size_t)ld, (pb - 1 - pa) * NB, diag);
     }
-    dag_wait_ge(&f->rows_done, q, ctl, 2u);
-    tile_gemm_tn(t, Km + (size_t)k1 * ld + k0, (size_t)ld, Km + (size_t)k1 * ld + j0, (size_t)ld, NB);
+    dag_wait_ge(&f->rows_done, pb, ctl, 2u);
+    const size_t r1 = (size_t)(pb - 1) * NB;
+    tile_gemm_tn(t, Km + r1 * ld + k0, (size_t)ld, Km + r1 * ld + j0, (size_t)ld, NB, diag);
 }
 
-// Fused kernel-matrix fill: tile (k0, j0) <- K(i, j) - acc, with K evaluated on the fly in the
-// MFMA accumulator layout (same arithmetic as k_fill_sym: squared-exponential sum, diagonal rule,
-// sigma^2 on the diagonal, identity padding).  The covariance matrix is therefore never
-// materialised in HBM: each tile is written exactly once, already updated.
+// partial sums travel through HBM as [register index][thread] so that every wave stores / loads
+// 512 contiguous bytes per instruction
+// The ONE consumer of the accumulators.  Every task ends its update here:
+//     dest(i, j) <- scale * K(i, j) - acc(i, j) + sum_s part_s(i, j)
+//   final tasks : dest = the tile (k0, j0) of the matrix, scale = 1, part_s = the n_part partial
+//                 tiles written by this tile's PART tasks (they hold -acc_s);
+//   PART tasks  : dest = a workspace slot (row-major 128 x 128), scale = 0, n_part = 0.
+// K is evaluated on the fly in the MFMA accumulator layout (same arithmetic as k_fill_sym:
+// squared-exponential sum, diagonal rule, sigma^2 on the diagonal, identity padding), so the
+// covariance matrix is never materialised in HBM: each tile is written once, already updated.
+// (A separate store routine for PART tasks would be cheaper by 64 x C exp() per thread, but a
+// second consumer of the 128 accumulator registers makes hipcc spill them inside the MFMA loops.)
 template <int C>
-__device__ __forceinline__ void dag_store_updated(const Tile& t, double* Km, int ld, int k0, int j0,
+__device__ __forceinline__ void dag_store_updated(const Tile& t, double* dest, size_t ldd, int k0, int j0,
                                                   const double* __restrict__ lw, const GpDev& g, double dsum,
-                                                  const double* __restrict__ sigma, int N)
+                                                  const double* __restrict__ sigma, int N, double scale,
+                                                  const double* part, int n_part)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -163,7 +196,10 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* Km, int
                 } else {
                     v = (i == j) ? 1.0 : 0.0;
                 }
-                Km[(size_t)i * ld + j] = v - t.acc[m][n][r];
+                const size_t off = (size_t)(i - k0) * NB + (size_t)(j - j0);   // inside a 128 x 128 slot
+                double x = scale * v - t.acc[m][n][r];
+                for (int sidx = 0; sidx < n_part; ++sidx) x += part[(size_t)sidx * NB * NB + off];
+                dest[(size_t)(i - k0) * ldd + (size_t)(j - j0)] = x;
             }
     }
 }
@@ -314,7 +350,7 @@ __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, in
     const int tid = threadIdx.x;
     if (tid < NB) zk[tid] = Rv[k0 + tid];
     t.zero();
-    tile_gemm_tn(t, Wm, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld, NB);
+    tile_gemm_tn(t, Wm, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld, NB, false, NB / 2);
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     double part[4] = {0.0, 0.0, 0.0, 0.0};
@@ -351,9 +387,11 @@ __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, in
 }
 
 template <int C>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, size_t mat_stride, int ld, int P, int B,
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, size_t mat_stride, int ld, int P,
+                                                             const DagTask* __restrict__ tasks, unsigned int total,
                                                              double* Wt, double* Rbase, int Npad, MatAcc* acc,
-                                                             MatFlags* flags, DagCtl* ctl, unsigned long long* tlog,
+                                                             MatFlags* flags, int* arrive, double* wspace,
+                                                             DagCtl* ctl, unsigned long long* tlog,
                                                              const double* __restrict__ lwl,
                                                              const double* __restrict__ gp,
                                                              const double* __restrict__ sigma, int N)
@@ -364,37 +402,30 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
     __shared__ double vec2[NB];   // column sums (OFF)
     __shared__ double red[2][4];
     __shared__ unsigned int s_ticket;
-    const unsigned int total = (unsigned int)B * (unsigned int)(P * (P + 1) / 2);
-    Tile t;
+    constexpr size_t SLOT = (size_t)NB * NB;   // doubles per workspace slot
     for (;;) {
+        Tile t;
         if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&ctl->ticket, 1u, PSOAP_RLX_AGENT);
         __syncthreads();
-        const unsigned int ticket = s_ticket;
+        // wave-uniform by construction: keep it (and everything decoded from it) in scalar registers
+        const unsigned int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
         __syncthreads();  // s_ticket is rewritten at the top of the next iteration
         if (ticket >= total) return;
         if (__hip_atomic_fetch_or(&ctl->error, 0u, PSOAP_RLX_AGENT) != 0u) return;
-        int q, dummy;
-        decode_upper((int)(ticket / (unsigned int)B), P, q, dummy);
-        const int row_first = (q * P - q * (q - 1) / 2) * B;
-        const int rem = (int)ticket - row_first;
-        const int ntasks_row = P - q;
-        int b, j;
-        if (rem < B) {
-            b = rem;
-            j = q;
-        } else {
-            const int r2 = rem - B;
-            b = r2 / (ntasks_row - 1);
-            j = q + 1 + r2 % (ntasks_row - 1);
-        }
+        const DagTask task = tasks[ticket];
+        const int b = task.b, q = task.q, j = task.j;
         double* Km = Kbase + (size_t)b * mat_stride;
         double* Rv = Rbase + (size_t)b * Npad;
         double* Wm = Wt + (size_t)b * NB * NB;
         MatFlags* f = flags + b;
         const int k0 = q * NB, j0 = j * NB;
+        const int ntasks_row = P - q;
 
         if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 0] = __builtin_amdgcn_s_memrealtime();
-        dag_update(t, Km, ld, k0, j0, q, f, ctl);
+        t.zero();
+        dag_update(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl);
+        const bool is_part = (task.type == DAG_PART);
+        if (!is_part && task.S > 1) dag_wait_ge(&arrive[task.ctr], task.S - 1, ctl, 4u);
         {
             GpDev g;
             load_gp(gp + (size_t)b * 2 * C, C, g);
@@ -403,11 +434,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
 #pragma clang fp contract(off)
                 for (int c = 1; c < C; ++c) dsum = dsum + g.a2[c];
             }
-            dag_store_updated<C>(t, Km, ld, k0, j0, lwl + (size_t)b * C * N, g, dsum, sigma, N);
+            double* dest = is_part ? (wspace + (size_t)task.slot * SLOT) : (Km + (size_t)k0 * ld + j0);
+            dag_store_updated<C>(t, dest, is_part ? (size_t)NB : (size_t)ld, k0, j0, lwl + (size_t)b * C * N, g, dsum,
+                                 sigma, N, is_part ? 0.0 : 1.0, wspace + (size_t)task.slot * SLOT,
+                                 is_part ? 0 : task.S - 1);
+        }
+        if (is_part) {
+            dag_drain();
+            if (threadIdx.x == 0) {
+                dag_release_fence();
+                __hip_atomic_fetch_add(&arrive[task.ctr], 1, PSOAP_RLX_AGENT);
+            }
+            if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+            continue;
         }
         dag_drain();  // the tile is re-read below in another layout by other waves of this block
         if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-        if (j == q) {
+        if (task.type == DAG_DIAG) {
             potrf256(Km, ld, k0, Wm, Rv, acc + b, rowbuf, dinv, vec1, red);
             dag_drain();
             if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 2] = __builtin_amdgcn_s_memrealtime();
@@ -428,6 +471,108 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
         }
         if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 3] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host: build the task list for a batch of B matrices of P block rows on `workers` persistent
+// workgroups.  Ticket order (every wait targets a smaller ticket):
+//   for each block row q:  DIAG finals of row q (all b)
+//                          PARTs that pre-accumulate the diagonal tile of row q+1 over rows < q
+//                          PARTs + OFF finals of row q (b-major, then j)
+// Returns the number of workspace slots and arrival counters needed.
+// ---------------------------------------------------------------------------------------------
+struct DagPlan {
+    std::vector<DagTask> tasks;
+    unsigned int n_slots = 0;
+    unsigned int n_ctrs = 0;
+};
+
+inline int dag_split_factor(int tasks_in_row, int q, int workers)
+{
+    // cut tiles of sparse block rows until the row offers about `workers` tasks (at most 8 parts,
+    // each at least one panel long)
+    int S = 1;
+    while (S < 8 && tasks_in_row * S < workers && 2 * S <= q) S *= 2;
+    return S;
+}
+
+inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first, int pb_last, int nparts)
+{
+    // parts 0 .. nparts-2 are PARTs over equal panel ranges of [pa_first, pb_last); the final part
+    // is the task of `type`.  nparts == 1: no PART, the final covers the whole range.
+    const unsigned int ctr = (nparts > 1) ? plan.n_ctrs++ : 0u;
+    const unsigned int slot0 = plan.n_slots;
+    const int span = pb_last - pa_first;
+    for (int sidx = 0; sidx < nparts; ++sidx) {
+        DagTask t{};
+        t.b = (unsigned short)b;
+        t.q = (unsigned char)q;
+        t.j = (unsigned char)j;
+        t.S = (unsigned char)nparts;
+        t.pa = (unsigned char)(pa_first + (long long)span * sidx / nparts);
+        t.pb = (unsigned char)(pa_first + (long long)span * (sidx + 1) / nparts);
+        t.ctr = ctr;
+        if (sidx < nparts - 1) {
+            t.type = DAG_PART;
+            t.slot = plan.n_slots++;
+        } else {
+            t.type = (unsigned char)type;
+            t.slot = slot0;
+        }
+        plan.tasks.push_back(t);
+    }
+}
+
+inline DagPlan dag_build_tasks(int B, int P, int workers)
+{
+    DagPlan plan;
+    // diag_parts[q]: PART tasks of DIAG(b,q) are emitted one block row early, its final in row q
+    std::vector<std::vector<DagTask>> early_final(P);
+    for (int q = 0; q < P; ++q) {
+        const int row_tasks = B * (P - q);
+        const int S_off = dag_split_factor(row_tasks, q, workers);
+        // 1. DIAG finals of this row (their PARTs were emitted in row q-1's section)
+        if (q <= 1) {
+            for (int b = 0; b < B; ++b) dag_emit(plan, DAG_DIAG, b, q, q, 0, q, 1);
+        } else {
+            for (const DagTask& t : early_final[q]) plan.tasks.push_back(t);
+        }
+        // 2. pre-accumulate the diagonal tile of row q+1 over rows [0, q): PARTs now, final (panel q) later
+        if (q + 1 < P && q >= 1) {
+            const int S_pre = dag_split_factor(B, q, workers / 4 > 0 ? workers / 4 : 1);
+            for (int b = 0; b < B; ++b) {
+                const unsigned int ctr = plan.n_ctrs++;
+                const unsigned int slot0 = plan.n_slots;
+                for (int sidx = 0; sidx < S_pre; ++sidx) {
+                    DagTask t{};
+                    t.type = DAG_PART;
+                    t.b = (unsigned short)b;
+                    t.q = (unsigned char)(q + 1);
+                    t.j = (unsigned char)(q + 1);
+                    t.S = (unsigned char)(S_pre + 1);
+                    t.pa = (unsigned char)((long long)q * sidx / S_pre);
+                    t.pb = (unsigned char)((long long)q * (sidx + 1) / S_pre);
+                    t.slot = plan.n_slots++;
+                    t.ctr = ctr;
+                    plan.tasks.push_back(t);
+                }
+                DagTask fin{};
+                fin.type = DAG_DIAG;
+                fin.b = (unsigned short)b;
+                fin.q = fin.j = (unsigned char)(q + 1);
+                fin.S = (unsigned char)(S_pre + 1);
+                fin.pa = (unsigned char)q;
+                fin.pb = (unsigned char)(q + 1);
+                fin.slot = slot0;
+                fin.ctr = ctr;
+                early_final[q + 1].push_back(fin);
+            }
+        }
+        // 3. off-diagonal tiles of this row
+        for (int b = 0; b < B; ++b)
+            for (int j = q + 1; j < P; ++j) dag_emit(plan, DAG_OFF, b, q, j, 0, q, S_off);
+    }
+    return plan;
 }
 
 }  // namespace psoap

@@ -90,8 +90,15 @@ __device__ __forceinline__ void tile_mma_chunk(Tile& t, int buf, int wr, int wc,
 }
 
 // Needs GEMM_LDS_BYTES of dynamic LDS at launch.  All 256 threads must call this.
+// Structural-zero skipping (the MFMA pipe is the contended resource, so idle quadrants are
+// worth skipping even though every wave still stages operands and meets the barriers):
+//   skip_lower_left : wave (wr=1, wc=0) issues no MFMA -- the strictly lower quadrant of a
+//                     symmetric diagonal tile is never read back;
+//   k_limit_upper   : waves wr=0 issue no MFMA for k >= k_limit_upper -- rows 0..63 of a product
+//                     with a lower-triangular left factor (W = U11^-T) only involve k < 64.
 __device__ __forceinline__ void tile_gemm_tn(Tile& t, const double* __restrict__ A, size_t lda,
-                                             const double* __restrict__ B, size_t ldb, int K)
+                                             const double* __restrict__ B, size_t ldb, int K,
+                                             bool skip_lower_left = false, int k_limit_upper = 0x7fffffff)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -106,7 +113,8 @@ __device__ __forceinline__ void tile_gemm_tn(Tile& t, const double* __restrict__
         const int cur = c & 1;
         const bool more = (c + 1 < nchunk);
         if (more) stage_load(s, A, lda, B, ldb, (c + 1) * KB, tid);
-        tile_mma_chunk(t, cur, wr, wc, lane);
+        const bool idle = (skip_lower_left && wr == 1 && wc == 0) || (wr == 0 && c * KB >= k_limit_upper);
+        if (!idle) tile_mma_chunk(t, cur, wr, wc, lane);
         if (more) stage_store(s, cur ^ 1, tid);
         __syncthreads();
     }

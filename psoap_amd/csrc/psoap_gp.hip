@@ -65,6 +65,15 @@ struct psoap_chunk {
     unsigned int* hDagErr = nullptr;
     int mode = 1;            // 1 = persistent DAG kernel, 0 = staged panels
     int dag_grid = 0;
+    // task list of the persistent kernel for the current batch size (dag_build_tasks)
+    int plan_B = 0;
+    unsigned int plan_tasks = 0, plan_ctrs = 0, plan_slots = 0;
+    DagTask* dTasks = nullptr;
+    size_t tasks_cap = 0;
+    double* dWs = nullptr;   // split-K partial tiles, plan_slots x 128 x 128
+    size_t ws_cap = 0;
+    size_t arrive_off = 0;   // byte offset of the arrival counters inside dDag
+    size_t arrive_cap = 0;   // ints
     unsigned long long* dTlog = nullptr;  // optional per-task timestamps (debug)
     long long tlog_tasks = 0;
     // pinned host staging
@@ -150,7 +159,9 @@ extern "C" int psoap_chunk_create(psoap_chunk** out, int device, int N, const do
     HIP_TRY(hipHostMalloc(&h->hLwl, sizeof(double) * nb * 3 * N));
     HIP_TRY(hipHostMalloc(&h->hGp, sizeof(double) * nb * 6));
     HIP_TRY(hipHostMalloc(&h->hOut, sizeof(double) * nb));
-    HIP_TRY(hipMalloc(&h->dDag, sizeof(DagCtl) + sizeof(MatFlags) * nb));
+    h->arrive_off = sizeof(DagCtl) + sizeof(MatFlags) * nb;
+    h->arrive_cap = nb * (size_t)h->P * (h->P + 1) / 2 + 16;
+    HIP_TRY(hipMalloc(&h->dDag, h->arrive_off + sizeof(int) * h->arrive_cap));
     HIP_TRY(hipHostMalloc(&h->hDagErr, 64));
     h->hDagErr[0] = 0;
     {
@@ -183,6 +194,7 @@ extern "C" int psoap_chunk_destroy(psoap_chunk* h)
     (void)hipFree(h->dK); (void)hipFree(h->dWt); (void)hipFree(h->dR); (void)hipFree(h->dAcc);
     (void)hipFree(h->dLwl); (void)hipFree(h->dGp); (void)hipFree(h->dVel); (void)hipFree(h->dOut);
     (void)hipFree(h->dDag); (void)hipHostFree(h->hDagErr); (void)hipFree(h->dTlog);
+    (void)hipFree(h->dTasks); (void)hipFree(h->dWs);
     (void)hipHostFree(h->hLwl); (void)hipHostFree(h->hGp); (void)hipHostFree(h->hVel); (void)hipHostFree(h->hOut);
     for (int g = 0; g < MAX_GROUPS; ++g) {
         if (h->streams[g]) (void)hipStreamDestroy(h->streams[g]);
@@ -236,7 +248,7 @@ extern "C" int psoap_chunk_dag_tasklog(psoap_chunk* h, unsigned long long* out, 
 {
     if (!h) FAIL("null handle");
     if (set_dev(h)) return 1;
-    const long long tasks = (long long)h->max_batch * h->P * (h->P + 1) / 2;
+    const long long tasks = 4ll * h->max_batch * h->P * (h->P + 1) / 2 + 1024;
     if (!h->dTlog) {
         HIP_TRY(hipMalloc(&h->dTlog, sizeof(unsigned long long) * 4 * tasks));
         HIP_TRY(hipMemset(h->dTlog, 0, sizeof(unsigned long long) * 4 * tasks));
@@ -246,6 +258,19 @@ extern "C" int psoap_chunk_dag_tasklog(psoap_chunk* h, unsigned long long* out, 
     if (out) {
         const long long n = max_tasks < tasks ? max_tasks : tasks;
         HIP_TRY(hipMemcpy(out, h->dTlog, sizeof(unsigned long long) * 4 * n, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+// Debug: copy the current task list (16-byte DagTask records, ticket order) to the host.
+extern "C" int psoap_chunk_dag_tasks(psoap_chunk* h, void* out, long long max_tasks, long long* n_tasks)
+{
+    if (!h || !n_tasks) FAIL("bad arguments");
+    if (set_dev(h)) return 1;
+    *n_tasks = h->plan_tasks;
+    if (out && h->dTasks) {
+        const long long n = max_tasks < (long long)h->plan_tasks ? max_tasks : (long long)h->plan_tasks;
+        HIP_TRY(hipMemcpy(out, h->dTasks, sizeof(DagTask) * n, hipMemcpyDeviceToHost));
     }
     return 0;
 }
@@ -352,20 +377,49 @@ static void launch_fill(psoap_chunk* h, hipStream_t s, int b0, int nb, int upper
                        h->dGp + (size_t)b0 * 2 * C, h->dSigma, upper_only);
 }
 
+// (re)build the task list of the persistent kernel when the batch size changes
+static int dag_prepare(psoap_chunk* h)
+{
+    if (h->plan_B == h->B) return 0;
+    if (h->P > 255) FAIL("N too large for the persistent kernel's 8-bit block-row indices (N <= 32640)");
+    HIP_TRY(hipDeviceSynchronize());
+    DagPlan plan = dag_build_tasks(h->B, h->P, h->dag_grid);
+    if (plan.n_ctrs > h->arrive_cap) FAIL("internal: arrival counter capacity exceeded");
+    if (plan.tasks.size() > h->tasks_cap) {
+        if (h->dTasks) HIP_TRY(hipFree(h->dTasks));
+        h->dTasks = nullptr;
+        HIP_TRY(hipMalloc(&h->dTasks, sizeof(DagTask) * plan.tasks.size()));
+        h->tasks_cap = plan.tasks.size();
+    }
+    if (plan.n_slots > h->ws_cap) {
+        if (h->dWs) HIP_TRY(hipFree(h->dWs));
+        h->dWs = nullptr;
+        HIP_TRY(hipMalloc(&h->dWs, sizeof(double) * NB * NB * (size_t)plan.n_slots));
+        h->ws_cap = plan.n_slots;
+    }
+    HIP_TRY(hipMemcpy(h->dTasks, plan.tasks.data(), sizeof(DagTask) * plan.tasks.size(), hipMemcpyHostToDevice));
+    h->plan_B = h->B;
+    h->plan_tasks = (unsigned int)plan.tasks.size();
+    h->plan_ctrs = plan.n_ctrs;
+    h->plan_slots = plan.n_slots;
+    return 0;
+}
+
 // One persistent launch for the whole batched factorisation (dag_kernel.hpp).
 static int eval_dag(psoap_chunk* h)
 {
     const int B = h->B, C = h->C, N = h->N, P = h->P;
     hipStream_t s = h->streams[0];
     h->recs.clear();
+    if (int rc = dag_prepare(h)) return rc;
     // no fill kernel: the DAG kernel evaluates the covariance tiles on the fly (dag_store_updated)
     if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
     hipLaunchKernelGGL(k_init_rhs, dim3((h->Npad + 255) / 256, B), dim3(256), 0, s, h->dR, h->Npad, N, h->dFl,
                        h->mu, h->dAcc);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(h->dDag, 0, sizeof(DagCtl) + sizeof(MatFlags) * (size_t)B, s));
+    HIP_TRY(hipMemsetAsync(h->dDag, 0, h->arrive_off + sizeof(int) * ((size_t)h->plan_ctrs + 4), s));
     if (prof_end(h, s)) return 1;
-    const long long tasks = (long long)B * P * (P + 1) / 2;
+    const long long tasks = h->plan_tasks;
     const int grid = (int)(tasks < h->dag_grid ? tasks : h->dag_grid);
     // executed MFMA flops: left-looking updates + strip solves, full 128^3 tiles
     double fl = 0.0;
@@ -376,7 +430,8 @@ static int eval_dag(psoap_chunk* h)
         DagCtl* ctl_ = reinterpret_cast<DagCtl*>(h->dDag);
 #define PSOAP_LAUNCH_DAG(CC)                                                                                     \
     hipLaunchKernelGGL(k_chol_dag<CC>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, h->dK, h->mat_stride,   \
-                       h->ld, P, B, h->dWt, h->dR, h->Npad, h->dAcc, fl_, ctl_, h->dTlog, h->dLwl, h->dGp,       \
+                       h->ld, P, h->dTasks, h->plan_tasks, h->dWt, h->dR, h->Npad, h->dAcc, fl_,                  \
+                       reinterpret_cast<int*>(h->dDag + h->arrive_off), h->dWs, ctl_, h->dTlog, h->dLwl, h->dGp, \
                        h->dSigma, N)
         if (C == 1) PSOAP_LAUNCH_DAG(1);
         else if (C == 2) PSOAP_LAUNCH_DAG(2);
