@@ -15,6 +15,7 @@ per-GPU work is fixed as N grows ("weak"); at 8 GPUs a step is exactly the 32-wa
 Rank 0 prints ONE JSON line.  Proposals are resident in HBM before the timed region.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -160,10 +161,35 @@ def main():
     avg_ms = dom["ms"] / max(1, dom["launches"])
     achieved = alg_per_launch / (avg_ms * 1e-3) / 1e12
     fill = tm["fill"]
+    if mode == "dag":
+        # the persistent kernel evaluates K on the fly; time the standalone HBM-bound fill kernel
+        # (the fill_V11_* drop-in and the staged path use it) with one event-profiled staged step
+        h.set_mode("staged")
+        h.set_profiling(True)
+        h.eval()
+        h.fetch()
+        fill = h.timings()["fill"]
+        h.set_profiling(False)
+        h.set_mode("dag")
+
+    # ---- PCIe-inclusive rate (never `value`): proposals uploaded from host memory every step
+    t1 = time.perf_counter()
+    for _ in range(3):
+        h.upload(lwls, gps)
+        h.eval()
+        h.fetch()
+    pcie_value = 3 * B / (time.perf_counter() - t1)
 
     out = None
     if rank == 0:
         mb = microbench(local_rank)
+        traffic, traffic_src = None, None
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+            tj = json.load(open(path))
+            w = tj.get("workload", {})
+            if (w.get("N"), w.get("components"), w.get("walkers"), w.get("mode")) == (N, c, B, mode):
+                traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+                break
         out = {
             "metric": "GP lnprob evals/sec (SB2, N=6000)",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -175,7 +201,8 @@ def main():
                        "parallelism": f"chunk-sharded x{world}, RCCL all_gather of walker lnprobs"},
             "roofline": {"bound": "mfma", "kernel": dom_name,
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src,
                          "launches_per_step": dom["launches"], "avg_launch_ms": avg_ms,
                          "algorithmic_flops_per_launch": alg_per_launch,
                          "executed_tflops": dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else None,
@@ -192,6 +219,7 @@ def main():
             "kernel_ms_profiled_step": {k: round(tm[k]["ms"], 3) for k in
                                         ("fill", "panel_update", "potrf", "trsm", "misc", "dag")},
             "profiled_step_total_ms": tm["total_ms"],
+            "pcie_inclusive_evals_per_s": pcie_value,
             "lnprob_walker0": float(total[0]),
         }
         if world == 1 and not args.no_cpu_baseline:
