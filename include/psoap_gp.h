@@ -138,6 +138,11 @@ int psoap_chunk_dag_tasklog(psoap_chunk *h, unsigned long long *out, long long m
  * slot(u32), ctr(u32)) in ticket order; *n_tasks receives the list length. */
 int psoap_chunk_dag_tasks(psoap_chunk *h, void *out, long long max_tasks, long long *n_tasks);
 
+/* Pure host function (touches no device): the task list of the persistent kernel for B matrices of
+ * P block rows on `workers` workgroups, same record format as psoap_chunk_dag_tasks. */
+int psoap_dag_plan(int B, int P, int workers, void *out, long long max_tasks, long long *n_tasks,
+                   long long *n_slots, long long *n_ctrs);
+
 /* fp64 MFMA / HBM micro-benchmarks used to state the measured peaks beside the
  * spec peaks in bench.py (results in TFLOP/s and GB/s). */
 int psoap_microbench_mfma_f64(int device, double *tflops);

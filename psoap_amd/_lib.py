@@ -57,6 +57,9 @@ SIGNATURES = {
     "psoap_chunk_set_mode": (ctypes.c_int, [_vp, ctypes.c_int]),
     "psoap_chunk_dag_tasklog": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_longlong]),
     "psoap_chunk_dag_tasks": (ctypes.c_int, [_vp, _vp, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
+    "psoap_dag_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_longlong,
+                                      ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong),
+                                      ctypes.POINTER(ctypes.c_longlong)]),
     "psoap_microbench_mfma_f64": (ctypes.c_int, [ctypes.c_int, _dp]),
     "psoap_microbench_hbm": (ctypes.c_int, [ctypes.c_int, _dp, _dp]),
 }

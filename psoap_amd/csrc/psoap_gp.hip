@@ -262,6 +262,23 @@ extern "C" int psoap_chunk_dag_tasklog(psoap_chunk* h, unsigned long long* out, 
     return 0;
 }
 
+// Pure host function (no HIP call): the task list the persistent kernel would run for a batch of
+// B matrices with P block rows on `workers` workgroups.  Lets the scheduler be validated on a CPU.
+extern "C" int psoap_dag_plan(int B, int P, int workers, void* out, long long max_tasks, long long* n_tasks,
+                              long long* n_slots, long long* n_ctrs)
+{
+    if (B < 1 || P < 1 || P > 255 || workers < 1 || !n_tasks) FAIL("psoap_dag_plan: bad arguments");
+    DagPlan plan = dag_build_tasks(B, P, workers);
+    *n_tasks = (long long)plan.tasks.size();
+    if (n_slots) *n_slots = plan.n_slots;
+    if (n_ctrs) *n_ctrs = plan.n_ctrs;
+    if (out) {
+        const long long n = max_tasks < *n_tasks ? max_tasks : *n_tasks;
+        memcpy(out, plan.tasks.data(), sizeof(DagTask) * n);
+    }
+    return 0;
+}
+
 // Debug: copy the current task list (16-byte DagTask records, ticket order) to the host.
 extern "C" int psoap_chunk_dag_tasks(psoap_chunk* h, void* out, long long max_tasks, long long* n_tasks)
 {

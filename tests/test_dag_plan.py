@@ -1,0 +1,93 @@
+"""CPU validation of the persistent kernel's scheduler: the host-built task list must cover every
+tile and every finished block row exactly once, and every wait must target a smaller ticket."""
+import ctypes
+
+import numpy as np
+import pytest
+
+TASK = np.dtype([("type", "u1"), ("q", "u1"), ("j", "u1"), ("S", "u1"), ("b", "<u2"), ("pa", "u1"), ("pb", "u1"),
+                 ("slot", "<u4"), ("ctr", "<u4")])
+PART, DIAG, OFF = 0, 1, 2
+
+
+def plan(B, P, workers):
+    from psoap_amd import _lib
+    L = _lib.load()
+    n, slots, ctrs = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+    assert L.psoap_dag_plan(B, P, workers, None, 0, ctypes.byref(n), ctypes.byref(slots), ctypes.byref(ctrs)) == 0
+    tasks = np.zeros(n.value, dtype=TASK)
+    assert L.psoap_dag_plan(B, P, workers, tasks.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n),
+                            ctypes.byref(slots), ctypes.byref(ctrs)) == 0
+    return tasks, slots.value, ctrs.value
+
+
+@pytest.mark.parametrize("B,P,workers", [(1, 1, 512), (1, 2, 512), (1, 47, 512), (3, 5, 512), (7, 16, 512),
+                                         (32, 47, 512), (32, 64, 512), (5, 20, 8), (200, 4, 512)])
+def test_plan_is_complete_and_deadlock_free(B, P, workers):
+    tasks, n_slots, n_ctrs = plan(B, P, workers)
+    assert TASK.itemsize == 16
+    finals = {}
+    covered = {}           # (b, q, j) -> list of (pa, pb)
+    part_done_ticket = {}  # ctr -> list of tickets of its PARTs
+    slots_seen = set()
+    diag_final_ticket = {}
+    row_final_last_ticket = {}   # (b, q) -> max ticket of the row's finals
+    for t, k in enumerate(tasks):
+        key = (int(k["b"]), int(k["q"]), int(k["j"]))
+        assert k["j"] >= k["q"] and k["q"] < P and k["j"] < P and k["b"] < B
+        assert k["pa"] <= k["pb"] <= k["q"]
+        covered.setdefault(key, []).append((int(k["pa"]), int(k["pb"])))
+        if k["type"] == PART:
+            assert k["S"] > 1 and k["slot"] < n_slots and k["ctr"] < n_ctrs
+            assert int(k["slot"]) not in slots_seen
+            slots_seen.add(int(k["slot"]))
+            part_done_ticket.setdefault(int(k["ctr"]), []).append(t)
+        else:
+            assert key not in finals, "one final task per tile"
+            finals[key] = t
+            assert (k["type"] == DIAG) == (k["j"] == k["q"])
+            if k["type"] == DIAG:
+                diag_final_ticket[(key[0], key[1])] = t
+            rk = (key[0], key[1])
+            row_final_last_ticket[rk] = max(row_final_last_ticket.get(rk, -1), t)
+    # every upper tile of every matrix has exactly one final
+    assert len(finals) == B * P * (P + 1) // 2
+    assert len(slots_seen) == n_slots
+    for key, ranges in covered.items():
+        b, q, j = key
+        ranges.sort()
+        # the parts tile [0, q) exactly
+        pos = 0
+        for pa, pb in ranges:
+            assert pa == pos
+            pos = pb
+        assert pos == q
+    # dependency order: every wait targets a smaller ticket
+    for t, k in enumerate(tasks):
+        b, q, j = int(k["b"]), int(k["q"]), int(k["j"])
+        # the update over block rows [pa, pb) needs rows < pb complete: all finals of those rows are earlier
+        for m in range(int(k["pb"])):
+            assert row_final_last_ticket[(b, m)] < t
+        if k["type"] != PART:
+            if k["S"] > 1:
+                parts = part_done_ticket[int(k["ctr"])]
+                assert len(parts) == k["S"] - 1 and max(parts) < t
+                # its partial slots are slot .. slot+S-2
+                got = sorted(int(tasks[p]["slot"]) for p in parts)
+                assert got == list(range(int(k["slot"]), int(k["slot"]) + int(k["S"]) - 1))
+                for p in parts:
+                    assert (int(tasks[p]["b"]), int(tasks[p]["q"]), int(tasks[p]["j"])) == (b, q, j)
+            if k["type"] == OFF:
+                assert diag_final_ticket[(b, q)] < t
+
+
+def test_sparse_rows_are_split_and_diagonal_is_preaccumulated():
+    tasks, _, _ = plan(32, 47, 512)
+    off = tasks[tasks["type"] == OFF]
+    # full rows are not split, the last block rows are
+    assert off[off["q"] == 10]["S"].max() == 1
+    assert off[off["q"] == 45]["S"].min() >= 4
+    diag = tasks[tasks["type"] == DIAG]
+    # from block row 2 on the diagonal final only covers the last finished row
+    late = diag[diag["q"] >= 2]
+    assert np.all(late["pb"] - late["pa"] == 1) and np.all(late["S"] >= 2)
