@@ -1,0 +1,70 @@
+"""Randomised agreement of the two execution modes (persistent DAG kernel vs staged kernels) and the
+oracle over many shapes and batch sizes; guards the in-kernel dependency protocol."""
+import numpy as np
+import pytest
+
+from psoap_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+LNP_RTOL = 1e-10
+
+
+def close(a, b):
+    return abs(a - b) <= LNP_RTOL * max(1.0, abs(b))
+
+
+def test_random_shapes_dag_vs_staged_vs_oracle(oracle):
+    from psoap_amd.chunk import ChunkHandle
+    rng = np.random.default_rng(2024)
+    for it in range(36):
+        c = int(rng.integers(1, 4))
+        n_epochs = int(rng.integers(1, 6))
+        n_pix = int(rng.integers(1, 330))
+        B = int(rng.integers(1, 10))
+        ch = syn.make_chunk(c, n_epochs, n_pix, seed=7000 + it, masked_fraction=0.15 if n_pix > 20 else 0.0)
+        gps = syn.make_walkers(c, B, seed=8000 + it)
+        lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, B, seed=9000 + it))
+        with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
+            h.set_mode("dag")
+            dag = h.lnlike_batch(lw, gps)
+            assert np.array_equal(h.lnlike_batch(lw, gps), dag)       # bit-reproducible
+            h.set_mode("staged")
+            staged = h.lnlike_batch(lw, gps)
+        for w in range(B):
+            assert close(dag[w], staged[w]), (it, ch.N, B, w, dag[w], staged[w])
+        w = int(rng.integers(0, B))
+        want = oracle.lnlike(lw[w], ch.fl, ch.sigma, gps[w])
+        assert close(dag[w], want), (it, ch.N, B, w, dag[w], want)
+
+
+def test_many_back_to_back_batches_same_handle():
+    """Re-launching the persistent kernel on one handle many times (state re-zeroed every launch),
+    alternating batch sizes so the task list is rebuilt."""
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_chunk(2, 4, 200, seed=99)          # N = 800
+    gps = syn.make_walkers(2, 8, seed=3)
+    lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, 8, seed=4))
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=8) as h:
+        ref = h.lnlike_batch(lw, gps)
+        for rep in range(40):
+            B = 1 + rep % 8
+            got = h.lnlike_batch(lw[:B], gps[:B])
+            assert np.array_equal(got, ref[:B]), rep
+
+
+def test_not_positive_definite_inside_batch():
+    """One singular matrix in a batch: that slot is -inf, the others are unaffected."""
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_chunk(2, 3, 100, seed=5)
+    B = 4
+    gps = np.tile(np.array(syn.GP_BASE[2]), (B, 1))
+    lw = np.repeat(ch.lwls[None], B, axis=0).copy()
+    lw[2, :, 1] = lw[2, :, 0]                        # duplicate pixel in proposal 2
+    sigma = ch.sigma.copy()
+    sigma[:2] = 0.0                                  # ... with zero noise there -> singular
+    for mode in ("dag", "staged"):
+        with ChunkHandle(ch.fl, sigma, max_batch=B) as h:
+            h.set_mode(mode)
+            got = h.lnlike_batch(lw, gps)
+        assert got[2] == -np.inf
+        assert np.isfinite(got[[0, 1, 3]]).all() and got[0] == got[1] == got[3]
