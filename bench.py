@@ -45,7 +45,7 @@ def flops_panel_update(N: int, nb: int = 128) -> float:
     return float(np.sum(2.0 * k0 * (N - i)))
 
 
-def cpu_baseline(chunk, n_evals: int = 6):
+def cpu_baseline(chunk, n_evals: int = 14):
     """The CPU oracle (C fill + SciPy cho_factor/cho_solve, i.e. the reference's own
     library calls) timed on this box's host cores.  Reported, never the target."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--groups", type=int, default=2, help="concurrent stream groups per batch (staged mode)")
     ap.add_argument("--mode", default="dag", choices=["dag", "staged"], help="execution mode of the batch eval")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend (nccl = RCCL; gloo only for single-GPU dry runs of the N>1 path)")
     args = ap.parse_args()
 
     import torch
@@ -95,10 +97,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.backend == "gloo":       # dry run: several ranks may share one GPU
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     os.environ.setdefault("PSOAP_DEVICE", str(local_rank))
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     from psoap_amd.chunk import ChunkHandle, microbench
     from psoap_amd.ensemble import gather_and_sum
@@ -136,7 +143,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

@@ -141,12 +141,15 @@ int psoap_chunk_dag_tasks(psoap_chunk *h, void *out, long long max_tasks, long l
 /* Pure host function (touches no device): the task list of the persistent kernel for B matrices of
  * P block rows on `workers` workgroups, same record format as psoap_chunk_dag_tasks. */
 int psoap_dag_plan(int B, int P, int workers, void *out, long long max_tasks, long long *n_tasks,
-                   long long *n_slots, long long *n_ctrs);
+                   long long *n_slots, long long *n_ctrs, unsigned int *queue_first /* 9 entries or NULL */);
 
 /* fp64 MFMA / HBM micro-benchmarks used to state the measured peaks beside the
  * spec peaks in bench.py (results in TFLOP/s and GB/s). */
 int psoap_microbench_mfma_f64(int device, double *tflops);
 int psoap_microbench_hbm(int device, double *write_gbs, double *copy_gbs);
+/* The MFMA tile engine alone (512 workgroups, K = 4096): shared_operands = 1 -> all tiles read the same
+ * L2-resident strips; 0 -> every tile streams its own B strip from HBM (the factorisation's pattern). */
+int psoap_microbench_tile_engine(int device, int shared_operands, double *tflops);
 
 #ifdef __cplusplus
 }

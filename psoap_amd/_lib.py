@@ -59,8 +59,9 @@ SIGNATURES = {
     "psoap_chunk_dag_tasks": (ctypes.c_int, [_vp, _vp, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
     "psoap_dag_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_longlong,
                                       ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong),
-                                      ctypes.POINTER(ctypes.c_longlong)]),
+                                      ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_uint32)]),
     "psoap_microbench_mfma_f64": (ctypes.c_int, [ctypes.c_int, _dp]),
+    "psoap_microbench_tile_engine": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp]),
     "psoap_microbench_hbm": (ctypes.c_int, [ctypes.c_int, _dp, _dp]),
 }
 

@@ -143,4 +143,9 @@ def microbench(device: int | None = None) -> dict:
     c = ctypes.c_double()
     check(L.psoap_microbench_mfma_f64(dev, ctypes.byref(tf)), "psoap_microbench_mfma_f64")
     check(L.psoap_microbench_hbm(dev, ctypes.byref(w), ctypes.byref(c)), "psoap_microbench_hbm")
-    return {"mfma_f64_tflops": tf.value, "hbm_write_gbs": w.value, "hbm_copy_gbs": c.value}
+    t1 = ctypes.c_double()
+    t0 = ctypes.c_double()
+    check(L.psoap_microbench_tile_engine(dev, 1, ctypes.byref(t1)), "psoap_microbench_tile_engine")
+    check(L.psoap_microbench_tile_engine(dev, 0, ctypes.byref(t0)), "psoap_microbench_tile_engine")
+    return {"mfma_f64_tflops": tf.value, "hbm_write_gbs": w.value, "hbm_copy_gbs": c.value,
+            "tile_engine_l2_tflops": t1.value, "tile_engine_hbm_tflops": t0.value}

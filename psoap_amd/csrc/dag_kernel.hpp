@@ -11,10 +11,14 @@
 //   OFF(b,q,j)   tile (q,j), j > q: the same MFMA update, then X = U11^-T (tile) as a K=128 MFMA
 //                product, then r[j-block] -= X^T z_q.
 //
-// Tasks are drawn from one atomic ticket counter in the order (q, DIAGs first, then b, j), so a
-// task only ever waits for tasks with smaller tickets, which are held by running workgroups:
-// no co-residency assumption, no deadlock, and while one matrix waits for its diagonal block the
-// workgroups work on the other matrices of the batch.  Hand-offs follow the agent-scope
+// Tasks are drawn from atomic ticket counters in the order (q, DIAGs first, then b, j), so a task
+// only ever waits for tasks with smaller tickets of the same queue, which are held by running
+// workgroups: no co-residency assumption, no deadlock, and while one matrix waits for its diagonal
+// block the workgroups work on the other matrices of the batch.  There is one queue per XCD: matrix
+// b belongs to queue b mod 8 and a workgroup serves the queue of the XCD it runs on (HW_REG_XCC_ID)
+// before stealing from the others, so the tiles of one block row -- which all stream the same
+// A operand -- run side by side under one L2 (measured before: 21 % L2 hit rate with one global
+// queue, the shared operand being fetched once per XCD).  Hand-offs follow the agent-scope
 // release/acquire recipe of cdna_hip_programming.md Guideline 16: plain stores, every wave drains
 // (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane release fence + drain, relaxed agent-scope
 // atomic on the counter; consumers poll relaxed, ONE acquire fence, drain, barrier, plain vector
@@ -38,10 +42,21 @@ struct alignas(64) MatFlags {
     int pad[13];
 };
 
+constexpr int DAG_QUEUES = 8;   // one ticket queue per XCD (MI355X: 8 XCDs, each with its own 4 MiB L2)
+
 struct alignas(64) DagCtl {
-    unsigned int ticket;
+    unsigned int reserved;
     unsigned int error;
-    unsigned int pad[14];
+    unsigned int pad[14];                 // pad[0..2]: diagnostics of the first timed-out wait
+    struct alignas(64) {
+        unsigned int next;                // next ticket of this queue
+        unsigned int fill[15];
+    } queue[DAG_QUEUES];
+};
+
+// queue g holds tasks[first[g] .. first[g+1]) in ticket order (kernel argument, by value)
+struct DagQueues {
+    unsigned int first[DAG_QUEUES + 1];
 };
 
 // One entry of the host-built task list (dag_build_tasks); the ticket is the index.
@@ -388,7 +403,7 @@ __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, in
 
 template <int C>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, size_t mat_stride, int ld, int P,
-                                                             const DagTask* __restrict__ tasks, unsigned int total,
+                                                             const DagTask* __restrict__ tasks, DagQueues queues,
                                                              double* Wt, double* Rbase, int Npad, MatAcc* acc,
                                                              MatFlags* flags, int* arrive, double* wspace,
                                                              DagCtl* ctl, unsigned long long* tlog,
@@ -403,14 +418,29 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
     __shared__ double red[2][4];
     __shared__ unsigned int s_ticket;
     constexpr size_t SLOT = (size_t)NB * NB;   // doubles per workspace slot
+    // the XCD this workgroup runs on: its queue first (L2 locality), the others when it runs dry
+    const int home = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20 /* HW_REG_XCC_ID[3:0] */) & 7u);
+    unsigned int dry = 0;                       // bit g: queue g is exhausted (wave-uniform)
+    int probe = 0;
     for (;;) {
         Tile t;
-        if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&ctl->ticket, 1u, PSOAP_RLX_AGENT);
+        if (dry == (1u << DAG_QUEUES) - 1u) return;
+        const int g = (home + probe) % DAG_QUEUES;
+        if (dry & (1u << g)) {
+            ++probe;
+            continue;
+        }
+        if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&ctl->queue[g].next, 1u, PSOAP_RLX_AGENT);
         __syncthreads();
         // wave-uniform by construction: keep it (and everything decoded from it) in scalar registers
-        const unsigned int ticket = __builtin_amdgcn_readfirstlane(s_ticket);
+        const unsigned int local = __builtin_amdgcn_readfirstlane(s_ticket);
         __syncthreads();  // s_ticket is rewritten at the top of the next iteration
-        if (ticket >= total) return;
+        if (local >= queues.first[g + 1] - queues.first[g]) {
+            dry |= 1u << g;
+            ++probe;
+            continue;
+        }
+        const unsigned int ticket = queues.first[g] + local;
         if (__hip_atomic_fetch_or(&ctl->error, 0u, PSOAP_RLX_AGENT) != 0u) return;
         const DagTask task = tasks[ticket];
         const int b = task.b, q = task.q, j = task.j;
@@ -474,15 +504,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
 }
 
 // ---------------------------------------------------------------------------------------------
-// Host: build the task list for a batch of B matrices of P block rows on `workers` persistent
-// workgroups.  Ticket order (every wait targets a smaller ticket):
-//   for each block row q:  DIAG finals of row q (all b)
+// Host: build the task lists (one queue per XCD, matrix b in queue b mod 8) for a batch of B
+// matrices of P block rows on `workers` persistent workgroups.  Ticket order inside a queue
+// (every wait targets a smaller ticket of the same queue):
+//   for each block row q:  DIAG finals of row q (the queue's matrices)
 //                          PARTs that pre-accumulate the diagonal tile of row q+1 over rows < q
 //                          PARTs + OFF finals of row q (b-major, then j)
-// Returns the number of workspace slots and arrival counters needed.
 // ---------------------------------------------------------------------------------------------
 struct DagPlan {
     std::vector<DagTask> tasks;
+    DagQueues queues{};
     unsigned int n_slots = 0;
     unsigned int n_ctrs = 0;
 };
@@ -490,7 +521,7 @@ struct DagPlan {
 inline int dag_split_factor(int tasks_in_row, int q, int workers)
 {
     // cut tiles of sparse block rows until the row offers about `workers` tasks (at most 8 parts,
-    // each at least one panel long)
+    // each at least two panels long)
     int S = 1;
     while (S < 8 && tasks_in_row * S < workers && 2 * S <= q) S *= 2;
     return S;
@@ -523,24 +554,26 @@ inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first,
     }
 }
 
-inline DagPlan dag_build_tasks(int B, int P, int workers)
+// task list of ONE queue: the matrices in `mats`, served by about `workers` workgroups
+// `Bq_nominal` (the largest queue's matrix count) decides the split factors, so every matrix of the
+// batch gets the same task structure and identical proposals give identical bits in any batch slot
+inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, int workers, int Bq_nominal)
 {
-    DagPlan plan;
-    // diag_parts[q]: PART tasks of DIAG(b,q) are emitted one block row early, its final in row q
-    std::vector<std::vector<DagTask>> early_final(P);
+    const int Bq = Bq_nominal;
+    if (mats.empty()) return;
+    std::vector<std::vector<DagTask>> early_final(P);   // DIAG finals whose PARTs were emitted a row early
     for (int q = 0; q < P; ++q) {
-        const int row_tasks = B * (P - q);
-        const int S_off = dag_split_factor(row_tasks, q, workers);
-        // 1. DIAG finals of this row (their PARTs were emitted in row q-1's section)
+        const int S_off = dag_split_factor(Bq * (P - q), q, workers);
+        // 1. DIAG finals of this row
         if (q <= 1) {
-            for (int b = 0; b < B; ++b) dag_emit(plan, DAG_DIAG, b, q, q, 0, q, 1);
+            for (int b : mats) dag_emit(plan, DAG_DIAG, b, q, q, 0, q, 1);
         } else {
             for (const DagTask& t : early_final[q]) plan.tasks.push_back(t);
         }
         // 2. pre-accumulate the diagonal tile of row q+1 over rows [0, q): PARTs now, final (panel q) later
         if (q + 1 < P && q >= 1) {
-            const int S_pre = dag_split_factor(B, q, workers / 4 > 0 ? workers / 4 : 1);
-            for (int b = 0; b < B; ++b) {
+            const int S_pre = dag_split_factor(Bq, q, workers / 4 > 0 ? workers / 4 : 1);
+            for (int b : mats) {
                 const unsigned int ctr = plan.n_ctrs++;
                 const unsigned int slot0 = plan.n_slots;
                 for (int sidx = 0; sidx < S_pre; ++sidx) {
@@ -569,9 +602,22 @@ inline DagPlan dag_build_tasks(int B, int P, int workers)
             }
         }
         // 3. off-diagonal tiles of this row
-        for (int b = 0; b < B; ++b)
+        for (int b : mats)
             for (int j = q + 1; j < P; ++j) dag_emit(plan, DAG_OFF, b, q, j, 0, q, S_off);
     }
+}
+
+inline DagPlan dag_build_tasks(int B, int P, int workers)
+{
+    DagPlan plan;
+    const int per_queue = workers / DAG_QUEUES > 0 ? workers / DAG_QUEUES : 1;
+    for (int g = 0; g < DAG_QUEUES; ++g) {
+        plan.queues.first[g] = (unsigned int)plan.tasks.size();
+        std::vector<int> mats;
+        for (int b = g; b < B; b += DAG_QUEUES) mats.push_back(b);
+        dag_build_queue(plan, mats, P, per_queue, (B + DAG_QUEUES - 1) / DAG_QUEUES);
+    }
+    plan.queues.first[DAG_QUEUES] = (unsigned int)plan.tasks.size();
     return plan;
 }
 

@@ -4,6 +4,7 @@
 #include <string>
 
 #include "common.hpp"
+#include "gemm_core.hpp"
 
 namespace psoap {
 
@@ -36,6 +37,26 @@ __global__ void k_stream_copy(d2* __restrict__ dst, const d2* __restrict__ src, 
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n2; i += stride) dst[i] = src[i];
+}
+
+// Tile-engine ceiling: every workgroup runs tile_gemm_tn over K rows.  shared_operands = 1: all
+// workgroups stream the same two strips (L2-resident after the first pass); 0: every workgroup
+// streams its own B strip from HBM and shares the A strip with the 31 others of its group.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_tile_engine_bench(const double* __restrict__ A,
+                                                                      const double* __restrict__ Bm, size_t ld, int K,
+                                                                      int shared_operands, double* sink)
+{
+    Tile t;
+    t.zero();
+    const size_t acol = shared_operands ? 0 : (size_t)(blockIdx.x / 32) * NB;
+    const size_t bcol = shared_operands ? NB : (size_t)(blockIdx.x % ((int)(ld / NB))) * NB;
+    tile_gemm_tn(t, A + acol, ld, Bm + bcol, ld, K);
+    double s = 0.0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) s += t.acc[m][n][0] + t.acc[m][n][1] + t.acc[m][n][2] + t.acc[m][n][3];
+    if (s == 12345.678) sink[0] = s;
 }
 
 #define MB_TRY(expr)                                                              \
@@ -72,6 +93,40 @@ inline int microbench_mfma(double* tflops, std::string& err)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(d);
+    return 0;
+}
+
+inline int microbench_tile_engine(int shared_operands, double* tflops, std::string& err)
+{
+    hipDeviceProp_t prop;
+    int dev = 0;
+    MB_TRY(hipGetDevice(&dev));
+    MB_TRY(hipGetDeviceProperties(&prop, dev));
+    const int blocks = prop.multiProcessorCount * 2;
+    const int K = 4096;
+    const size_t ld = (size_t)blocks * NB;          // one 128-column strip per workgroup
+    double* M = nullptr;
+    MB_TRY(hipMalloc(&M, sizeof(double) * ld * K));
+    MB_TRY(hipMemset(M, 0, sizeof(double) * ld * K));
+    hipLaunchKernelGGL(k_stream_write, dim3(2048), dim3(256), 0, 0, reinterpret_cast<d2*>(M), ld * K / 2, 1.0e-3);
+    MB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_engine_bench),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
+    hipEvent_t e0, e1;
+    MB_TRY(hipEventCreate(&e0));
+    MB_TRY(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_tile_engine_bench, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, M, M, ld, 256,
+                       shared_operands, M);
+    MB_TRY(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_tile_engine_bench, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, M, M, ld, K,
+                       shared_operands, M);
+    MB_TRY(hipEventRecord(e1, 0));
+    MB_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MB_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *tflops = 2.0 * NB * NB * (double)K * blocks / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(M);
     return 0;
 }
 

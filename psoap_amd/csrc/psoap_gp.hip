@@ -68,6 +68,7 @@ struct psoap_chunk {
     // task list of the persistent kernel for the current batch size (dag_build_tasks)
     int plan_B = 0;
     unsigned int plan_tasks = 0, plan_ctrs = 0, plan_slots = 0;
+    DagQueues plan_queues{};
     DagTask* dTasks = nullptr;
     size_t tasks_cap = 0;
     double* dWs = nullptr;   // split-K partial tiles, plan_slots x 128 x 128
@@ -265,13 +266,14 @@ extern "C" int psoap_chunk_dag_tasklog(psoap_chunk* h, unsigned long long* out, 
 // Pure host function (no HIP call): the task list the persistent kernel would run for a batch of
 // B matrices with P block rows on `workers` workgroups.  Lets the scheduler be validated on a CPU.
 extern "C" int psoap_dag_plan(int B, int P, int workers, void* out, long long max_tasks, long long* n_tasks,
-                              long long* n_slots, long long* n_ctrs)
+                              long long* n_slots, long long* n_ctrs, unsigned int* queue_first)
 {
     if (B < 1 || P < 1 || P > 255 || workers < 1 || !n_tasks) FAIL("psoap_dag_plan: bad arguments");
     DagPlan plan = dag_build_tasks(B, P, workers);
     *n_tasks = (long long)plan.tasks.size();
     if (n_slots) *n_slots = plan.n_slots;
     if (n_ctrs) *n_ctrs = plan.n_ctrs;
+    if (queue_first) memcpy(queue_first, plan.queues.first, sizeof plan.queues.first);
     if (out) {
         const long long n = max_tasks < *n_tasks ? max_tasks : *n_tasks;
         memcpy(out, plan.tasks.data(), sizeof(DagTask) * n);
@@ -419,6 +421,7 @@ static int dag_prepare(psoap_chunk* h)
     h->plan_tasks = (unsigned int)plan.tasks.size();
     h->plan_ctrs = plan.n_ctrs;
     h->plan_slots = plan.n_slots;
+    h->plan_queues = plan.queues;
     return 0;
 }
 
@@ -447,7 +450,7 @@ static int eval_dag(psoap_chunk* h)
         DagCtl* ctl_ = reinterpret_cast<DagCtl*>(h->dDag);
 #define PSOAP_LAUNCH_DAG(CC)                                                                                     \
     hipLaunchKernelGGL(k_chol_dag<CC>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, h->dK, h->mat_stride,   \
-                       h->ld, P, h->dTasks, h->plan_tasks, h->dWt, h->dR, h->Npad, h->dAcc, fl_,                  \
+                       h->ld, P, h->dTasks, h->plan_queues, h->dWt, h->dR, h->Npad, h->dAcc, fl_,                 \
                        reinterpret_cast<int*>(h->dDag + h->arrive_off), h->dWs, ctl_, h->dTlog, h->dLwl, h->dGp, \
                        h->dSigma, N)
         if (C == 1) PSOAP_LAUNCH_DAG(1);
@@ -573,12 +576,13 @@ extern "C" int psoap_batch_fetch(psoap_chunk* h, double* out)
     if (h->mode == 1 && h->hDagErr[0] != 0) {
         char buf[512];
         int dbg[32] = {0};
-        (void)hipMemcpy(dbg, h->dDag, sizeof dbg, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(dbg, h->dDag, 16 * sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(dbg + 16, h->dDag + sizeof(DagCtl), 16 * sizeof(int), hipMemcpyDeviceToHost);
         snprintf(buf, sizeof buf,
                  "psoap_batch_fetch: a dependency wait in the DAG kernel timed out (results invalid); "
-                 "first failing wait: code=%u target=%u seen=%u; ticket=%d err=%d; matrix0 rows_done=%d "
+                 "first failing wait: code=%u target=%u seen=%u; err=%d; matrix0 rows_done=%d "
                  "potrf_done=%d cnt=%d",
-                 h->hDagErr[1], h->hDagErr[2], h->hDagErr[3], dbg[0], dbg[1], dbg[16], dbg[17], dbg[18]);
+                 h->hDagErr[1], h->hDagErr[2], h->hDagErr[3], dbg[1], dbg[16], dbg[17], dbg[18]);
         h->hDagErr[0] = 0;
         FAIL(buf);
     }
@@ -694,6 +698,12 @@ extern "C" int psoap_microbench_mfma_f64(int device, double* tflops)
 {
     HIP_TRY(hipSetDevice(device));
     return microbench_mfma(tflops, g_err);
+}
+
+extern "C" int psoap_microbench_tile_engine(int device, int shared_operands, double* tflops)
+{
+    HIP_TRY(hipSetDevice(device));
+    return microbench_tile_engine(shared_operands, tflops, g_err);
 }
 
 extern "C" int psoap_microbench_hbm(int device, double* write_gbs, double* copy_gbs)

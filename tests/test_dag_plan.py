@@ -14,10 +14,12 @@ def plan(B, P, workers):
     from psoap_amd import _lib
     L = _lib.load()
     n, slots, ctrs = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
-    assert L.psoap_dag_plan(B, P, workers, None, 0, ctypes.byref(n), ctypes.byref(slots), ctypes.byref(ctrs)) == 0
+    first = (ctypes.c_uint32 * 9)()
+    assert L.psoap_dag_plan(B, P, workers, None, 0, ctypes.byref(n), ctypes.byref(slots), ctypes.byref(ctrs), first) == 0
     tasks = np.zeros(n.value, dtype=TASK)
     assert L.psoap_dag_plan(B, P, workers, tasks.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n),
-                            ctypes.byref(slots), ctypes.byref(ctrs)) == 0
+                            ctypes.byref(slots), ctypes.byref(ctrs), first) == 0
+    plan.queue_first = list(first)
     return tasks, slots.value, ctrs.value
 
 
@@ -26,6 +28,11 @@ def plan(B, P, workers):
 def test_plan_is_complete_and_deadlock_free(B, P, workers):
     tasks, n_slots, n_ctrs = plan(B, P, workers)
     assert TASK.itemsize == 16
+    # one queue per XCD: matrix b lives in queue b mod 8, queues are contiguous ranges of the list
+    first = plan.queue_first
+    assert first[0] == 0 and first[8] == len(tasks) and all(first[g] <= first[g + 1] for g in range(8))
+    for g in range(8):
+        assert np.all(tasks["b"][first[g]:first[g + 1]] % 8 == g)
     finals = {}
     covered = {}           # (b, q, j) -> list of (pa, pb)
     part_done_ticket = {}  # ctr -> list of tickets of its PARTs
