@@ -150,6 +150,9 @@ int psoap_microbench_hbm(int device, double *write_gbs, double *copy_gbs);
 /* The MFMA tile engine alone (512 workgroups, K = 4096): shared_operands = 1 -> all tiles read the same
  * L2-resident strips; 0 -> every tile streams its own B strip from HBM (the factorisation's pattern). */
 int psoap_microbench_tile_engine(int device, int shared_operands, double *tflops);
+/* One workgroup factoring a 128 x 128 tile (potrf_blocked), microseconds per factorisation; ablate 0 =
+ * the shipped routine, 1-3 = timing ablations (no in-wave 16 x 16 factorisation / no MFMA phases / no W output). */
+int psoap_microbench_potrf(int device, int ablate, double *usec);
 
 #ifdef __cplusplus
 }

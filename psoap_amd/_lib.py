@@ -62,6 +62,7 @@ SIGNATURES = {
                                       ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_uint32)]),
     "psoap_microbench_mfma_f64": (ctypes.c_int, [ctypes.c_int, _dp]),
     "psoap_microbench_tile_engine": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp]),
+    "psoap_microbench_potrf": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp]),
     "psoap_microbench_hbm": (ctypes.c_int, [ctypes.c_int, _dp, _dp]),
 }
 

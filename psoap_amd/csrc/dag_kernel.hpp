@@ -6,7 +6,7 @@
 // tasks of a dependency graph executed by persistent 256-thread workgroups (2 per CU):
 //
 //   DIAG(b,q)    tile (q,q) of matrix b: left-looking MFMA update over the q finished block
-//                rows, then an in-block Cholesky of the 128 x 128 tile that also yields
+//                rows, then an in-block Cholesky of the 128 x 128 tile (potrf_blocked.hpp) that also yields
 //                U11^-T (operand of the strip solve), z_q = U11^-T r_q and the logdet/quad sums.
 //   OFF(b,q,j)   tile (q,j), j > q: the same MFMA update, then X = U11^-T (tile) as a K=128 MFMA
 //                product, then r[j-block] -= X^T z_q.
@@ -32,6 +32,7 @@
 
 #include "chol_kernels.hpp"
 #include "fill_kernels.hpp"
+#include "potrf_blocked.hpp"
 
 namespace psoap {
 
@@ -219,145 +220,6 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* dest, s
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// In-block Cholesky of a 128 x 128 tile by 256 threads (16 x 16 grid: rows ty+16a, cols tx+16b,
-// 64 values per thread).  The register image M starts as the symmetric tile; the upper triangle
-// becomes U, and the strictly lower triangle is re-used in place for the strictly lower part of
-// W = U^-T (its diagonal is 1/U_jj, kept in dinv): slot (i, c<i) is first written at pivot step c
-// (W_ic = -U_ci / U_cc ...) and afterwards receives the same row eliminations as the upper part.
-// One LDS broadcast line and one barrier per pivot.
-// ---------------------------------------------------------------------------------------------
-template <int JA>
-__device__ __forceinline__ void potrf256_phase(double (&M)[8][8], double (*rowbuf)[NB], double* dinv, int ty, int tx,
-                                               int& bad)
-{
-#pragma unroll 1
-    for (int jr = 0; jr < 16; ++jr) {
-        const int j = 16 * JA + jr;
-        const int cur = j & 1;
-        if (ty == jr) {
-#pragma unroll
-            for (int b = 0; b < 8; ++b) rowbuf[cur][tx + 16 * b] = M[JA][b];
-        }
-        __syncthreads();
-        const double d = rowbuf[cur][j];
-        if (!(d > 0.0)) bad = 1;
-        const double inv = rsqrt(d);
-        double p[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) p[b] = rowbuf[cur][tx + 16 * b] * inv;
-        const bool pivcol = (tx == jr);  // column j lives in block b == JA at tx == jr
-#pragma unroll
-        for (int a = JA; a < 8; ++a) {
-            double mval = rowbuf[cur][ty + 16 * a] * inv;  // U_ji, i = ty + 16a > j
-            if (a == JA && ty <= jr) mval = 0.0;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                if (b == JA) {
-                    // first touch of W_ij at column j: -U_ji / U_jj; other columns: plain elimination
-                    const double upd = fma(-mval, p[b], M[a][b]);
-                    const bool live = !(a == JA && ty <= jr);
-                    M[a][b] = (pivcol && live) ? (-mval * inv) : upd;
-                } else {
-                    M[a][b] = fma(-mval, p[b], M[a][b]);
-                }
-            }
-        }
-        if (ty == jr) {
-#pragma unroll
-            for (int b = 0; b < 8; ++b) M[JA][b] = p[b];   // scaled pivot row: U_j,c>j and W_j,c<j
-            if (pivcol) M[JA][JA] = sqrt(d);               // U_jj
-            if (tx == 0) dinv[j] = inv;                    // W_jj
-        }
-    }
-}
-
-// Factor tile (k0,k0) of Km in place; write W^T (k-major) to Wm; z = W r_k into Rv[k0..]; sums to acc.
-// All 256 threads call this; uses the three LDS arrays passed in.
-__device__ __forceinline__ void potrf256(double* Km, int ld, int k0, double* Wm, double* Rv, MatAcc* acc,
-                                         double (*rowbuf)[NB], double* dinv, double* rk, double (*red)[4])
-{
-    const int tid = threadIdx.x;
-    const int ty = tid >> 4, tx = tid & 15;
-    double M[8][8];
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const int i = ty + 16 * a;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int c = tx + 16 * b;
-            // upper triangle from memory; the lower slots start as the mirror (their first use overwrites them)
-            M[a][b] = (c >= i) ? Km[(size_t)(k0 + i) * ld + k0 + c] : Km[(size_t)(k0 + c) * ld + k0 + i];
-        }
-    }
-    if (tid < NB) rk[tid] = Rv[k0 + tid];
-    int bad = 0;
-    // the factorisation is a latency-bound chain on the batch's critical path: let its waves win
-    // issue arbitration against the MFMA workgroup sharing the CU
-    __builtin_amdgcn_s_setprio(3);
-    potrf256_phase<0>(M, rowbuf, dinv, ty, tx, bad);
-    potrf256_phase<1>(M, rowbuf, dinv, ty, tx, bad);
-    potrf256_phase<2>(M, rowbuf, dinv, ty, tx, bad);
-    potrf256_phase<3>(M, rowbuf, dinv, ty, tx, bad);
-    potrf256_phase<4>(M, rowbuf, dinv, ty, tx, bad);
-    potrf256_phase<5>(M, rowbuf, dinv, ty, tx, bad);
-    potrf256_phase<6>(M, rowbuf, dinv, ty, tx, bad);
-    potrf256_phase<7>(M, rowbuf, dinv, ty, tx, bad);
-    __builtin_amdgcn_s_setprio(0);
-    __syncthreads();
-
-    double logpart = 0.0, quadpart = 0.0;
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const int i = ty + 16 * a;
-        double zp = 0.0;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int c = tx + 16 * b;
-            double w;  // W[i][c] = (U^-T)[i][c]
-            if (c > i) {
-                Km[(size_t)(k0 + i) * ld + k0 + c] = M[a][b];
-                w = 0.0;
-            } else if (c == i) {
-                Km[(size_t)(k0 + i) * ld + k0 + c] = M[a][b];
-                logpart += log(M[a][b]);
-                w = dinv[i];
-            } else {
-                w = M[a][b];
-            }
-            Wm[(size_t)c * NB + i] = w;  // k-major operand: Wt[e=c][i]
-            zp = fma(w, rk[c], zp);
-        }
-#pragma unroll
-        for (int off = 8; off >= 1; off >>= 1) zp += __shfl_xor(zp, off, 64);
-        if (tx == 0) {
-            Rv[k0 + i] = zp;
-            quadpart = fma(zp, zp, quadpart);
-        }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        logpart += __shfl_xor(logpart, off, 64);
-        quadpart += __shfl_xor(quadpart, off, 64);
-    }
-    const int wave = tid >> 6;
-    if ((tid & 63) == 0) {
-        red[0][wave] = logpart;
-        red[1][wave] = quadpart;
-    }
-    const int anybad = __syncthreads_or(bad);
-    if (tid == 0) {
-        const double l = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-        const double qd = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
-        // MatAcc is handed from block row to block row across workgroups: agent-scope accesses only
-        const double l0 = __hip_atomic_load(&acc->logdet_half, PSOAP_RLX_AGENT);
-        const double q0 = __hip_atomic_load(&acc->quad, PSOAP_RLX_AGENT);
-        __hip_atomic_store(&acc->logdet_half, l0 + l, PSOAP_RLX_AGENT);
-        __hip_atomic_store(&acc->quad, q0 + qd, PSOAP_RLX_AGENT);
-        if (anybad) __hip_atomic_store(&acc->info, 1.0, PSOAP_RLX_AGENT);
-    }
-}
-
 // strip solve + right-hand-side update for tile (k0, j0); the updated tile is already in memory
 __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, int j0, const double* Wm, double* Rv,
                                          int Npad, double* zk, double* colsum)
@@ -411,11 +273,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
                                                              const double* __restrict__ gp,
                                                              const double* __restrict__ sigma, int N)
 {
-    __shared__ double rowbuf[2][NB];
-    __shared__ double dinv[NB];
-    __shared__ double vec1[NB];   // r_k (DIAG) / z_k (OFF)
+    __shared__ double vec1[NB];   // z_k (OFF)
     __shared__ double vec2[NB];   // column sums (OFF)
-    __shared__ double red[2][4];
     __shared__ unsigned int s_ticket;
     constexpr size_t SLOT = (size_t)NB * NB;   // doubles per workspace slot
     // the XCD this workgroup runs on: its queue first (L2 locality), the others when it runs dry
@@ -481,7 +340,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
         dag_drain();  // the tile is re-read below in another layout by other waves of this block
         if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 1] = __builtin_amdgcn_s_memrealtime();
         if (task.type == DAG_DIAG) {
-            potrf256(Km, ld, k0, Wm, Rv, acc + b, rowbuf, dinv, vec1, red);
+            potrf_blocked(Km, ld, k0, Wm, Rv, acc + b);
             dag_drain();
             if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 2] = __builtin_amdgcn_s_memrealtime();
             if (threadIdx.x == 0) {

@@ -1,10 +1,14 @@
 // microbench_kernels.hpp -- measured ceilings quoted next to the spec peaks in bench.py:
 // back-to-back v_mfma_f64_16x16x4_f64 issue rate and streaming HBM write / copy bandwidth.
 #pragma once
+#include <stdio.h>
+
 #include <string>
+#include <vector>
 
 #include "common.hpp"
 #include "gemm_core.hpp"
+#include "potrf_blocked.hpp"
 
 namespace psoap {
 
@@ -57,6 +61,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_tile_engine_bench(const dou
 #pragma unroll
         for (int n = 0; n < 4; ++n) s += t.acc[m][n][0] + t.acc[m][n][1] + t.acc[m][n][2] + t.acc[m][n][3];
     if (s == 12345.678) sink[0] = s;
+}
+
+template <int ABLATE>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_potrf_bench(double* Km, int ld, double* Wm, double* Rv, MatAcc* acc,
+                                                                const double* K0, int reps)
+{
+    for (int it = 0; it < reps; ++it) {
+        for (int i = threadIdx.x; i < NB * NB; i += GEMM_THREADS) Km[(size_t)(i / NB) * ld + i % NB] = K0[i];
+        if (threadIdx.x < NB) Rv[threadIdx.x] = 1.0;
+        __syncthreads();
+        potrf_blocked<ABLATE>(Km, ld, 0, Wm, Rv, acc);
+        __syncthreads();
+    }
 }
 
 #define MB_TRY(expr)                                                              \
@@ -127,6 +144,54 @@ inline int microbench_tile_engine(int shared_operands, double* tflops, std::stri
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipFree(M);
+    return 0;
+}
+
+inline int microbench_potrf(int ablate, double* usec, std::string& err)
+{
+    std::vector<double> K0(NB * NB);
+    for (int i = 0; i < NB; ++i)
+        for (int j = 0; j < NB; ++j) K0[i * NB + j] = (i == j ? 2.0 : 0.0) + 1.0 / (1.0 + (i > j ? i - j : j - i));
+    double *dK0 = nullptr, *dK = nullptr, *dW = nullptr, *dR = nullptr;
+    MatAcc* dAcc = nullptr;
+    MB_TRY(hipMalloc(&dK0, sizeof(double) * NB * NB));
+    MB_TRY(hipMalloc(&dK, sizeof(double) * NB * NB));
+    MB_TRY(hipMalloc(&dW, sizeof(double) * NB * NB));
+    MB_TRY(hipMalloc(&dR, sizeof(double) * NB));
+    MB_TRY(hipMalloc(&dAcc, sizeof(MatAcc)));
+    MB_TRY(hipMemcpy(dK0, K0.data(), sizeof(double) * NB * NB, hipMemcpyHostToDevice));
+    MB_TRY(hipMemset(dW, 0, sizeof(double) * NB * NB));
+    MB_TRY(hipMemset(dAcc, 0, sizeof(MatAcc)));
+    const int reps = 200;
+    hipEvent_t e0, e1;
+    MB_TRY(hipEventCreate(&e0));
+    MB_TRY(hipEventCreate(&e1));
+#define PSOAP_PB(AB)                                                                                              \
+    MB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_bench<AB>),                                   \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));                  \
+    hipLaunchKernelGGL(k_potrf_bench<AB>, dim3(1), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dK, NB, dW, dR, dAcc, dK0, 2); \
+    MB_TRY(hipEventRecord(e0, 0));                                                                                \
+    hipLaunchKernelGGL(k_potrf_bench<AB>, dim3(1), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dK, NB, dW, dR, dAcc, dK0, reps); \
+    MB_TRY(hipEventRecord(e1, 0));
+    if (ablate == 0) { PSOAP_PB(0) } else if (ablate == 1) { PSOAP_PB(1) } else if (ablate == 2) { PSOAP_PB(2) } else if (ablate == 3) { PSOAP_PB(3) } else { PSOAP_PB(9) }
+#undef PSOAP_PB
+    MB_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MB_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *usec = 1e3 * ms / reps;
+    if (ablate == 9) {
+        unsigned long long st[16 * 6];
+        MB_TRY(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_potrf_stamps), sizeof st));
+        for (int w = 0; w < 2; ++w)
+            for (int bb = 0; bb < 8; ++bb) {
+                const unsigned long long* p = st + (w * 8 + bb) * 6;
+                printf("wave %d step %d: A %5llu | wait1 %5llu | B %5llu | wait2 %5llu | C %5llu cycles\n", w, bb,
+                       p[1] - p[0], p[2] - p[1], p[3] - p[2], p[4] - p[3], p[5] - p[4]);
+            }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(dK0); (void)hipFree(dK); (void)hipFree(dW); (void)hipFree(dR); (void)hipFree(dAcc);
     return 0;
 }
 

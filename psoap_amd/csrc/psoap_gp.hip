@@ -152,6 +152,7 @@ extern "C" int psoap_chunk_create(psoap_chunk** out, int device, int N, const do
     HIP_TRY(hipMalloc(&h->dSigma, sizeof(double) * N));
     HIP_TRY(hipMalloc(&h->dK, sizeof(double) * nb * h->mat_stride));
     HIP_TRY(hipMalloc(&h->dWt, sizeof(double) * nb * NB * NB));
+    HIP_TRY(hipMemset(h->dWt, 0, sizeof(double) * nb * NB * NB));   // the strictly upper part of every W stays zero
     HIP_TRY(hipMalloc(&h->dR, sizeof(double) * nb * h->Npad));
     HIP_TRY(hipMalloc(&h->dAcc, sizeof(MatAcc) * nb));
     HIP_TRY(hipMalloc(&h->dLwl, sizeof(double) * nb * 3 * N));
@@ -704,6 +705,12 @@ extern "C" int psoap_microbench_tile_engine(int device, int shared_operands, dou
 {
     HIP_TRY(hipSetDevice(device));
     return microbench_tile_engine(shared_operands, tflops, g_err);
+}
+
+extern "C" int psoap_microbench_potrf(int device, int ablate, double* usec)
+{
+    HIP_TRY(hipSetDevice(device));
+    return microbench_potrf(ablate, usec, g_err);
 }
 
 extern "C" int psoap_microbench_hbm(int device, double* write_gbs, double* copy_gbs)
