@@ -2,6 +2,7 @@
 // back-to-back v_mfma_f64_16x16x4_f64 issue rate and streaming HBM write / copy bandwidth.
 #pragma once
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -34,6 +35,30 @@ __global__ void k_stream_write(d2* __restrict__ dst, size_t n2, double v)
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     d2 val = {v, v};
     for (; i < n2; i += stride) dst[i] = val;
+}
+
+// store-path variants for finding the streaming-write ceiling: 0 plain, 1 nontemporal, 2 plain with
+// 4 stores in flight per thread per iteration
+template <int V>
+__global__ void k_stream_write_v(d2* __restrict__ dst, size_t n2, double v)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    d2 val = {v, v};
+    if (V == 2) {
+        for (; i + 3 * stride < n2; i += 4 * stride) {
+            dst[i] = val;
+            dst[i + stride] = val;
+            dst[i + 2 * stride] = val;
+            dst[i + 3 * stride] = val;
+        }
+        for (; i < n2; i += stride) dst[i] = val;
+    } else {
+        for (; i < n2; i += stride) {
+            if (V == 1) __builtin_nontemporal_store(val, &dst[i]);
+            else dst[i] = val;
+        }
+    }
 }
 
 __global__ void k_stream_copy(d2* __restrict__ dst, const d2* __restrict__ src, size_t n2)
@@ -207,12 +232,38 @@ inline int microbench_hbm(double* write_gbs, double* copy_gbs, std::string& err)
     MB_TRY(hipEventCreate(&e1));
     float ms = 0.f;
     hipLaunchKernelGGL(k_stream_write, dim3(2048), dim3(256), 0, 0, a, n2, 1.0);
-    MB_TRY(hipEventRecord(e0, 0));
-    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_stream_write, dim3(2048), dim3(256), 0, 0, b, n2, 2.0);
-    MB_TRY(hipEventRecord(e1, 0));
-    MB_TRY(hipEventSynchronize(e1));
-    MB_TRY(hipEventElapsedTime(&ms, e0, e1));
-    *write_gbs = 5.0 * bytes / (ms * 1e-3) / 1e9;
+    // streaming-write ceiling: best of a few grid sizes / store flavours (it varies 3.9-5.3 TB/s with the
+    // number of workgroups on this part; many short workgroups win)
+    *write_gbs = 0.0;
+    for (int variant = 0; variant < 2; ++variant)
+        for (int g : {2048, 16384}) {
+            MB_TRY(hipEventRecord(e0, 0));
+            for (int r = 0; r < 5; ++r) {
+                if (variant == 0) hipLaunchKernelGGL(k_stream_write_v<0>, dim3(g), dim3(256), 0, 0, b, n2, 2.0);
+                else hipLaunchKernelGGL(k_stream_write_v<1>, dim3(g), dim3(256), 0, 0, b, n2, 2.0);
+            }
+            MB_TRY(hipEventRecord(e1, 0));
+            MB_TRY(hipEventSynchronize(e1));
+            MB_TRY(hipEventElapsedTime(&ms, e0, e1));
+            const double gbs = 5.0 * bytes / (ms * 1e-3) / 1e9;
+            if (gbs > *write_gbs) *write_gbs = gbs;
+        }
+    if (getenv("PSOAP_WRITE_SWEEP")) {
+        const int grids[] = {1024, 2048, 4096, 8192, 16384};
+        for (int variant = 0; variant < 3; ++variant)
+            for (int g : grids) {
+                MB_TRY(hipEventRecord(e0, 0));
+                for (int r = 0; r < 5; ++r) {
+                    if (variant == 0) hipLaunchKernelGGL(k_stream_write_v<0>, dim3(g), dim3(256), 0, 0, b, n2, 2.0);
+                    else if (variant == 1) hipLaunchKernelGGL(k_stream_write_v<1>, dim3(g), dim3(256), 0, 0, b, n2, 2.0);
+                    else hipLaunchKernelGGL(k_stream_write_v<2>, dim3(g), dim3(256), 0, 0, b, n2, 2.0);
+                }
+                MB_TRY(hipEventRecord(e1, 0));
+                MB_TRY(hipEventSynchronize(e1));
+                MB_TRY(hipEventElapsedTime(&ms, e0, e1));
+                printf("write variant %d grid %5d: %.0f GB/s\n", variant, g, 5.0 * bytes / (ms * 1e-3) / 1e9);
+            }
+    }
     MB_TRY(hipEventRecord(e0, 0));
     for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_stream_copy, dim3(2048), dim3(256), 0, 0, b, a, n2);
     MB_TRY(hipEventRecord(e1, 0));
