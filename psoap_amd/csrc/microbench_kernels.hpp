@@ -77,6 +77,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_tile_engine_bench(const dou
 {
     Tile t;
     t.zero();
+    // shared_operands & 2: give the two workgroups that share a CU different issue priorities
     const size_t acol = shared_operands ? 0 : (size_t)(blockIdx.x / 32) * NB;
     const size_t bcol = shared_operands ? NB : (size_t)(blockIdx.x % ((int)(ld / NB))) * NB;
     tile_gemm_tn(t, A + acol, ld, Bm + bcol, ld, K);

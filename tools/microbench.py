@@ -3,3 +3,4 @@ import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from psoap_amd.chunk import microbench
 print(json.dumps(microbench()))
+
