@@ -69,6 +69,17 @@ int psoap_batch_upload(psoap_chunk *h, int B, int c, const double *lwl,
  * lwl_c = lwl - vel[c, epoch]/c_kms (psoap/data.py:37,61).  Needs set_grid. */
 int psoap_batch_upload_velocities(psoap_chunk *h, int B, int c, const double *vel,
                                   const double *gp, double mu_GP);
+/* Orbit proposals: the batched Kepler solve, the Doppler shift and the
+ * |v| >= c_kms -> -inf rule of Worker.lnprob (psoap/sample_parallel.py:183-193) run on the device.
+ * model: 0 SB1, 1 SB2, 2 ST1, 3 ST2, 4 ST3; p_orb (B, n_orb) in the order of utils.registered_params
+ * up to and including gamma (psoap/utils.py:4-14): n_orb = 6, 7, 11, 12, 13.  Needs set_grid + set_dates. */
+int psoap_chunk_set_dates(psoap_chunk *h, const double *dates, int n_epochs);
+int psoap_batch_upload_orbits(psoap_chunk *h, int B, int model, const double *p_orb, const double *gp,
+                              double mu_GP);
+/* orbit.models[model](*p_orb, dates).get_velocities() for B parameter vectors at once
+ * (psoap/orbit.py:95-115,148-170,301-320,394-417,463-487): vel_out (B, c, n_dates) km/s. */
+int psoap_orbit_velocities(int device, int model, int B, const double *p_orb, int n_dates, const double *dates,
+                           double *vel_out);
 int psoap_batch_eval(psoap_chunk *h);
 int psoap_batch_fetch(psoap_chunk *h, double *out);
 int psoap_chunk_sync(psoap_chunk *h);

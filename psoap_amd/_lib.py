@@ -43,6 +43,9 @@ SIGNATURES = {
     "psoap_lnlike_batch": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double, _dp]),
     "psoap_batch_upload": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double]),
     "psoap_batch_upload_velocities": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double]),
+    "psoap_chunk_set_dates": (ctypes.c_int, [_vp, _dp, ctypes.c_int]),
+    "psoap_batch_upload_orbits": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double]),
+    "psoap_orbit_velocities": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, ctypes.c_int, _dp, _dp]),
     "psoap_batch_eval": (ctypes.c_int, [_vp]),
     "psoap_batch_fetch": (ctypes.c_int, [_vp, _dp]),
     "psoap_chunk_sync": (ctypes.c_int, [_vp]),

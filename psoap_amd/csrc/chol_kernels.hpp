@@ -238,12 +238,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trsm_strip(double* __restri
 }
 
 // lnp = -0.5 * (z^T z + 2 sum log U_ii)   (covariance.py:329-331); -inf when not positive definite
-__global__ void k_finalize(const MatAcc* __restrict__ acc, double* __restrict__ out, int B)
+__global__ void k_finalize(const MatAcc* __restrict__ acc, double* __restrict__ out, int B,
+                           const int* __restrict__ too_fast)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) {
         const MatAcc a = acc[b];
-        const bool bad = (a.info != 0.0);
+        // too_fast: an orbit proposal with |v| >= c (sample_parallel.py:186-187)
+        const bool bad = (a.info != 0.0) || (too_fast != nullptr && too_fast[b] != 0);
         out[b] = bad ? -INFINITY : -0.5 * (a.quad + 2.0 * a.logdet_half);
     }
 }

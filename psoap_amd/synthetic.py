@@ -53,6 +53,7 @@ class SyntheticChunk:
     sigma: np.ndarray       # (N,)
     seed: int
     mask: np.ndarray        # (n_epochs, n_pix) bool; N = mask.sum()
+    dates: np.ndarray = None  # (n_epochs,) observation dates [JD], for the orbit / lnprob(p) boundary
 
     @property
     def N(self) -> int:
@@ -81,6 +82,40 @@ def replicate_wls(lwl: np.ndarray, velocities: np.ndarray, mask: np.ndarray) -> 
     out = np.empty((c, lwl.shape[0]), dtype=np.float64)
     for i in range(c):
         out[i] = lwl + (-velocities[i][ep]) / C_KMS
+    return out
+
+
+def make_dates(n_epochs: int, seed: int) -> np.ndarray:
+    """Sorted observation dates [JD] from an independent stream (does not disturb the chunk's draws)."""
+    rng = np.random.default_rng([seed, 0x0DA7E5])
+    return np.sort(rng.uniform(2455000.0, 2455400.0, size=n_epochs))
+
+
+# orbital parameters (registered_params order up to gamma) used by fixtures and examples
+ORBIT_BASE = {
+    "SB1": (12.0, 0.25, 40.0, 23.0, 2455010.0, 3.0),
+    "SB2": (0.6, 12.0, 0.25, 40.0, 23.0, 2455010.0, 3.0),
+    "ST1": (12.0, 0.25, 40.0, 23.0, 2455010.0, 4.0, 0.1, 200.0, 310.0, 2455100.0, 3.0),
+    "ST2": (0.6, 12.0, 0.25, 40.0, 23.0, 2455010.0, 4.0, 0.1, 200.0, 310.0, 2455100.0, 3.0),
+    "ST3": (0.6, 12.0, 0.25, 40.0, 23.0, 2455010.0, 0.3, 4.0, 0.1, 200.0, 310.0, 2455100.0, 3.0),
+}
+
+
+def make_orbit_proposals(model: str, n: int, seed: int) -> np.ndarray:
+    """(n, n_orb) orbital parameter vectors: the base vector (row 0) plus seeded perturbations with
+    eccentricities kept in [0, 0.9)."""
+    rng = np.random.default_rng([seed, 0x0B17])
+    base = np.array(ORBIT_BASE[model], dtype=np.float64)
+    out = np.repeat(base[None], n, axis=0)
+    scale = np.maximum(np.abs(base) * 0.1, 0.05)
+    out[1:] += scale * rng.standard_normal(out[1:].shape)
+    names_e = {"SB1": [1], "SB2": [2], "ST1": [1, 6], "ST2": [2, 7], "ST3": [2, 8]}[model]
+    for j in names_e:
+        out[:, j] = np.clip(np.abs(out[:, j]), 0.0, 0.89)
+    names_pos = {"SB1": [0, 3], "SB2": [0, 1, 4], "ST1": [0, 3, 5, 8], "ST2": [0, 1, 4, 6, 9],
+                 "ST3": [0, 1, 4, 6, 7, 10]}[model]
+    for j in names_pos:
+        out[:, j] = np.abs(out[:, j]) + 1e-3
     return out
 
 
@@ -132,7 +167,7 @@ def make_chunk(n_components: int, n_epochs: int, n_pix: int, seed: int,
     return SyntheticChunk(n_components, n_epochs, n_pix,
                           np.ascontiguousarray(lwl), velocities,
                           np.ascontiguousarray(lwls), np.ascontiguousarray(fl),
-                          sigma, seed, mask)
+                          sigma, seed, mask, make_dates(n_epochs, seed))
 
 
 def make_config_chunk(cfg: int, chunk_index: int = 0, **kw) -> SyntheticChunk:
