@@ -187,6 +187,21 @@ def main():
         h.fetch()
     pcie_value = 3 * B / (time.perf_counter() - t1)
 
+    # ---- the lnprob(p) boundary: orbital parameters in, lnprob out; Kepler solve,
+    # Doppler shift and likelihood all on the device.  Reported beside `value`, never as `value`.
+    from psoap_amd.lnprob import ChunkWorker
+    h.close()
+    model = {1: "SB1", 2: "SB2", 3: "ST3"}[c]
+    worker = ChunkWorker(model, chunk.lwl, chunk.fl, chunk.sigma, chunk.epoch_index, chunk.dates, max_batch=B,
+                         device=local_rank)
+    pfit = np.hstack([syn.make_orbit_proposals(model, B, seed=1000 * cfg + 502), gps])
+    worker.lnprob_batch(pfit)
+    t2 = time.perf_counter()
+    for _ in range(3):
+        worker.lnprob_batch(pfit)
+    lnprob_p_value = 3 * B / (time.perf_counter() - t2)
+    worker.close()
+
     out = None
     if rank == 0:
         mb = microbench(local_rank)
@@ -227,13 +242,13 @@ def main():
                                         ("fill", "panel_update", "potrf", "trsm", "misc", "dag")},
             "profiled_step_total_ms": tm["total_ms"],
             "pcie_inclusive_evals_per_s": pcie_value,
+            "lnprob_of_p_evals_per_s": lnprob_p_value,
             "lnprob_walker0": float(total[0]),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(chunk)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    h.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
