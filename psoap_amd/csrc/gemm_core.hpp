@@ -96,7 +96,7 @@ __device__ __forceinline__ void tile_mma_chunk(Tile& t, int buf, int wr, int wc,
 //                     symmetric diagonal tile is never read back;
 //   k_limit_upper   : waves wr=0 issue no MFMA for k >= k_limit_upper -- rows 0..63 of a product
 //                     with a lower-triangular left factor (W = U11^-T) only involve k < 64.
-__device__ __forceinline__ void tile_gemm_tn(Tile& t, const double* __restrict__ A, size_t lda,
+__device__ __forceinline__ void tile_gemm_tn_reg(Tile& t, const double* __restrict__ A, size_t lda,
                                              const double* __restrict__ B, size_t ldb, int K,
                                              bool skip_lower_left = false, int k_limit_upper = 0x7fffffff)
 {
@@ -116,6 +116,45 @@ __device__ __forceinline__ void tile_gemm_tn(Tile& t, const double* __restrict__
         const bool idle = (skip_lower_left && wr == 1 && wc == 0) || (wr == 0 && c * KB >= k_limit_upper);
         if (!idle) tile_mma_chunk(t, cur, wr, wc, lane);
         if (more) stage_store(s, cur ^ 1, tid);
+        __syncthreads();
+    }
+}
+
+// LDS-DMA staging: one global_load_lds_dwordx4 per wave moves one 1 KiB operand row (128 doubles)
+// straight into its padded LDS row -- no staging VGPRs, no ds_write pass.  Wave w fills rows
+// w, w+4, w+8, w+12 of both operand chunks.
+__device__ __forceinline__ void stage_glds(const double* __restrict__ A, size_t lda, const double* __restrict__ B,
+                                           size_t ldb, int k, int buf, int tid)
+{
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = wave + 4 * it;
+        const int off = buf * LDS_BUFFER + row * LDS_LD;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(A + (size_t)(k + row) * lda + 2 * lane), (lds_ptr)(psoap_smem + off), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(B + (size_t)(k + row) * ldb + 2 * lane),
+                                         (lds_ptr)(psoap_smem + off + LDS_OPERAND), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void tile_gemm_tn(Tile& t, const double* __restrict__ A, size_t lda,
+                                                  const double* __restrict__ B, size_t ldb, int K,
+                                                  bool skip_lower_left = false, int k_limit_upper = 0x7fffffff)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    if (K <= 0) return;
+    stage_glds(A, lda, B, ldb, 0, 0, tid);
+    __syncthreads();
+    const int nchunk = K / KB;
+    for (int c = 0; c < nchunk; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nchunk) stage_glds(A, lda, B, ldb, (c + 1) * KB, cur ^ 1, tid);
+        const bool idle = (skip_lower_left && wr == 1 && wc == 0) || (wr == 0 && c * KB >= k_limit_upper);
+        if (!idle) tile_mma_chunk(t, cur, wr, wc, lane);
         __syncthreads();
     }
 }

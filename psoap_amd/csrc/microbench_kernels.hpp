@@ -71,6 +71,7 @@ __global__ void k_stream_copy(d2* __restrict__ dst, const d2* __restrict__ src, 
 // Tile-engine ceiling: every workgroup runs tile_gemm_tn over K rows.  shared_operands = 1: all
 // workgroups stream the same two strips (L2-resident after the first pass); 0: every workgroup
 // streams its own B strip from HBM and shares the A strip with the 31 others of its group.
+template <int ENG>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_tile_engine_bench(const double* __restrict__ A,
                                                                       const double* __restrict__ Bm, size_t ld, int K,
                                                                       int shared_operands, double* sink)
@@ -80,7 +81,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_tile_engine_bench(const dou
     // shared_operands & 2: give the two workgroups that share a CU different issue priorities
     const size_t acol = shared_operands ? 0 : (size_t)(blockIdx.x / 32) * NB;
     const size_t bcol = shared_operands ? NB : (size_t)(blockIdx.x % ((int)(ld / NB))) * NB;
-    tile_gemm_tn(t, A + acol, ld, Bm + bcol, ld, K);
+    if (ENG == 1) tile_gemm_tn(t, A + acol, ld, Bm + bcol, ld, K);
+    else tile_gemm_tn_reg(t, A + acol, ld, Bm + bcol, ld, K);
     double s = 0.0;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -100,6 +102,50 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_potrf_bench(double* Km, int
         potrf_blocked<ABLATE>(Km, ld, 0, Wm, Rv, acc);
         __syncthreads();
     }
+}
+
+// Ablations of the tile-engine loop (diagnostics): ABL bit 0 = no global loads / LDS stores after the
+// first stage, bit 1 = no workgroup barrier, bit 2 = no LDS fragment reads (MFMAs on stale registers).
+template <int ABL>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_tile_engine_ablate(const double* __restrict__ A, size_t ld, int K,
+                                                                       double* sink)
+{
+    Tile t;
+    t.zero();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const double* Ab = A + (size_t)(blockIdx.x / 32) * NB;
+    const double* Bb = A + (size_t)(blockIdx.x % ((int)(ld / NB))) * NB;
+    Staging s;
+    stage_load(s, Ab, ld, Bb, ld, 0, tid);
+    stage_store(s, 0, tid);
+    stage_store(s, 1, tid);
+    __syncthreads();
+    const int fr = lane & 15, fk = lane >> 4;
+    double a[4] = {1.0, 2.0, 3.0, 4.0}, b[4] = {1.5, 2.5, 3.5, 4.5};
+    const int nchunk = K / KB;
+    for (int c = 0; c < nchunk; ++c) {
+        const int cur = c & 1;
+        if (!(ABL & 1)) stage_load(s, Ab, ld, Bb, ld, ((c + 1) % nchunk) * KB, tid);
+        if (ABL & 4) {
+#pragma unroll
+            for (int ks = 0; ks < KB / 4; ++ks)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        t.acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], t.acc[m][n], 0, 0, 0);
+        } else {
+            tile_mma_chunk(t, cur, wr, wc, lane);
+        }
+        if (!(ABL & 1)) stage_store(s, cur ^ 1, tid);
+        if (!(ABL & 2)) __syncthreads();
+    }
+    double sum = a[0] * fr + b[0] * fk;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) sum += t.acc[m][n][0] + t.acc[m][n][1] + t.acc[m][n][2] + t.acc[m][n][3];
+    if (sum == 12345.678) sink[0] = sum;
 }
 
 #define MB_TRY(expr)                                                              \
@@ -152,17 +198,50 @@ inline int microbench_tile_engine(int shared_operands, double* tflops, std::stri
     MB_TRY(hipMalloc(&M, sizeof(double) * ld * K));
     MB_TRY(hipMemset(M, 0, sizeof(double) * ld * K));
     hipLaunchKernelGGL(k_stream_write, dim3(2048), dim3(256), 0, 0, reinterpret_cast<d2*>(M), ld * K / 2, 1.0e-3);
-    MB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_engine_bench),
+    MB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_engine_bench<0>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
+    MB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_engine_bench<1>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
     hipEvent_t e0, e1;
     MB_TRY(hipEventCreate(&e0));
     MB_TRY(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k_tile_engine_bench, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, M, M, ld, 256,
+    if (shared_operands >= 16) {   // 16 + ABL: loop ablations
+        const int abl = shared_operands - 16;
+#define PSOAP_TE(AB)                                                                                          \
+    MB_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_engine_ablate<AB>),                        \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));              \
+    hipLaunchKernelGGL(k_tile_engine_ablate<AB>, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, M, ld, 256, M); \
+    MB_TRY(hipEventRecord(e0, 0));                                                                            \
+    hipLaunchKernelGGL(k_tile_engine_ablate<AB>, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, M, ld, K, M);   \
+    MB_TRY(hipEventRecord(e1, 0));
+        switch (abl) {
+            case 0: { PSOAP_TE(0) } break;
+            case 1: { PSOAP_TE(1) } break;
+            case 2: { PSOAP_TE(2) } break;
+            case 3: { PSOAP_TE(3) } break;
+            case 4: { PSOAP_TE(4) } break;
+            case 5: { PSOAP_TE(5) } break;
+            case 6: { PSOAP_TE(6) } break;
+            default: { PSOAP_TE(7) } break;
+        }
+#undef PSOAP_TE
+    } else {
+    if (shared_operands >= 8) {   // 8, 9: LDS-DMA staging
+    hipLaunchKernelGGL(k_tile_engine_bench<1>, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, M, M, ld, 256,
+                       shared_operands & 1, M);
+    MB_TRY(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_tile_engine_bench<1>, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, M, M, ld, K,
+                       shared_operands & 1, M);
+    MB_TRY(hipEventRecord(e1, 0));
+    } else {
+    hipLaunchKernelGGL(k_tile_engine_bench<0>, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, M, M, ld, 256,
                        shared_operands, M);
     MB_TRY(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(k_tile_engine_bench, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, M, M, ld, K,
+    hipLaunchKernelGGL(k_tile_engine_bench<0>, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, M, M, ld, K,
                        shared_operands, M);
     MB_TRY(hipEventRecord(e1, 0));
+    }
+    }
     MB_TRY(hipEventSynchronize(e1));
     float ms = 0.f;
     MB_TRY(hipEventElapsedTime(&ms, e0, e1));
