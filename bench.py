@@ -200,6 +200,15 @@ def main():
     for _ in range(3):
         worker.lnprob_batch(pfit)
     lnprob_p_value = 3 * B / (time.perf_counter() - t2)
+
+    # ---- the sampler boundary (8(f) f-2): B Metropolis-Hastings chains in lock-step on that worker,
+    # proposals drawn on the host, one batched device evaluation per iteration.
+    from psoap_amd.samplers import MultiChainMHSampler
+    mh = MultiChainMHSampler(1e-6 * np.eye(pfit.shape[1]), pfit.shape[1], worker.lnprob_batch, B,
+                             seeds=[7000 + b for b in range(B)])
+    t3 = time.perf_counter()
+    mh.run_mcmc(pfit, 3)                              # 1 starting + 3 proposal evaluations of B chains
+    mh_value = 4 * B / (time.perf_counter() - t3)
     worker.close()
 
     out = None
@@ -243,6 +252,7 @@ def main():
             "profiled_step_total_ms": tm["total_ms"],
             "pcie_inclusive_evals_per_s": pcie_value,
             "lnprob_of_p_evals_per_s": lnprob_p_value,
+            "mh_sampler_evals_per_s": mh_value,
             "lnprob_walker0": float(total[0]),
         }
         if world == 1 and not args.no_cpu_baseline:

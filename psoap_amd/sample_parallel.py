@@ -1,0 +1,208 @@
+"""Multi-chunk, multi-chain sampling driver on the device lnprob(p) boundary.
+
+What /root/reference/psoap/sample_parallel.py does with one forked process per chunk, a pipe protocol
+(:206-255, :258-278) and one proposal per iteration (:371-390, :434-438), restated for GPUs:
+
+* every chunk of ``chunks.dat`` is loaded, masked (:66-72) and kept resident on a GPU by a
+  ``ChunkWorker`` (orbit solve + Doppler shift + GP likelihood on the device);
+* with G processes (one per GPU, ``torch.distributed``), rank r owns chunks ``k = r (mod G)``; the
+  per-(chunk, chain) log-likelihoods are exchanged by one small all_gather (RCCL) and summed in chunk
+  order on every rank (:382-390), so all ranks see bit-identical posteriors and take identical
+  accept/reject decisions without broadcasting proposals (same seeds everywhere);
+* B independent Metropolis-Hastings chains advance in lock-step (``MultiChainMHSampler``), chain b
+  writing what reference run ``run_index + b`` would: ``<outdir>/run{NN}/flatchain.npy`` and
+  ``lnprob.npy`` (:440-443) plus a copy of the configuration (:52).
+
+    python -m psoap_amd.sample_parallel 0 --chains 32 [--seed 1]
+    python -m torch.distributed.run --nproc-per-node 8 -m psoap_amd.sample_parallel 0 --chains 32
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import shutil
+
+import numpy as np
+
+from . import data as pdata
+from . import priors as ppriors
+from . import utils
+from .ensemble import gather_chunk_lnprobs, owned_chunks, sum_over_chunks
+from .samplers import MultiChainMHSampler
+
+
+def load_config(path="config.yaml"):
+    """config.yaml keys: model, chunk_file, mask_file, epoch_limit, soften, parameters, jumps, fix_params,
+    samples, opt_jump, outdir (/root/reference/psoap/data/config.SB2.yaml; loaded at sample_parallel.py:11-14)."""
+    import yaml
+    try:
+        with open(path) as f:
+            return yaml.safe_load(f)
+    except FileNotFoundError:
+        print("You need to copy a config.yaml file to this directory, and then edit the values to your particular case.")
+        raise
+
+
+def load_chunks(config, prefix=""):
+    """Open and mask every chunk of ``config['chunk_file']`` (sample_parallel.py:58-72)."""
+    chunks = []
+    for order, wl0, wl1 in pdata.read_chunk_table(config["chunk_file"]):
+        ch = pdata.Chunk.open(order, wl0, wl1, limit=config["epoch_limit"], prefix=prefix)
+        ch.apply_mask()
+        chunks.append(ch)
+    return chunks
+
+
+def proposal_covariance(config, model, dim):
+    """``opt_jump`` covariance if the file loads, else the diagonal of squared hand-specified jumps (:425-431)."""
+    try:
+        cov = np.load(config["opt_jump"])
+        print("using optimal jumps")
+    except Exception:
+        print("using hand-specified jumps")
+        cov = utils.convert_dict(model, config["fix_params"], **config["jumps"]) ** 2 * np.eye(dim)
+    return cov
+
+
+class Posterior:
+    """``lnprob_batch(P)`` = prior + sum over chunks of the per-chunk GP log-likelihood (:371-390).
+
+    ``chunks``: masked ``Chunk``-like objects (``lwl, fl, sigma, epoch_index, date1D``), ALL chunks on
+    every rank; only the owned ones are uploaded.  ``make_worker`` is injectable for CPU tests.
+    """
+
+    def __init__(self, model, chunks, fix_params=(), parameters=None, soften=1.0, max_batch=1, world=1, rank=0,
+                 device_index=None, prior=None, make_worker=None):
+        self.model = model
+        self.fix_params = list(fix_params)
+        self.parameters = dict(parameters or {})
+        self.n_chunks = len(chunks)
+        self.world, self.rank, self.device_index = int(world), int(rank), device_index
+        self.max_batch = int(max_batch)
+        self.mine = owned_chunks(self.n_chunks, self.world, self.rank)
+        if self.world > 1 and not self.mine:
+            raise ValueError("every rank must own at least one chunk (n_chunks >= world)")
+        self.prior = prior if prior is not None else ppriors.make_prior(model, self.fix_params, **self.parameters)
+        if make_worker is None:
+            from .lnprob import ChunkWorker
+
+            def make_worker(ch):
+                return ChunkWorker(model, ch.lwl, ch.fl, ch.sigma, ch.epoch_index, ch.date1D,
+                                   fix_params=self.fix_params, defaults=self.parameters, max_batch=self.max_batch,
+                                   device=device_index, soften=soften)
+        self.workers = {k: make_worker(chunks[k]) for k in self.mine}
+
+    def close(self):
+        for w in self.workers.values():
+            if hasattr(w, "close"):
+                w.close()
+
+    def lnprob_batch(self, P):
+        P = np.atleast_2d(np.asarray(P, dtype=np.float64))
+        B = P.shape[0]
+        lnprior = np.asarray(self.prior(P), dtype=np.float64)
+        ok = np.isfinite(lnprior)                 # -inf prior: never evaluated (:373-375)
+        out = np.full(B, -np.inf)
+        n_ok = int(ok.sum())
+        # every rank sees the same P, hence the same `ok`: the collective below stays matched
+        if n_ok:
+            block = np.empty((len(self.mine), n_ok))
+            Pok = P[ok]
+            for i, k in enumerate(self.mine):
+                for s in range(0, n_ok, self.max_batch):
+                    block[i, s:s + self.max_batch] = self.workers[k].lnprob_batch(Pok[s:s + self.max_batch])
+            table = gather_chunk_lnprobs(block, self.n_chunks, self.world, self.rank, self.device_index)
+            out[ok] = sum_over_chunks(table) + lnprior[ok]
+        return out
+
+    def lnprob(self, p):
+        return float(self.lnprob_batch(np.atleast_2d(p))[0])
+
+
+def run(config, chunks, run_index=0, n_chains=1, seed=None, world=1, rank=0, device_index=None, iterations=None,
+        config_path=None, make_worker=None, prior=None, verbose=True):
+    """Sample ``n_chains`` chains for ``config['samples']`` iterations; returns the sampler.
+
+    Chain b uses ``RandomState(seed + b)`` when ``seed`` is given (fresh entropy otherwise -- then every
+    rank must be handed the same ``seed``: pass one explicitly under torch.distributed).
+    """
+    model = config["model"]
+    pars = config["parameters"]
+    fix = config["fix_params"]
+    dim = len(utils.registered_params[model]) - len(fix)
+    p0 = utils.convert_dict(model, fix, **pars)
+    if world > 1 and seed is None:
+        raise ValueError("multi-rank sampling needs an explicit seed so that all ranks draw the same proposals")
+    post = Posterior(model, chunks, fix, pars, soften=config.get("soften", 1.0), max_batch=n_chains, world=world,
+                     rank=rank, device_index=device_index, prior=prior, make_worker=make_worker)
+    try:
+        if verbose and rank == 0:
+            print("Trying first evaluation")
+        lnp0 = post.lnprob(p0)
+        if lnp0 == -np.inf:
+            raise RuntimeError("Starting position for Markov Chain evaluates to -np.inf")     # :405-419
+        if verbose and rank == 0:
+            print("Starting position good. lnp: {}".format(lnp0))
+        cov = proposal_covariance(config, model, dim)
+        seeds = [None if seed is None else seed + b for b in range(n_chains)]
+        sampler = MultiChainMHSampler(cov, dim, post.lnprob_batch, n_chains, seeds)
+        n_iter = int(config["samples"] if iterations is None else iterations)
+        for i, _ in enumerate(sampler.sample(p0, lnprob0=lnp0, iterations=n_iter)):
+            if verbose and rank == 0 and (i + 1) % 20 == 0:
+                print("Iteration", i + 1)
+    finally:
+        post.close()
+    if rank == 0:
+        if verbose:
+            print("Acceptance fraction", sampler.acceptance_fraction)
+        for b in range(n_chains):
+            routdir = os.path.join(config["outdir"], "run{:0>2}".format(run_index + b)) + "/"
+            if os.path.exists(routdir):
+                shutil.rmtree(routdir)
+            os.makedirs(routdir)
+            if config_path is not None and os.path.exists(config_path):
+                shutil.copy(config_path, routdir + "config.yaml")
+            np.save(routdir + "lnprob.npy", sampler.lnprobability[b])
+            np.save(routdir + "flatchain.npy", sampler.chain[b])
+    return sampler
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser(description="Sample the distribution across multiple chunks.")
+    parser.add_argument("run_index", type=int, nargs="?", default=0,
+                        help="First output subdirectory; chain b is written to run{run_index + b}.")
+    parser.add_argument("--chains", type=int, default=32, help="Independent MH chains evaluated per batched step.")
+    parser.add_argument("--seed", type=int, default=None)
+    parser.add_argument("--config", default="config.yaml")
+    parser.add_argument("--prefix", default="", help="Directory prefix of the chunk files.")
+    args = parser.parse_args(argv)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    seed = args.seed
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")
+        if seed is None:
+            seed = 0
+    config = load_config(args.config)
+    chunks = load_chunks(config, args.prefix)
+    if rank == 0:
+        print("Sampling {} chunks on {} GPU(s), {} chains per step.".format(len(chunks), world, args.chains))
+    prior = ppriors.load_user_prior(".")
+    if rank == 0:
+        print("Loaded user defined prior." if prior is not None else "Using default prior.")
+    try:
+        run(config, chunks, args.run_index, args.chains, seed, world, rank, local if world > 1 else None,
+            config_path=args.config, prior=prior)
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,3 +46,9 @@ def convert_vectors(ps, model, fix_params, **kwargs):
         full[:, i] = kwargs[name]
     k = n_params_orb[model]
     return np.ascontiguousarray(full[:, :k]), np.ascontiguousarray(full[:, k:])
+
+
+def convert_dict(model, fix_params, **kwargs):
+    """Fitted-parameter vector from a ``{name: value}`` dictionary such as config.yaml's ``parameters`` or
+    ``jumps`` (utils.py:71-84): the registered parameters that are not fixed, in registered order."""
+    return np.array([kwargs[name] for name in registered_params[model] if name not in fix_params], dtype=np.float64)
