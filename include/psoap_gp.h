@@ -114,6 +114,35 @@ int psoap_predict(int device, int mode, int c, int N, int M, const double *lwl,
                   const double *mu_c, const double *gp, double *mu_out,
                   double *Sigma_out, int *status_out);
 
+/* ---- calibration ---------------------------------------------
+ * Chebyshev re-normalisation of one epoch's flux against reference epochs:
+ *   fl' = mu + C B^-1 (fl_fixed - mu),  C' = A - C B^-1 C^T,  D = fl_cal * T_k(lwl_cal),
+ *   X = (D^T C'^-1 D)^-1 D^T C'^-1 fl',  fl_cor = D X.
+ * psoap_calibrate_explicit replaces optimize_calibration (covariance.py:560-624):
+ *   caller-filled A (M,M) with sigma_cal^2 on the diagonal, B (N,N) with
+ *   sigma_fixed^2, C (M,N); row-major host arrays.
+ * psoap_calibrate evaluates the three matrices on the device from c-component
+ *   rest-frame grids: optimize_calibration_static (covariance.py:628-707, c = 1,
+ *   lwls_cal == lwl_cal) and the per-epoch body of
+ *   scripts/psoap_process_calibration_ST3.py:147-183 (c = 3).  lwls_cal (c,M),
+ *   lwls_fixed (c,N), gp (2c); lwl_cal (M) is the Chebyshev abscissa, mapped from
+ *   [lwl0, lwl1] onto [-1, 1] as numpy's Chebyshev(domain=...) does.
+ * Outputs: fl_cor (M), X (order+1).  order <= 15.
+ * status_out: 0 ok; 1 B, 2 C', 3 the normal equations not positive definite (the
+ * reference raises LinAlgError there; outputs are then unspecified). */
+int psoap_calibrate(int device, int c, int M, int N, int order, double lwl0,
+                    double lwl1, const double *lwl_cal, const double *lwls_cal,
+                    const double *fl_cal, const double *sigma_cal,
+                    const double *lwls_fixed, const double *fl_fixed,
+                    const double *sigma_fixed, const double *gp, double mu_GP,
+                    double *fl_cor, double *X, int *status_out);
+int psoap_calibrate_explicit(int device, int M, int N, int order, double lwl0,
+                             double lwl1, const double *lwl_cal,
+                             const double *fl_cal, const double *fl_fixed,
+                             const double *A, const double *B, const double *C,
+                             double mu_GP, double *fl_cor, double *X,
+                             int *status_out);
+
 /* ---- measurement ----------------------------------------------------------------
  * With profiling on, every kernel launch of psoap_batch_eval is bracketed by
  * hipEvents on its own stream (single stream group, so launches serialise);

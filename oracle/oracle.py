@@ -217,3 +217,40 @@ def predict_sum(lwls, fl, sigma, lwls_predict, mu_sum, gp):
         mu = mu_sum + np.dot(V12.T, cho_solve(factor, fl - mu_sum))
     Sigma = V11 - np.dot(V12, cho_solve(factor, V12.T))
     return mu, Sigma
+
+
+# ---- calibration (test infrastructure, like everything in this file) --------------------------------
+def _cheb_design(lwl0, lwl1, lwl_cal, fl_cal, order):
+    """D = fl_cal[:, None] * T_k(lwl_cal), k = 0..order, Chebyshev domain [lwl0, lwl1] (covariance.py:584-593)."""
+    from numpy.polynomial import Chebyshev
+    T = np.array([Chebyshev([0] * k + [1], domain=[lwl0, lwl1])(lwl_cal) for k in range(order + 1)])
+    return np.asarray(fl_cal)[:, None] * T.T
+
+
+def optimize_calibration(lwl0, lwl1, lwl_cal, fl_cal, fl_fixed, A, B, C, order=1, mu_GP=1.0):
+    """covariance.py:560-624 restated with SciPy's cho_factor / cho_solve."""
+    D = _cheb_design(lwl0, lwl1, lwl_cal, fl_cal, order)
+    Bc = cho_factor(B)
+    fl_prime = mu_GP + C @ cho_solve(Bc, np.asarray(fl_fixed).flatten() - mu_GP)
+    C_prime = A - C @ cho_solve(Bc, C.T)
+    Cc = cho_factor(C_prime)
+    left = D.T @ cho_solve(Cc, D)
+    right = D.T @ cho_solve(Cc, fl_prime)
+    X = cho_solve(cho_factor(left), right)
+    return D @ X, X
+
+
+def calibration_blocks(lwls_cal, sigma_cal, lwls_fixed, sigma_fixed, gp):
+    """A, B, C as scripts/psoap_process_calibration_ST3.py:147-176 builds them (per-component fills summed)."""
+    lwls_cal, lwls_fixed = np.atleast_2d(lwls_cal), np.atleast_2d(lwls_fixed)
+    c, M = lwls_cal.shape
+    N = lwls_fixed.shape[1]
+    A, B, C = np.zeros((M, M)), np.zeros((N, N)), np.zeros((M, N))
+    for k in range(c):
+        a, l = gp[2 * k], gp[2 * k + 1]
+        t = np.empty((M, M)); fill_V11_f(t, lwls_cal[k], a, l); A = A + t
+        t = np.empty((N, N)); fill_V11_f(t, lwls_fixed[k], a, l); B = B + t
+        t = np.empty((M, N)); fill_V12_f(t, lwls_cal[k], lwls_fixed[k], a, l); C = C + t
+    A[np.diag_indices_from(A)] += np.asarray(sigma_cal) ** 2
+    B[np.diag_indices_from(B)] += np.asarray(sigma_fixed) ** 2
+    return A, B, C

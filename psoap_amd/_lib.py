@@ -54,6 +54,12 @@ SIGNATURES = {
                                         ctypes.c_double, _dp]),
     "psoap_predict": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp,
                                      _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "psoap_calibrate": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_double, ctypes.c_double, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp,
+                                       ctypes.c_double, _dp, _dp, _ip]),
+    "psoap_calibrate_explicit": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                                ctypes.c_double, _dp, _dp, _dp, _dp, _dp, _dp, ctypes.c_double, _dp, _dp,
+                                                _ip]),
     "psoap_chunk_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "psoap_chunk_get_timings": (ctypes.c_int, [_vp, ctypes.POINTER(Timings)]),
     "psoap_chunk_set_stream_groups": (ctypes.c_int, [_vp, ctypes.c_int]),

@@ -143,3 +143,110 @@ def predict_f_g_h_sum(lwl_f, lwl_g, lwl_h, fl_fgh, sigma_fgh, lwl_f_predict, lwl
                          "(covariance.py:294)")
     return _predict(1, [lwl_f, lwl_g, lwl_h], fl_fgh, sigma_fgh, [lwl_f_predict, lwl_g_predict, lwl_h_predict],
                     [mu_fgh], [amp_f, l_f, amp_g, l_g, amp_h, l_h])
+
+
+# ---- calibration ---------------------------------------------------------------
+_CAL_FAIL = {1: "reference-epoch covariance B", 2: "conditional covariance C'", 3: "Chebyshev normal equations"}
+
+
+def _cal_result(status, fl_cor, X):
+    if status != 0:
+        # cho_factor raises in the reference (covariance.py:597-601, :607, :613)
+        print("Failed to solve matrix inverse. Calibration not valid.")
+        raise np.linalg.LinAlgError(f"{_CAL_FAIL[status]} is not positive definite")
+    return fl_cor, X
+
+
+def optimize_calibration(lwl0, lwl1, lwl_cal, fl_cal, fl_fixed, A, B, C, order=1, mu_GP=1.0):
+    """Chebyshev calibration of one epoch with caller-filled covariance blocks (covariance.py:560-624).
+
+    ``A`` (M,M) and ``B`` (N,N) carry the squared uncertainties on their diagonals, ``C`` (M,N) is the
+    cross block.  Returns ``(fl_cor (M,), X (order+1,))``; the two Cholesky passes run on the device.
+    """
+    lwl_cal = as_f64(lwl_cal)
+    M = lwl_cal.shape[0]
+    fl_cal = as_f64(fl_cal, (M,))
+    fl_fixed = as_f64(np.asarray(fl_fixed).flatten())
+    N = fl_fixed.shape[0]
+    A, B, C = as_f64(A, (M, M)), as_f64(B, (N, N)), as_f64(C, (M, N))
+    fl_cor, X = np.empty(M), np.empty(order + 1)
+    status = ctypes.c_int(0)
+    check(_lib.load().psoap_calibrate_explicit(_lib.default_device(), M, N, int(order), float(lwl0), float(lwl1),
+                                               dptr(lwl_cal), dptr(fl_cal), dptr(fl_fixed), dptr(A), dptr(B), dptr(C),
+                                               float(mu_GP), dptr(fl_cor), dptr(X), ctypes.byref(status)),
+          "psoap_calibrate_explicit")
+    return _cal_result(status.value, fl_cor, X)
+
+
+def optimize_calibration_components(lwl0, lwl1, lwl_cal, lwls_cal, fl_cal, sigma_cal, lwls_fixed, fl_fixed, sigma_fixed,
+                                    gp, order=1, mu_GP=1.0):
+    """The per-epoch body of scripts/psoap_process_calibration_ST3.py:147-183 with the covariance blocks
+    evaluated on the device: ``lwls_cal`` (c,M) / ``lwls_fixed`` (c,N) are the rest-frame grids of the epoch
+    and of the reference epochs, ``gp = (amp_f, l_f[, amp_g, l_g[, amp_h, l_h]])``; ``lwl_cal`` (M,) is the
+    observed-frame abscissa of the Chebyshev polynomials on [lwl0, lwl1]."""
+    lwls_cal = np.ascontiguousarray(np.atleast_2d(np.asarray(lwls_cal, dtype=np.float64)))
+    lwls_fixed = np.ascontiguousarray(np.atleast_2d(np.asarray(lwls_fixed, dtype=np.float64)))
+    c, M = lwls_cal.shape
+    N = lwls_fixed.shape[1]
+    assert lwls_fixed.shape[0] == c, "epoch and reference grids need the same number of components"
+    lwl_cal, fl_cal, sigma_cal = as_f64(lwl_cal, (M,)), as_f64(fl_cal, (M,)), as_f64(sigma_cal, (M,))
+    fl_fixed, sigma_fixed = as_f64(np.asarray(fl_fixed).flatten(), (N,)), as_f64(np.asarray(sigma_fixed).flatten(), (N,))
+    gp = as_f64(gp, (2 * c,))
+    fl_cor, X = np.empty(M), np.empty(order + 1)
+    status = ctypes.c_int(0)
+    check(_lib.load().psoap_calibrate(_lib.default_device(), c, M, N, int(order), float(lwl0), float(lwl1), dptr(lwl_cal),
+                                      dptr(lwls_cal), dptr(fl_cal), dptr(sigma_cal), dptr(lwls_fixed), dptr(fl_fixed),
+                                      dptr(sigma_fixed), dptr(gp), float(mu_GP), dptr(fl_cor), dptr(X),
+                                      ctypes.byref(status)),
+          "psoap_calibrate")
+    return _cal_result(status.value, fl_cor, X)
+
+
+def optimize_calibration_static(wl0, wl1, wl_cal, fl_cal, sigma_cal, wl_fixed, fl_fixed, sigma_fixed, amp, l_f, order=1,
+                                mu_GP=1.0):
+    """Single-component calibration with zero relative velocities (covariance.py:628-707): the same
+    vectors serve as kernel abscissa and as Chebyshev abscissa."""
+    return optimize_calibration_components(wl0, wl1, wl_cal, [wl_cal], fl_cal, sigma_cal,
+                                           [np.asarray(wl_fixed).flatten()], fl_fixed, sigma_fixed, [amp, l_f],
+                                           order=order, mu_GP=mu_GP)
+
+
+def cycle_calibration(wl, fl, sigma, amp_f, l_f, ncycles, order=1, limit_array=3, mu_GP=1.0, soften=1.0):
+    """Cycle the calibration over all epochs of an (n_epochs, n_pix) block (covariance.py:710-745).
+
+    The reference body calls ``optimize_calibration`` with ``optimize_calibration_static``'s argument
+    list (:740) and cannot run; this implements that evident intent."""
+    wl, sigma = np.asarray(wl, dtype=np.float64), soften * np.asarray(sigma, dtype=np.float64)
+    wl0, wl1 = np.min(wl), np.max(wl)
+    fl_out = np.array(fl, dtype=np.float64)
+    for _ in range(ncycles):
+        for i in range(len(wl)):
+            wl_remain = np.delete(wl, i, axis=0)[0:limit_array]
+            fl_remain = np.delete(fl_out, i, axis=0)[0:limit_array]
+            sigma_remain = np.delete(sigma, i, axis=0)[0:limit_array]
+            fl_out[i], _X = optimize_calibration_static(wl0, wl1, wl[i], fl_out[i], sigma[i], wl_remain.flatten(),
+                                                        fl_remain.flatten(), sigma_remain.flatten(), amp_f, l_f,
+                                                        order=order, mu_GP=mu_GP)
+    return fl_out
+
+
+def cycle_calibration_chunk(chunk, amp_f, l_f, n_cycles, order=1, limit_array=3, mu_GP=1.0, soften=1.0):
+    """Mask-aware cycle over a 2-D ``Chunk``; overwrites ``chunk.fl`` (covariance.py:747-800, same stale
+    call at :776).  Masked pixels are left out of the solve and corrected with the fitted polynomial.
+    As in the reference, ``soften`` is computed but the un-softened ``chunk.sigma`` enters the solve."""
+    from numpy.polynomial import chebyshev as npcheb
+    wl0, wl1 = np.min(chunk.wl), np.max(chunk.wl)
+    fl_out = np.array(chunk.fl, dtype=np.float64)
+    for _ in range(n_cycles):
+        for i in range(chunk.n_epochs):
+            mt = chunk.mask[i]
+            wl_remain = np.delete(chunk.wl, i, axis=0)[0:limit_array]
+            fl_remain = np.delete(fl_out, i, axis=0)[0:limit_array]
+            sigma_remain = np.delete(chunk.sigma, i, axis=0)[0:limit_array]
+            mr = np.delete(chunk.mask, i, axis=0)[0:limit_array]
+            _fl, X = optimize_calibration_static(wl0, wl1, chunk.wl[i][mt], fl_out[i][mt], chunk.sigma[i][mt],
+                                                 wl_remain[mr], fl_remain[mr], sigma_remain[mr], amp_f, l_f,
+                                                 order=order, mu_GP=mu_GP)
+            u = (2.0 * chunk.wl[i] - (wl0 + wl1)) / (wl1 - wl0)
+            fl_out[i] = fl_out[i] * npcheb.chebval(u, X)          # D X re-evaluated on every pixel (:781-797)
+    chunk.fl[:] = fl_out

@@ -161,6 +161,23 @@ static void launch_region_c(int C, double* out, size_t ld, int col0, int nrows, 
     else launch_region<3>(out, ld, col0, nrows, ncols, xrow, xrs, xcol, xcs, g, sym, nug);
 }
 
+// The left-looking factorisation of an Npad x (Npad + Mt*128) augmented matrix [B | extra columns]:
+// afterwards the extra columns hold U^-T (extra) and dR holds z = U^-T r.
+inline void factor_augmented(double* dK, size_t ld, int P, int Mt, double* dW, double* dR, int Npad, MatAcc* dAcc)
+{
+    for (int p = 0; p < P; ++p) {
+        const int k0 = p * NB;
+        const int ntile = P - p + Mt;
+        if (p > 0)
+            hipLaunchKernelGGL(k_panel_update, dim3(ntile, 1), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dK, (size_t)0,
+                               (int)ld, k0);
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), 0, 0, dK, (size_t)0, (int)ld, k0, dW, dR, Npad, dAcc);
+        if (ntile > 1)
+            hipLaunchKernelGGL(k_trsm_strip, dim3(ntile - 1, 1), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dK, (size_t)0,
+                               (int)ld, k0, dW, dR, Npad);
+    }
+}
+
 // mode 0: components (predict_f_g / predict_f_g_h); 1: sum (predict_f_g_sum / _h_sum); 2: predict_f
 inline int predict_run(int mode, int c, int N, int M, const double* lwl, const double* fl, const double* sigma,
                        const double* lwl_pred, const double* mu_c, const double* gp, double* mu_out,
@@ -238,18 +255,8 @@ inline int predict_run(int mode, int c, int N, int M, const double* lwl, const d
     hipLaunchKernelGGL(k_init_rhs, dim3((Npad + 255) / 256, 1), dim3(256), 0, 0, dR, Npad, N, dFl, offset, dAcc);
     PR_TRY(hipGetLastError());
 
-    for (int p = 0; p < P; ++p) {
-        const int k0 = p * NB;
-        const int ntile = P - p + Mt;
-        if (p > 0)
-            hipLaunchKernelGGL(k_panel_update, dim3(ntile, 1), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dK, (size_t)0,
-                               (int)ld, k0);
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(512), 0, 0, dK, (size_t)0, (int)ld, k0, dW, dR, Npad, dAcc);
-        if (ntile > 1)
-            hipLaunchKernelGGL(k_trsm_strip, dim3(ntile - 1, 1), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dK, (size_t)0,
-                               (int)ld, k0, dW, dR, Npad);
-        PR_TRY(hipGetLastError());
-    }
+    factor_augmented(dK, ld, P, Mt, dW, dR, Npad, dAcc);
+    PR_TRY(hipGetLastError());
     PR_TRY(hipMemcpy(&hacc, dAcc, sizeof(MatAcc), hipMemcpyDeviceToHost));
     *status = (hacc.info != 0.0) ? 1 : 0;
 

@@ -17,6 +17,7 @@
 #include "microbench_kernels.hpp"
 #include "orbit_kernels.hpp"
 #include "predict_kernels.hpp"
+#include "calibrate_kernels.hpp"
 
 using namespace psoap;
 
@@ -784,6 +785,54 @@ extern "C" int psoap_predict(int device, int mode, int c, int N, int M, const do
     if (configure_kernels()) return 1;
     int status = 0;
     int rc = predict_run(mode, c, N, M, lwl, fl, sigma, lwl_pred, mu_c, gp, mu_out, Sigma_out, &status, g_err);
+    if (status_out) *status_out = status;
+    return rc;
+}
+
+// ---- calibration ------------------------------------------------------------------------------
+static int calibrate_check(int M, int N, int order, double lwl0, double lwl1)
+{
+    if (M <= 0 || N <= 0 || order < 0 || order > CAL_MAX_ORDER || !(lwl1 > lwl0)) return 1;
+    return 0;
+}
+
+extern "C" int psoap_calibrate(int device, int c, int M, int N, int order, double lwl0, double lwl1,
+                               const double* lwl_cal, const double* lwls_cal, const double* fl_cal,
+                               const double* sigma_cal, const double* lwls_fixed, const double* fl_fixed,
+                               const double* sigma_fixed, const double* gp, double mu_GP, double* fl_cor, double* X,
+                               int* status_out)
+{
+    if (c < 1 || c > 3 || calibrate_check(M, N, order, lwl0, lwl1) || !lwl_cal || !lwls_cal || !fl_cal || !sigma_cal ||
+        !lwls_fixed || !fl_fixed || !sigma_fixed || !gp || !fl_cor || !X)
+        FAIL("psoap_calibrate: bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    if (configure_kernels()) return 1;
+    CalibInputs in{};
+    in.M = M; in.N = N; in.order = order; in.lwl0 = lwl0; in.lwl1 = lwl1; in.mu = mu_GP;
+    in.lwl_cal = lwl_cal; in.fl_cal = fl_cal; in.fl_fixed = fl_fixed;
+    in.c = c; in.lwls_cal = lwls_cal; in.sigma_cal = sigma_cal; in.lwls_fixed = lwls_fixed; in.sigma_fixed = sigma_fixed;
+    in.gp = gp;
+    int status = 0;
+    int rc = calibrate_run(in, fl_cor, X, &status, g_err);
+    if (status_out) *status_out = status;
+    return rc;
+}
+
+extern "C" int psoap_calibrate_explicit(int device, int M, int N, int order, double lwl0, double lwl1,
+                                        const double* lwl_cal, const double* fl_cal, const double* fl_fixed,
+                                        const double* A, const double* B, const double* C, double mu_GP,
+                                        double* fl_cor, double* X, int* status_out)
+{
+    if (calibrate_check(M, N, order, lwl0, lwl1) || !lwl_cal || !fl_cal || !fl_fixed || !A || !B || !C || !fl_cor || !X)
+        FAIL("psoap_calibrate_explicit: bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    if (configure_kernels()) return 1;
+    CalibInputs in{};
+    in.M = M; in.N = N; in.order = order; in.lwl0 = lwl0; in.lwl1 = lwl1; in.mu = mu_GP;
+    in.lwl_cal = lwl_cal; in.fl_cal = fl_cal; in.fl_fixed = fl_fixed;
+    in.c = 0; in.A = A; in.B = B; in.C = C;
+    int status = 0;
+    int rc = calibrate_run(in, fl_cor, X, &status, g_err);
     if (status_out) *status_out = status;
     return rc;
 }
