@@ -83,11 +83,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("PSOAP_GP_LIB", LIB_PATH)   # override: A/B runs of two builds of the HIP library
+    if not os.path.exists(path):
         raise PsoapError(
-            f"{LIB_PATH} not found: build it with `python -m psoap_amd.build` "
+            f"{path} not found: build it with `python -m psoap_amd.build` "
             "(hipcc, gfx950).  There is no CPU fallback.")
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the symbol is missing
         fn.restype = res
