@@ -70,7 +70,7 @@ struct DagQueues {
 // over rows < q while block row q is still in flight (its final part is one panel long, so the
 // critical chain per block row is 128-row update -> in-block Cholesky), and the last block rows,
 // which have too few tiles to occupy the persistent grid, are cut into up to 8 parts per tile.
-enum : unsigned char { DAG_PART = 0, DAG_DIAG = 1, DAG_OFF = 2 };
+enum : unsigned char { DAG_PART = 0, DAG_DIAG = 1, DAG_OFF = 2, DAG_TYPE_MASK = 0x0F, DAG_CHAIN = 0x10 };
 struct DagTask {
     unsigned char type, q, j, S;
     unsigned short b;
@@ -157,13 +157,12 @@ __device__ __forceinline__ void dag_update(Tile& t, double* Km, int ld, int k0, 
     tile_gemm_tn(t, Km + r1 * ld + k0, (size_t)ld, Km + r1 * ld + j0, (size_t)ld, NB, diag);
 }
 
-// partial sums travel through HBM as [register index][thread] so that every wave stores / loads
-// 512 contiguous bytes per instruction
 // The ONE consumer of the accumulators.  Every task ends its update here:
-//     dest(i, j) <- scale * K(i, j) - acc(i, j) + sum_s part_s(i, j)
-//   final tasks : dest = the tile (k0, j0) of the matrix, scale = 1, part_s = the n_part partial
-//                 tiles written by this tile's PART tasks (they hold -acc_s);
-//   PART tasks  : dest = a workspace slot (row-major 128 x 128), scale = 0, n_part = 0.
+//     dest(i, j) <- scale * K(i, j) - acc(i, j) + sum_s prev_s(i, j)
+//   final tasks : dest = the tile (k0, j0) of the matrix, scale = 1, prev = the n_prev partial tiles
+//                 left by the tile's PART tasks (all S-1 of them, or the running sum of a chain);
+//   PART tasks  : dest = a workspace slot (row-major 128 x 128), scale = 0, prev = the slot of the
+//                 previous PART of a chain (n_prev = 1) or nothing.
 // K is evaluated on the fly in the MFMA accumulator layout (same arithmetic as k_fill_sym:
 // squared-exponential sum, diagonal rule, sigma^2 on the diagonal, identity padding), so the
 // covariance matrix is never materialised in HBM: each tile is written once, already updated.
@@ -173,7 +172,7 @@ template <int C>
 __device__ __forceinline__ void dag_store_updated(const Tile& t, double* dest, size_t ldd, int k0, int j0,
                                                   const double* __restrict__ lw, const GpDev& g, double dsum,
                                                   const double* __restrict__ sigma, int N, double scale,
-                                                  const double* part, int n_part)
+                                                  const double* prev, int n_prev)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -214,7 +213,7 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* dest, s
                 }
                 const size_t off = (size_t)(i - k0) * NB + (size_t)(j - j0);   // inside a 128 x 128 slot
                 double x = scale * v - t.acc[m][n][r];
-                for (int sidx = 0; sidx < n_part; ++sidx) x += part[(size_t)sidx * NB * NB + off];
+                for (int sidx = 0; sidx < n_prev; ++sidx) x += prev[(size_t)sidx * NB * NB + off];
                 dest[(size_t)(i - k0) * ldd + (size_t)(j - j0)] = x;
             }
     }
@@ -313,8 +312,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
         if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 0] = __builtin_amdgcn_s_memrealtime();
         t.zero();
         dag_update(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl);
-        const bool is_part = (task.type == DAG_PART);
-        if (!is_part && task.S > 1) dag_wait_ge(&arrive[task.ctr], task.S - 1, ctl, 4u);
+        const int ttype = task.type & DAG_TYPE_MASK;
+        const bool chain = (task.type & DAG_CHAIN) != 0;
+        const bool is_part = (ttype == DAG_PART);
+        // partial sums of a split tile, two schemes (dag_emit): gathered -- the final waits for all S-1
+        // PARTs and adds their S-1 tiles; chained -- PART s waits for PART s-1 and adds its tile to its
+        // own, the final adds the last one
+        const int n_wait = is_part ? (chain ? (int)task.S : 0) : (int)task.S - 1;
+        const int n_prev = is_part ? (n_wait > 0 ? 1 : 0) : (chain ? (n_wait > 0 ? 1 : 0) : n_wait);
+        if (n_wait > 0) dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);
         {
             GpDev g;
             load_gp(gp + (size_t)b * 2 * C, C, g);
@@ -324,9 +330,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
                 for (int c = 1; c < C; ++c) dsum = dsum + g.a2[c];
             }
             double* dest = is_part ? (wspace + (size_t)task.slot * SLOT) : (Km + (size_t)k0 * ld + j0);
+            const double* prev = wspace + (size_t)(is_part ? task.slot - (unsigned int)n_prev : task.slot) * SLOT;
             dag_store_updated<C>(t, dest, is_part ? (size_t)NB : (size_t)ld, k0, j0, lwl + (size_t)b * C * N, g, dsum,
-                                 sigma, N, is_part ? 0.0 : 1.0, wspace + (size_t)task.slot * SLOT,
-                                 is_part ? 0 : task.S - 1);
+                                 sigma, N, is_part ? 0.0 : 1.0, prev, n_prev);
         }
         if (is_part) {
             dag_drain();
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
         }
         dag_drain();  // the tile is re-read below in another layout by other waves of this block
         if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-        if (task.type == DAG_DIAG) {
+        if (ttype == DAG_DIAG) {
             potrf_blocked(Km, ld, k0, Wm, Rv, acc + b);
             dag_drain();
             if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 2] = __builtin_amdgcn_s_memrealtime();
@@ -386,37 +392,58 @@ inline int dag_split_factor(int tasks_in_row, int q, int workers)
     return S;
 }
 
-inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first, int pb_last, int nparts)
+// Tasks of one tile whose update over panels [pa_first, pb_last) is cut into pieces.
+//   scheme 0 (throughput): nsplit equal ranges; the first nsplit-1 are PARTs, the final takes the last
+//     range and GATHERS the nsplit-1 partial tiles.  Least work per tile; right when other matrices of
+//     the queue hide the wait for the block row above.
+//   scheme 1 (latency): nsplit PARTs over equal ranges of [pa_first, pb_last - 1) plus a final that
+//     covers the LAST panel only -- the one piece that has to wait for the block row above, kept as
+//     short as the dependency allows (the PARTs wait for older rows and run ahead).  The partial sums
+//     are CHAINED: PART s adds the tile PART s-1 left in the previous slot to its own, so every task
+//     reads one partial tile.  Right when a queue holds one matrix and the row-to-row chain is the
+//     critical path.
+// Encoding: PART.S = index in the chain (0 when gathered), PART.slot = its output (consecutive);
+// final.S = number of pieces, final.slot = first slot to read (gather: the first PART's, chain: the
+// last PART's).  nsplit == 1: one final over the whole range.
+inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first, int pb_last, int nsplit, int scheme)
 {
-    // parts 0 .. nparts-2 are PARTs over equal panel ranges of [pa_first, pb_last); the final part
-    // is the task of `type`.  nparts == 1: no PART, the final covers the whole range.
-    const unsigned int ctr = (nparts > 1) ? plan.n_ctrs++ : 0u;
+    const bool chain = (scheme == 1) && nsplit > 1;
+    const int nparts = chain ? nsplit : nsplit - 1;                 // PART tasks
+    const unsigned int ctr = (nparts > 0) ? plan.n_ctrs++ : 0u;
     const unsigned int slot0 = plan.n_slots;
-    const int span = pb_last - pa_first;
+    const int pb_parts = chain ? pb_last - 1 : pb_last;
+    const int span = pb_parts - pa_first;
+    const unsigned char flag = chain ? DAG_CHAIN : 0;
     for (int sidx = 0; sidx < nparts; ++sidx) {
         DagTask t{};
+        t.type = DAG_PART | flag;
         t.b = (unsigned short)b;
         t.q = (unsigned char)q;
         t.j = (unsigned char)j;
-        t.S = (unsigned char)nparts;
-        t.pa = (unsigned char)(pa_first + (long long)span * sidx / nparts);
-        t.pb = (unsigned char)(pa_first + (long long)span * (sidx + 1) / nparts);
+        t.S = (unsigned char)(chain ? sidx : 0);
+        t.pa = (unsigned char)(pa_first + (long long)span * sidx / nsplit);
+        t.pb = (unsigned char)(pa_first + (long long)span * (sidx + 1) / nsplit);
+        t.slot = plan.n_slots++;
         t.ctr = ctr;
-        if (sidx < nparts - 1) {
-            t.type = DAG_PART;
-            t.slot = plan.n_slots++;
-        } else {
-            t.type = (unsigned char)type;
-            t.slot = slot0;
-        }
         plan.tasks.push_back(t);
     }
+    DagTask t{};
+    t.type = (unsigned char)type | flag;
+    t.b = (unsigned short)b;
+    t.q = (unsigned char)q;
+    t.j = (unsigned char)j;
+    t.S = (unsigned char)(nparts + 1);
+    t.pa = (unsigned char)(chain ? pb_last - 1 : pa_first + (long long)span * (nsplit - 1) / nsplit);
+    t.pb = (unsigned char)pb_last;
+    t.slot = (nparts > 0) ? (chain ? plan.n_slots - 1 : slot0) : 0u;
+    t.ctr = ctr;
+    plan.tasks.push_back(t);
 }
 
 // task list of ONE queue: the matrices in `mats`, served by about `workers` workgroups
 // `Bq_nominal` (the largest queue's matrix count) decides the split factors, so every matrix of the
 // batch gets the same task structure and identical proposals give identical bits in any batch slot
-inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, int workers, int Bq_nominal)
+inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, int workers, int Bq_nominal, int scheme)
 {
     const int Bq = Bq_nominal;
     if (mats.empty()) return;
@@ -425,7 +452,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, 
         const int S_off = dag_split_factor(Bq * (P - q), q, workers);
         // 1. DIAG finals of this row
         if (q <= 1) {
-            for (int b : mats) dag_emit(plan, DAG_DIAG, b, q, q, 0, q, 1);
+            for (int b : mats) dag_emit(plan, DAG_DIAG, b, q, q, 0, q, 1, scheme);
         } else {
             for (const DagTask& t : early_final[q]) plan.tasks.push_back(t);
         }
@@ -435,13 +462,15 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, 
             for (int b : mats) {
                 const unsigned int ctr = plan.n_ctrs++;
                 const unsigned int slot0 = plan.n_slots;
+                const bool chain = (scheme == 1);
+                const unsigned char flag = chain ? DAG_CHAIN : 0;
                 for (int sidx = 0; sidx < S_pre; ++sidx) {
                     DagTask t{};
-                    t.type = DAG_PART;
+                    t.type = DAG_PART | flag;
                     t.b = (unsigned short)b;
                     t.q = (unsigned char)(q + 1);
                     t.j = (unsigned char)(q + 1);
-                    t.S = (unsigned char)(S_pre + 1);
+                    t.S = (unsigned char)(chain ? sidx : 0);
                     t.pa = (unsigned char)((long long)q * sidx / S_pre);
                     t.pb = (unsigned char)((long long)q * (sidx + 1) / S_pre);
                     t.slot = plan.n_slots++;
@@ -449,32 +478,40 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, 
                     plan.tasks.push_back(t);
                 }
                 DagTask fin{};
-                fin.type = DAG_DIAG;
+                fin.type = DAG_DIAG | flag;
                 fin.b = (unsigned short)b;
                 fin.q = fin.j = (unsigned char)(q + 1);
                 fin.S = (unsigned char)(S_pre + 1);
                 fin.pa = (unsigned char)q;
                 fin.pb = (unsigned char)(q + 1);
-                fin.slot = slot0;
+                fin.slot = chain ? plan.n_slots - 1 : slot0;
                 fin.ctr = ctr;
                 early_final[q + 1].push_back(fin);
             }
         }
         // 3. off-diagonal tiles of this row
         for (int b : mats)
-            for (int j = q + 1; j < P; ++j) dag_emit(plan, DAG_OFF, b, q, j, 0, q, S_off);
+            for (int j = q + 1; j < P; ++j) dag_emit(plan, DAG_OFF, b, q, j, 0, q, S_off, scheme);
     }
 }
 
-inline DagPlan dag_build_tasks(int B, int P, int workers)
+// scheme: 0 throughput, 1 latency (dag_emit), -1 automatic: latency while the batch is small enough that
+// the row-to-row dependency chain, not the MFMA work, bounds the run time.  Measured crossover on
+// MI355X (tools/scheme_table.py; N = 2000 .. 8192, B = 1 .. 32): about 14,000 tiles in the batch --
+// e.g. N = 6000: chain wins up to B = 12 (B = 1: 14.9 -> 7.7 ms), gather from B = 16 (B = 32: 39.9 vs 42.9 ms).
+constexpr long long DAG_LATENCY_TILES = 14000;
+inline DagPlan dag_build_tasks(int B, int P, int workers, int scheme = -1)
 {
     DagPlan plan;
-    const int per_queue = workers / DAG_QUEUES > 0 ? workers / DAG_QUEUES : 1;
+    if (scheme < 0) scheme = ((long long)B * P * (P + 1) / 2 <= DAG_LATENCY_TILES) ? 1 : 0;
+    // workgroups of XCDs whose own queue is empty steal, so the workers are shared by the queues in use
+    const int used = B < DAG_QUEUES ? (B > 0 ? B : 1) : DAG_QUEUES;
+    const int per_queue = workers / used > 0 ? workers / used : 1;
     for (int g = 0; g < DAG_QUEUES; ++g) {
         plan.queues.first[g] = (unsigned int)plan.tasks.size();
         std::vector<int> mats;
         for (int b = g; b < B; b += DAG_QUEUES) mats.push_back(b);
-        dag_build_queue(plan, mats, P, per_queue, (B + DAG_QUEUES - 1) / DAG_QUEUES);
+        dag_build_queue(plan, mats, P, per_queue, (B + DAG_QUEUES - 1) / DAG_QUEUES, scheme);
     }
     plan.queues.first[DAG_QUEUES] = (unsigned int)plan.tasks.size();
     return plan;

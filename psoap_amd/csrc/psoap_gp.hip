@@ -261,7 +261,7 @@ extern "C" int psoap_chunk_dag_tasklog(psoap_chunk* h, unsigned long long* out, 
 {
     if (!h) FAIL("null handle");
     if (set_dev(h)) return 1;
-    const long long tasks = 4ll * h->max_batch * h->P * (h->P + 1) / 2 + 1024;
+    const long long tasks = 9ll * h->max_batch * h->P * (h->P + 1) / 2 + 1024;   // <= 8 parts per tile + early DIAG parts
     if (!h->dTlog) {
         HIP_TRY(hipMalloc(&h->dTlog, sizeof(unsigned long long) * 4 * tasks));
         HIP_TRY(hipMemset(h->dTlog, 0, sizeof(unsigned long long) * 4 * tasks));
@@ -496,7 +496,9 @@ static int dag_prepare(psoap_chunk* h)
     if (h->plan_B == h->B) return 0;
     if (h->P > 255) FAIL("N too large for the persistent kernel's 8-bit block-row indices (N <= 32640)");
     HIP_TRY(hipDeviceSynchronize());
-    DagPlan plan = dag_build_tasks(h->B, h->P, h->dag_grid);
+    // PSOAP_DAG_SCHEME=0|1 pins the split scheme (experiments); default: automatic
+    const char* env_scheme = getenv("PSOAP_DAG_SCHEME");
+    DagPlan plan = dag_build_tasks(h->B, h->P, h->dag_grid, env_scheme ? atoi(env_scheme) : -1);
     if (plan.n_ctrs > h->arrive_cap) FAIL("internal: arrival counter capacity exceeded");
     if (plan.tasks.size() > h->tasks_cap) {
         if (h->dTasks) HIP_TRY(hipFree(h->dTasks));

@@ -8,6 +8,7 @@ import pytest
 TASK = np.dtype([("type", "u1"), ("q", "u1"), ("j", "u1"), ("S", "u1"), ("b", "<u2"), ("pa", "u1"), ("pb", "u1"),
                  ("slot", "<u4"), ("ctr", "<u4")])
 PART, DIAG, OFF = 0, 1, 2
+TYPE_MASK, CHAIN = 0x0F, 0x10
 
 
 def plan(B, P, workers):
@@ -20,6 +21,8 @@ def plan(B, P, workers):
     assert L.psoap_dag_plan(B, P, workers, tasks.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n),
                             ctypes.byref(slots), ctypes.byref(ctrs), first) == 0
     plan.queue_first = list(first)
+    plan.chain = (tasks["type"] & CHAIN) != 0
+    tasks["type"] &= TYPE_MASK
     return tasks, slots.value, ctrs.value
 
 
@@ -27,7 +30,10 @@ def plan(B, P, workers):
                                          (32, 47, 512), (32, 64, 512), (5, 20, 8), (200, 4, 512)])
 def test_plan_is_complete_and_deadlock_free(B, P, workers):
     tasks, n_slots, n_ctrs = plan(B, P, workers)
+    chain = plan.chain
     assert TASK.itemsize == 16
+    # small batches (<= 14,000 tiles): latency scheme, chained partial sums; otherwise gathered
+    assert np.all(chain[tasks["S"] > 1] == (B * P * (P + 1) // 2 <= 14000)) if (tasks["S"] > 1).any() else True
     # one queue per XCD: matrix b lives in queue b mod 8, queues are contiguous ranges of the list
     first = plan.queue_first
     assert first[0] == 0 and first[8] == len(tasks) and all(first[g] <= first[g + 1] for g in range(8))
@@ -45,7 +51,7 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
         assert k["pa"] <= k["pb"] <= k["q"]
         covered.setdefault(key, []).append((int(k["pa"]), int(k["pb"])))
         if k["type"] == PART:
-            assert k["S"] > 1 and k["slot"] < n_slots and k["ctr"] < n_ctrs
+            assert k["slot"] < n_slots and k["ctr"] < n_ctrs
             assert int(k["slot"]) not in slots_seen
             slots_seen.add(int(k["slot"]))
             part_done_ticket.setdefault(int(k["ctr"]), []).append(t)
@@ -79,11 +85,23 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
             if k["S"] > 1:
                 parts = part_done_ticket[int(k["ctr"])]
                 assert len(parts) == k["S"] - 1 and max(parts) < t
-                # its partial slots are slot .. slot+S-2
-                got = sorted(int(tasks[p]["slot"]) for p in parts)
-                assert got == list(range(int(k["slot"]), int(k["slot"]) + int(k["S"]) - 1))
+                assert parts == sorted(parts)
+                got = [int(tasks[p]["slot"]) for p in parts]
+                assert got == list(range(got[0], got[0] + len(parts)))        # consecutive slots
                 for p in parts:
                     assert (int(tasks[p]["b"]), int(tasks[p]["q"]), int(tasks[p]["j"])) == (b, q, j)
+                    assert chain[p] == chain[t]
+                if chain[t]:
+                    # chained: PART s has index S == s and waits for its predecessor (a smaller ticket);
+                    # the final reads the last PART's slot and covers only the last panel -- the one
+                    # that depends on the block row above
+                    assert [int(tasks[p]["S"]) for p in parts] == list(range(len(parts)))
+                    assert int(k["slot"]) == got[-1]
+                    assert int(k["pb"]) - int(k["pa"]) == 1
+                else:
+                    # gathered: PARTs wait for nothing, the final reads all of them from the first slot
+                    assert all(int(tasks[p]["S"]) == 0 for p in parts)
+                    assert int(k["slot"]) == got[0]
             if k["type"] == OFF:
                 assert diag_final_ticket[(b, q)] < t
 

@@ -68,3 +68,23 @@ def test_not_positive_definite_inside_batch():
             got = h.lnlike_batch(lw, gps)
         assert got[2] == -np.inf
         assert np.isfinite(got[[0, 1, 3]]).all() and got[0] == got[1] == got[3]
+
+
+def test_both_split_schemes_agree_with_oracle(oracle, monkeypatch):
+    """The persistent kernel's two ways of cutting a tile's update (gathered partial tiles for
+    throughput, chained partial sums + last-panel finals for latency) pinned one after the other."""
+    from psoap_amd.chunk import ChunkHandle
+    for c, ne, npx, B, seed in ((2, 5, 300, 3, 31), (3, 4, 260, 1, 32), (1, 9, 200, 11, 33)):
+        ch = syn.make_chunk(c, ne, npx, seed=seed, masked_fraction=0.1)
+        gps = syn.make_walkers(c, B, seed=seed + 100)
+        lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, B, seed=seed + 200))
+        got = {}
+        for scheme in ("0", "1"):
+            monkeypatch.setenv("PSOAP_DAG_SCHEME", scheme)
+            with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
+                got[scheme] = h.lnlike_batch(lw, gps)
+                assert np.array_equal(h.lnlike_batch(lw, gps), got[scheme])
+        for w in range(B):
+            assert close(got["0"][w], got["1"][w]), (ch.N, w)
+        want = oracle.lnlike(lw[B - 1], ch.fl, ch.sigma, gps[B - 1])
+        assert close(got["0"][B - 1], want) and close(got["1"][B - 1], want), (ch.N, got, want)
