@@ -187,9 +187,12 @@ int psoap_dag_plan(int B, int P, int workers, void *out, long long max_tasks, lo
  * spec peaks in bench.py (results in TFLOP/s and GB/s). */
 int psoap_microbench_mfma_f64(int device, double *tflops);
 int psoap_microbench_hbm(int device, double *write_gbs, double *copy_gbs);
-/* The MFMA tile engine alone (512 workgroups, K = 4096): shared_operands = 1 -> all tiles read the same
- * L2-resident strips; 0 -> every tile streams its own B strip from HBM (the factorisation's pattern). */
-int psoap_microbench_tile_engine(int device, int shared_operands, double *tflops);
+/* The MFMA tile engine alone (512 workgroups, K = 4096).  variant: 9 / 8 = the production engine
+ * (LDS-DMA staging) with all tiles reading the same L2-resident strips / every tile streaming its own
+ * B strip from HBM (the factorisation's pattern); 1 / 0 = the same two patterns with the earlier
+ * register-staged engine (global_load -> ds_write), kept for comparison; 16 + abl = loop ablations
+ * (abl bit 0: no staging traffic, bit 1: no workgroup barrier, bit 2: no LDS fragment reads). */
+int psoap_microbench_tile_engine(int device, int variant, double *tflops);
 /* One workgroup factoring a 128 x 128 tile (potrf_blocked), microseconds per factorisation; ablate 0 =
  * the shipped routine, 1-3 = timing ablations (no in-wave 16 x 16 factorisation / no MFMA phases / no W output). */
 int psoap_microbench_potrf(int device, int ablate, double *usec);

@@ -145,7 +145,8 @@ def microbench(device: int | None = None) -> dict:
     check(L.psoap_microbench_hbm(dev, ctypes.byref(w), ctypes.byref(c)), "psoap_microbench_hbm")
     t1 = ctypes.c_double()
     t0 = ctypes.c_double()
-    check(L.psoap_microbench_tile_engine(dev, 1, ctypes.byref(t1)), "psoap_microbench_tile_engine")
-    check(L.psoap_microbench_tile_engine(dev, 0, ctypes.byref(t0)), "psoap_microbench_tile_engine")
+    # variants 9 / 8: the production engine (LDS-DMA staging) on L2-resident / HBM-streamed operands
+    check(L.psoap_microbench_tile_engine(dev, 9, ctypes.byref(t1)), "psoap_microbench_tile_engine")
+    check(L.psoap_microbench_tile_engine(dev, 8, ctypes.byref(t0)), "psoap_microbench_tile_engine")
     return {"mfma_f64_tflops": tf.value, "hbm_write_gbs": w.value, "hbm_copy_gbs": c.value,
             "tile_engine_l2_tflops": t1.value, "tile_engine_hbm_tflops": t0.value}

@@ -1,0 +1,52 @@
+"""Copy the judged evidence of a profiling round from gpurun_out/ (scratch) into profiles/ (tracked).
+
+    python tools/collect_profiles.py r1
+
+Takes the newest rocprofv3 outputs under gpurun_out/prof_<tag>/ (tools/profile_round.sh), keeps the rows
+of the dominant kernel from the counter passes, and rewrites profiles/<tag>_traffic.json from the
+FETCH_SIZE / WRITE_SIZE passes (gfx950 correction: FETCH_SIZE x 2, MI355X_MICROARCH.md).
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+KERNEL = "k_chol_dag"
+
+
+def newest(pattern):
+    files = glob.glob(os.path.join(src, pattern))
+    if not files:
+        sys.exit(f"nothing matches {pattern} under {src}")
+    return max(files, key=os.path.getmtime)
+
+
+shutil.copy(newest("trace/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+shutil.copy(os.path.join(src, f"summary_{tag}.md"), os.path.join(dst, f"{tag}_summary.md"))
+means = {}
+for name in ("sq", "fetch", "write"):
+    rows = list(csv.DictReader(open(newest(f"pmc_{name}/*/*_counter_collection.csv"))))
+    keep = [r for r in rows if KERNEL in r["Kernel_Name"]]
+    with open(os.path.join(dst, f"{tag}_pmc_{name}.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(keep)
+    for r in keep:
+        means.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+fetch_kb = sum(means["FETCH_SIZE"]) / len(means["FETCH_SIZE"])
+write_kb = sum(means["WRITE_SIZE"]) / len(means["WRITE_SIZE"])
+old = json.load(open(os.path.join(dst, f"{tag}_traffic.json")))
+old.update(fetch_size_kb_raw=fetch_kb, write_size_kb_raw=write_kb, fetch_correction=2.0,
+           hbm_bytes_per_launch=(2.0 * fetch_kb + write_kb) * 1024.0)
+json.dump(old, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=2)
+for a, b in ((f"latency_{tag}.jsonl", f"{tag}_latency_table.jsonl"), (f"bench_{tag}.json", f"{tag}_bench.json")):
+    p = os.path.join(ROOT, "gpurun_out", a)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, b))
+print("traffic per launch: %.1f GB (read %.1f, written %.1f)" % ((2 * fetch_kb + write_kb) * 1024 / 1e9, 2 * fetch_kb * 1024 / 1e9, write_kb * 1024 / 1e9))
