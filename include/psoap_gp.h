@@ -193,6 +193,9 @@ int psoap_microbench_hbm(int device, double *write_gbs, double *copy_gbs);
  * register-staged engine (global_load -> ds_write), kept for comparison; 16 + abl = loop ablations
  * (abl bit 0: no staging traffic, bit 1: no workgroup barrier, bit 2: no LDS fragment reads). */
 int psoap_microbench_tile_engine(int device, int variant, double *tflops);
+/* Self-check of the batched exp() the fused-fill epilogue uses for non-positive arguments: counts the
+ * x[i] (n a multiple of 4) whose result differs in any bit from the device library's exp(). */
+int psoap_microbench_exp_check(int device, long long n, const double *x, long long *mismatches);
 /* One workgroup factoring a 128 x 128 tile (potrf_blocked), microseconds per factorisation; ablate 0 =
  * the shipped routine, 1-3 = timing ablations (no in-wave 16 x 16 factorisation / no MFMA phases / no W output). */
 int psoap_microbench_potrf(int device, int ablate, double *usec);

@@ -60,6 +60,7 @@ SIGNATURES = {
     "psoap_calibrate_explicit": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                                 ctypes.c_double, _dp, _dp, _dp, _dp, _dp, _dp, ctypes.c_double, _dp, _dp,
                                                 _ip]),
+    "psoap_microbench_exp_check": (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong, _dp, ctypes.POINTER(ctypes.c_longlong)]),
     "psoap_chunk_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "psoap_chunk_get_timings": (ctypes.c_int, [_vp, ctypes.POINTER(Timings)]),
     "psoap_chunk_set_stream_groups": (ctypes.c_int, [_vp, ctypes.c_int]),

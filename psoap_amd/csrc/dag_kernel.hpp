@@ -196,7 +196,9 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* dest, s
             for (int c = 0; c < C; ++c) xi[r][c] = (ii[r] < N) ? lw[(size_t)c * N + ii[r]] : 0.0;
         }
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < 4; ++n) {
+            double kv[4] = {0.0, 0.0, 0.0, 0.0};
+            if (scale != 0.0) kern_elem4_skip<C>(xi, xj[n], g, kv);   // wave-uniform: PART tasks never need K
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = ii[r], j = jj[n];
@@ -206,10 +208,8 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* dest, s
 #pragma clang fp contract(off)
                         const double sg = sigma[i];
                         v = dsum + sg * sg;
-                    } else if (scale != 0.0) {   // wave-uniform: PART tasks (scale 0) never need K
-                        v = kern_elem<C>(xi[r], xj[n], g);
                     } else {
-                        v = 0.0;
+                        v = kv[r];
                     }
                 } else {
                     v = (i == j) ? 1.0 : 0.0;
@@ -219,6 +219,7 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* dest, s
                 for (int sidx = 0; sidx < n_prev; ++sidx) x += prev[(size_t)sidx * NB * NB + off];
                 dest[(size_t)(i - k0) * ldd + (size_t)(j - j0)] = x;
             }
+        }
     }
 }
 

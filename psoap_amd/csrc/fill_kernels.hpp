@@ -51,6 +51,87 @@ __device__ __forceinline__ double kern_elem(const double (&xi)[C], const double 
     return cov;
 }
 
+// exp() of NE arguments at once, operation for operation the sequence the device math library's
+// double-precision exp compiles to on gfx950 (Cody-Waite reduction by ln2 in two parts, degree-11
+// Horner polynomial, ldexp; constants read back from the compiled library code), so the results are
+// bit-identical to exp() for every x <= 0 and for NaN -- the only arguments the kernel produces; the
+// library's x > 1024 -> inf select is dropped.  The point of the batch: the NE Horner chains are
+// independent (an epilogue runs with one wave per SIMD, so a single chain is latency-bound), and each
+// polynomial constant is materialised once per step instead of once per call.
+template <int NE>
+__device__ __forceinline__ void exp_nonpos_batch(const double (&x)[NE], double (&z)[NE])
+{
+    constexpr double LOG2E = 0x1.71547652b82fep+0;      // 0x3ff71547652b82fe
+    constexpr double NLN2_HI = -0x1.62e42fefa39efp-1;   // 0xbfe62e42fefa39ef
+    constexpr double NLN2_LO = -0x1.abc9e3b39803fp-56;  // 0xbc7abc9e3b39803f
+    constexpr double CK[10] = {
+        0x1.ade156a5dcb37p-26,  // 0x3e5ade156a5dcb37
+        0x1.28af3fca7ab0cp-22,  // 0x3e928af3fca7ab0c
+        0x1.71dee623fde64p-19,  // 0x3ec71dee623fde64
+        0x1.a01997c89e6b0p-16,  // 0x3efa01997c89e6b0
+        0x1.a01a014761f6ep-13,  // 0x3f2a01a014761f6e
+        0x1.6c16c1852b7b0p-10,  // 0x3f56c16c1852b7b0
+        0x1.1111111122322p-7,   // 0x3f81111111122322
+        0x1.55555555502a1p-5,   // 0x3fa55555555502a1
+        0x1.5555555555511p-3,   // 0x3fc5555555555511
+        0x1.000000000000bp-1,   // 0x3fe000000000000b
+    };
+    double dn[NE], t[NE], p[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) dn[e] = __builtin_rint(x[e] * LOG2E);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) t[e] = __builtin_fma(NLN2_HI, dn[e], x[e]);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) t[e] = __builtin_fma(NLN2_LO, dn[e], t[e]);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) p[e] = __builtin_fma(CK[0], t[e], CK[1]);
+#pragma unroll
+    for (int k = 2; k < 10; ++k)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) p[e] = __builtin_fma(t[e], p[e], CK[k]);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) p[e] = __builtin_fma(t[e], p[e], 1.0);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) p[e] = __builtin_fma(t[e], p[e], 1.0);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const double r = __builtin_ldexp(p[e], (int)dn[e]);
+        z[e] = (x[e] < -1075.0) ? 0.0 : r;
+    }
+}
+
+// Four squared-exponential elements (the four accumulator registers of one MFMA block) with the
+// underflow shortcut: exp(a) is exactly +0 for a < -745.14, so when every lane of the wave is below
+// -746 for all four the terms are +0 without evaluating exp (a wave-uniform branch; same bits as
+// kern_elem).  With resolved spectra most 16 x 16 patches far from the band diagonals underflow.
+template <int C>
+__device__ __forceinline__ void kern_elem4_skip(const double (&xi)[4][C], const double (&xj)[C], const GpDev& g,
+                                                double (&cov)[4])
+{
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        double a[4], e[4];
+        bool live = false;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double d = xj[c] - xi[r][c];
+            a[r] = g.p2[c] * d * d;
+            live = live || !(a[r] <= -746.0);
+        }
+        if (__builtin_amdgcn_ballot_w64(live) != 0ull) {
+            exp_nonpos_batch<4>(a, e);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = g.a2[c] * e[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cov[r] = (c == 0) ? e[r] : cov[r] + e[r];
+    }
+}
+
 // Symmetric fill of a batch of padded matrices.
 //   Kbase + b*mat_stride : (Npad x ld) row-major; rows/cols >= N become identity
 //   lwl  : (B, C, N) device;  gp : (B, 2C) device;  sigma : (N) device or nullptr

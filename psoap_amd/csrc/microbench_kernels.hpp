@@ -252,6 +252,43 @@ inline int microbench_tile_engine(int shared_operands, double* tflops, std::stri
     return 0;
 }
 
+// exp_nonpos_batch against the device library's exp(), bit for bit (the fused-fill epilogue relies on it)
+__global__ void k_exp_check(const double* __restrict__ x, long long n, unsigned long long* mismatches)
+{
+    const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 + 3 >= n) return;
+    double a[4], z[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = x[i0 + e];
+    exp_nonpos_batch<4>(a, z);
+    unsigned long long bad = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double want = exp(a[e]);
+        bad += (__double_as_longlong(want) != __double_as_longlong(z[e])) ? 1ull : 0ull;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+inline int microbench_exp_check(long long n, const double* x, long long* mismatches, std::string& err)
+{
+    double* dx = nullptr;
+    unsigned long long* dm = nullptr;
+    unsigned long long hm = 0;
+    n -= n % 4;
+    MB_TRY(hipMalloc(&dx, sizeof(double) * n));
+    MB_TRY(hipMalloc(&dm, sizeof(unsigned long long)));
+    MB_TRY(hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
+    MB_TRY(hipMemset(dm, 0, sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_exp_check, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, 0, dx, n, dm);
+    MB_TRY(hipGetLastError());
+    MB_TRY(hipMemcpy(&hm, dm, sizeof(hm), hipMemcpyDeviceToHost));
+    (void)hipFree(dx);
+    (void)hipFree(dm);
+    *mismatches = (long long)hm;
+    return 0;
+}
+
 inline int microbench_potrf(int ablate, double* usec, std::string& err)
 {
     std::vector<double> K0(NB * NB);

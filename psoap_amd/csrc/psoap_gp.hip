@@ -858,6 +858,13 @@ extern "C" int psoap_microbench_potrf(int device, int ablate, double* usec)
     return microbench_potrf(ablate, usec, g_err);
 }
 
+extern "C" int psoap_microbench_exp_check(int device, long long n, const double* x, long long* mismatches)
+{
+    if (n < 4 || !x || !mismatches) FAIL("psoap_microbench_exp_check: bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    return microbench_exp_check(n, x, mismatches, g_err);
+}
+
 extern "C" int psoap_microbench_hbm(int device, double* write_gbs, double* copy_gbs)
 {
     HIP_TRY(hipSetDevice(device));

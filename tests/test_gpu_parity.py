@@ -294,3 +294,23 @@ def test_predict_sum_transposed_mean_and_predict_f(oracle, cov):
     np.testing.assert_allclose(Sig, Sig_o, rtol=0, atol=1e-9)
     with pytest.raises(AssertionError, match="Input wavelengths must be the same length."):
         cov.predict_f_g(ch.lwls[0], ch.lwls[1][:-1], ch.fl, ch.sigma, pg, pg, 0.0, 0.2, 5.0, 0.0, 0.1, 7.0)
+
+
+def test_batched_exp_is_bit_identical_to_library_exp():
+    """The fused-fill epilogue evaluates exp() four at a time with the library's own operation sequence;
+    every non-positive argument (normal, denormal result, underflow, -0, huge) and NaN must give the same bits."""
+    import ctypes
+    from psoap_amd import _lib
+    rng = np.random.default_rng(77)
+    x = np.concatenate([
+        -rng.uniform(0.0, 760.0, 400000),                 # the whole useful range incl. denormal results
+        -np.exp(rng.uniform(-40.0, 7.0, 200000)),         # log-uniform magnitudes down to 1e-18
+        -rng.uniform(700.0, 1100.0, 50000),               # around the underflow thresholds
+        np.array([0.0, -0.0, -745.1332191019411, -745.1332191019412, -746.0, -1074.9, -1075.0, -1075.1,
+                  -1e10, -1e300, -np.inf, np.nan, -5e-324, -2.2250738585072014e-308]),
+    ])
+    x = np.ascontiguousarray(x[: len(x) - len(x) % 4])
+    bad = ctypes.c_longlong(-1)
+    _lib.check(_lib.load().psoap_microbench_exp_check(_lib.default_device(), len(x), _lib.dptr(x), ctypes.byref(bad)),
+               "psoap_microbench_exp_check")
+    assert bad.value == 0
