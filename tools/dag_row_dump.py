@@ -20,6 +20,7 @@ with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
     h._L.psoap_chunk_dag_tasks(h._h, tasks.ctypes.data_as(ctypes.c_void_p), nt, ctypes.byref(n))
     log = np.zeros(nt * 4, dtype=np.uint64)
     h._L.psoap_chunk_dag_tasklog(h._h, log.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), nt)
+tasks["type"] &= 0x0F   # strip the chain flag
 log = log.reshape(nt, 4).astype(np.float64) / 100.0
 log -= log[:, 0].min()
 names = {0: "PART", 1: "DIAG", 2: "OFF "}
