@@ -28,6 +28,7 @@
 // factored), cnt (finished tasks of the current block row).  The update of block row q reads
 // rows < q; it is split so that rows < q-1 are consumed before waiting for row q-1 (look-ahead).
 #pragma once
+#include <algorithm>
 #include <vector>
 
 #include "chol_kernels.hpp"
@@ -519,9 +520,11 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, 
 
 // scheme: 0 throughput, 1 latency (dag_emit), -1 automatic: latency while the batch is small enough that
 // the row-to-row dependency chain, not the MFMA work, bounds the run time.  Measured crossover on
-// MI355X (tools/scheme_table.py; N = 2000 .. 8192, B = 1 .. 32): about 14,000 tiles in the batch --
-// e.g. N = 6000: chain wins up to B = 12 (B = 1: 14.9 -> 7.7 ms), gather from B = 16 (B = 32: 39.9 vs 42.9 ms).
-constexpr long long DAG_LATENCY_TILES = 14000;
+// MI355X (tools/scheme_table.py; N = 2000 .. 8192, B = 1 .. 32): about 20,000 tiles in the batch --
+// e.g. N = 6000: latency wins up to B = 16 (B = 1: 14.9 -> 7.7 ms, B = 8: 19.5 -> 14.8 ms), throughput
+// from B = 24 (B = 32: 39.5 vs 40.3 ms).  (Readiness ordering was also tried for the throughput scheme:
+// 800 -> 776 evals/s, not adopted.)
+constexpr long long DAG_LATENCY_TILES = 20000;
 inline DagPlan dag_build_tasks(int B, int P, int workers, int scheme = -1)
 {
     DagPlan plan;
@@ -534,6 +537,27 @@ inline DagPlan dag_build_tasks(int B, int P, int workers, int scheme = -1)
         std::vector<int> mats;
         for (int b = g; b < B; b += DAG_QUEUES) mats.push_back(b);
         dag_build_queue(plan, mats, P, per_queue, (B + DAG_QUEUES - 1) / DAG_QUEUES, scheme);
+        if (scheme == 1) {
+            // Latency scheme: hand the tasks out in order of READINESS instead of block row by block row.
+            // A task over panels [pa, pb) can run once block row pb-1 is finished ("stage" pb); within a
+            // stage the diagonal final (the in-block Cholesky everybody waits for) comes first, then the
+            // row's other finals, then the PARTs that just became ready, nearest block row first.  PARTs of
+            // far-away rows thus run as soon as their panels exist instead of arriving in a burst when
+            // their row comes up, and a worker rarely takes a ticket it then has to spin on.  Every wait
+            // still targets a smaller ticket: a chain's PARTs have increasing pb, its final the largest.
+            auto cls = [](const DagTask& t) {
+                const int ty = t.type & DAG_TYPE_MASK;
+                return ty == DAG_DIAG ? 0 : (ty == DAG_OFF ? 1 : 2);
+            };
+            std::stable_sort(plan.tasks.begin() + plan.queues.first[g], plan.tasks.end(),
+                             [&](const DagTask& a, const DagTask& b) {
+                                 if (a.pb != b.pb) return a.pb < b.pb;
+                                 const int ca = cls(a), cb = cls(b);
+                                 if (ca != cb) return ca < cb;
+                                 if (ca == 2 && a.q != b.q) return a.q < b.q;
+                                 return false;
+                             });
+        }
     }
     plan.queues.first[DAG_QUEUES] = (unsigned int)plan.tasks.size();
     return plan;

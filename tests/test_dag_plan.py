@@ -32,8 +32,8 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
     tasks, n_slots, n_ctrs = plan(B, P, workers)
     chain = plan.chain
     assert TASK.itemsize == 16
-    # small batches (<= 14,000 tiles): latency scheme, chained partial sums; otherwise gathered
-    assert np.all(chain[tasks["S"] > 1] == (B * P * (P + 1) // 2 <= 14000)) if (tasks["S"] > 1).any() else True
+    # small batches (<= 20,000 tiles): latency scheme, chained partial sums; otherwise gathered
+    assert np.all(chain[tasks["S"] > 1] == (B * P * (P + 1) // 2 <= 20000)) if (tasks["S"] > 1).any() else True
     # one queue per XCD: matrix b lives in queue b mod 8, queues are contiguous ranges of the list
     first = plan.queue_first
     assert first[0] == 0 and first[8] == len(tasks) and all(first[g] <= first[g + 1] for g in range(8))
