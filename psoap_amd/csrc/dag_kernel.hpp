@@ -170,21 +170,40 @@ __device__ __forceinline__ void dag_update(Tile& t, double* Km, int ld, int k0, 
 // (A separate store routine for PART tasks makes hipcc spill the 128 accumulator registers inside the
 // MFMA loops -- a second consumer -- so PART tasks share this one and skip the exp() evaluation through
 // a wave-uniform branch per element: +0.7 % end to end, the fp64 pipe time goes back to the MFMAs.)
-template <int C>
+// Augmented columns (predict: [B | Cx^T]): column tiles j >= P carry cross-covariances between the data
+// grid (rows) and a prediction grid (columns).  colx holds the prediction abscissae per component,
+// (C, Rpad); a component that must not contribute to a column is given the abscissa 1e30 there (its
+// exponent underflows to an exact +0).  Columns >= R are padding (zeros).
+struct DagAug {
+    int Pt;               // column tiles in total (P + extra); == P when there are none
+    int R, Rpad;          // valid / padded extra columns
+    const double* colx;   // (C, Rpad)
+};
+
+template <int C, bool AUG>
 __device__ __forceinline__ void dag_store_updated(const Tile& t, double* dest, size_t ldd, int k0, int j0,
                                                   const double* __restrict__ lw, const GpDev& g, double dsum,
                                                   const double* __restrict__ sigma, int N, double scale,
-                                                  const double* prev, int n_prev)
+                                                  const double* prev, int n_prev, int Npad, const DagAug& aug)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     double xj[4][C];
     int jj[4];
+    const bool cross = AUG && j0 >= Npad;   // wave-uniform: a tile of the appended columns
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         jj[n] = j0 + tile_col(wc, n, lane);
+        if (cross) {
+            // map to a column index that passes / fails the `j < N` test below and never equals a row index
+            const int e = jj[n] - Npad;
 #pragma unroll
-        for (int c = 0; c < C; ++c) xj[n][c] = (jj[n] < N) ? lw[(size_t)c * N + jj[n]] : 0.0;
+            for (int c = 0; c < C; ++c) xj[n][c] = (e < aug.R) ? aug.colx[(size_t)c * aug.Rpad + e] : 0.0;
+            jj[n] = (e < aug.R) ? -1 - e : 0x7fffffff;
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) xj[n][c] = (jj[n] < N) ? lw[(size_t)c * N + jj[n]] : 0.0;
+        }
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -215,10 +234,11 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* dest, s
                 } else {
                     v = (i == j) ? 1.0 : 0.0;
                 }
-                const size_t off = (size_t)(i - k0) * NB + (size_t)(j - j0);   // inside a 128 x 128 slot
+                const int jc = tile_col(wc, n, lane);                          // column inside the tile
+                const size_t off = (size_t)(i - k0) * NB + (size_t)jc;         // inside a 128 x 128 slot
                 double x = scale * v - t.acc[m][n][r];
                 for (int sidx = 0; sidx < n_prev; ++sidx) x += prev[(size_t)sidx * NB * NB + off];
-                dest[(size_t)(i - k0) * ldd + (size_t)(j - j0)] = x;
+                dest[(size_t)(i - k0) * ldd + (size_t)jc] = x;
             }
         }
     }
@@ -267,7 +287,7 @@ __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, in
     }
 }
 
-template <int C>
+template <int C, bool AUG = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, size_t mat_stride, int ld, int P,
                                                              const DagTask* __restrict__ tasks, DagQueues queues,
                                                              double* Wt, double* Rbase, int Npad, MatAcc* acc,
@@ -275,7 +295,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
                                                              DagCtl* ctl, unsigned long long* tlog,
                                                              const double* __restrict__ lwl,
                                                              const double* __restrict__ gp,
-                                                             const double* __restrict__ sigma, int N)
+                                                             const double* __restrict__ sigma, int N, DagAug aug)
 {
     __shared__ double vec1[NB];   // z_k (OFF)
     __shared__ double vec2[NB];   // column sums (OFF)
@@ -330,7 +350,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
         double* Wm = Wt + (size_t)b * NB * NB;
         MatFlags* f = flags + b;
         const int k0 = q * NB, j0 = j * NB;
-        const int ntasks_row = P - q;
+        const int ntasks_row = (AUG ? aug.Pt : P) - q;
 
         if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 0] = __builtin_amdgcn_s_memrealtime();
         t.zero();
@@ -354,8 +374,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
             }
             double* dest = is_part ? (wspace + (size_t)task.slot * SLOT) : (Km + (size_t)k0 * ld + j0);
             const double* prev = wspace + (size_t)(is_part ? task.slot - (unsigned int)n_prev : task.slot) * SLOT;
-            dag_store_updated<C>(t, dest, is_part ? (size_t)NB : (size_t)ld, k0, j0, lwl + (size_t)b * C * N, g, dsum,
-                                 sigma, N, is_part ? 0.0 : 1.0, prev, n_prev);
+            dag_store_updated<C, AUG>(t, dest, is_part ? (size_t)NB : (size_t)ld, k0, j0, lwl + (size_t)b * C * N, g,
+                                      dsum, sigma, N, is_part ? 0.0 : 1.0, prev, n_prev, Npad, aug);
         }
         if (is_part) {
             dag_drain();
@@ -466,13 +486,14 @@ inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first,
 // task list of ONE queue: the matrices in `mats`, served by about `workers` workgroups
 // `Bq_nominal` (the largest queue's matrix count) decides the split factors, so every matrix of the
 // batch gets the same task structure and identical proposals give identical bits in any batch slot
-inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, int workers, int Bq_nominal, int scheme)
+inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, int workers, int Bq_nominal, int scheme,
+                            int Mt = 0)
 {
     const int Bq = Bq_nominal;
     if (mats.empty()) return;
     std::vector<std::vector<DagTask>> early_final(P);   // DIAG finals whose PARTs were emitted a row early
     for (int q = 0; q < P; ++q) {
-        const int S_off = dag_split_factor(Bq * (P - q), q, workers);
+        const int S_off = dag_split_factor(Bq * (P + Mt - q), q, workers);
         // 1. DIAG finals of this row
         if (q <= 1) {
             for (int b : mats) dag_emit(plan, DAG_DIAG, b, q, q, 0, q, 1, scheme);
@@ -514,7 +535,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, 
         }
         // 3. off-diagonal tiles of this row
         for (int b : mats)
-            for (int j = q + 1; j < P; ++j) dag_emit(plan, DAG_OFF, b, q, j, 0, q, S_off, scheme);
+            for (int j = q + 1; j < P + Mt; ++j) dag_emit(plan, DAG_OFF, b, q, j, 0, q, S_off, scheme);
     }
 }
 
@@ -525,10 +546,10 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, 
 // from B = 24 (B = 32: 39.5 vs 40.3 ms).  (Readiness ordering was also tried for the throughput scheme:
 // 800 -> 776 evals/s, not adopted.)
 constexpr long long DAG_LATENCY_TILES = 20000;
-inline DagPlan dag_build_tasks(int B, int P, int workers, int scheme = -1)
+inline DagPlan dag_build_tasks(int B, int P, int workers, int scheme = -1, int Mt = 0)
 {
     DagPlan plan;
-    if (scheme < 0) scheme = ((long long)B * P * (P + 1) / 2 <= DAG_LATENCY_TILES) ? 1 : 0;
+    if (scheme < 0) scheme = ((long long)B * (P * (P + 1) / 2 + P * Mt) <= DAG_LATENCY_TILES) ? 1 : 0;
     // workgroups of XCDs whose own queue is empty steal, so the workers are shared by the queues in use
     const int used = B < DAG_QUEUES ? (B > 0 ? B : 1) : DAG_QUEUES;
     const int per_queue = workers / used > 0 ? workers / used : 1;
@@ -536,7 +557,7 @@ inline DagPlan dag_build_tasks(int B, int P, int workers, int scheme = -1)
         plan.queues.first[g] = (unsigned int)plan.tasks.size();
         std::vector<int> mats;
         for (int b = g; b < B; b += DAG_QUEUES) mats.push_back(b);
-        dag_build_queue(plan, mats, P, per_queue, (B + DAG_QUEUES - 1) / DAG_QUEUES, scheme);
+        dag_build_queue(plan, mats, P, per_queue, (B + DAG_QUEUES - 1) / DAG_QUEUES, scheme, Mt);
         if (scheme == 1) {
             // Latency scheme: hand the tasks out in order of READINESS instead of block row by block row.
             // A task over panels [pa, pb) can run once block row pb-1 is finished ("stage" pb); within a

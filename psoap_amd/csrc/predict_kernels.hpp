@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "chol_kernels.hpp"
+#include "dag_kernel.hpp"
 #include "fill_kernels.hpp"
 
 namespace psoap {
@@ -130,8 +131,18 @@ __global__ void k_zero(double* __restrict__ p, size_t n)
 
 inline hipError_t predict_configure_kernels()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_sub), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)GEMM_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_sub),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag<1, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag<2, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag<3, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+    return e;
 }
 
 #define PR_TRY(expr)                                                 \
@@ -202,8 +213,15 @@ inline int predict_run(int mode, int c, int N, int M, const double* lwl, const d
 
     double *dK = nullptr, *dW = nullptr, *dR = nullptr, *dLwl = nullptr, *dPred = nullptr, *dFl = nullptr,
            *dSig = nullptr, *dGp = nullptr, *dS = nullptr, *dMu = nullptr, *dM0 = nullptr, *dPart = nullptr,
-           *dOut = nullptr;
+           *dOut = nullptr, *dColx = nullptr, *dWs = nullptr;
     MatAcc* dAcc = nullptr;
+    unsigned char* dDag = nullptr;
+    DagTask* dTasks = nullptr;
+    // The factorisation of [B | Cx^T] runs as ONE launch of the persistent dependency-graph kernel with
+    // the appended columns as extra column tiles (k_chol_dag<C, true>: the cross-covariances are
+    // evaluated on the fly like B itself).  The transposed-mean variant (covariance.py:294) needs a
+    // block whose ROW abscissae are the prediction grid and keeps the staged three-kernel loop.
+    const bool use_dag = !transposed_mean && (P + Mt) <= 255;
     std::vector<double> m0(Rq);
     MatAcc hacc;
     GpHost gall;
@@ -228,6 +246,57 @@ inline int predict_run(int mode, int c, int N, int M, const double* lwl, const d
     PR_TRY(hipMemcpy(dSig, sigma, sizeof(double) * N, hipMemcpyHostToDevice));
     PR_TRY(hipMemcpy(dGp, gp, sizeof(double) * 2 * c, hipMemcpyHostToDevice));
 
+    if (use_dag) {
+        // prediction abscissae per component for the appended columns; a component that does not
+        // contribute to a column block (mode 0: C = vstack(V12_f, V12_g, ..), :136,:246) sits at 1e30
+        std::vector<double> colx((size_t)c * Rq_pad, 0.0);
+        for (int cc = 0; cc < c; ++cc)
+            for (int q = 0; q < Rq; ++q) {
+                const int blk = (mode == 0) ? q / M : cc;
+                colx[(size_t)cc * Rq_pad + q] = (mode == 0 && blk != cc) ? 1e30 : lwl_pred[(size_t)cc * M + (q % M)];
+            }
+        int dev = 0, blocks_per_cu = 0;
+        hipDeviceProp_t prop;
+        PR_TRY(hipGetDevice(&dev));
+        PR_TRY(hipGetDeviceProperties(&prop, dev));
+        PR_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_chol_dag<3, true>, GEMM_THREADS,
+                                                            GEMM_LDS_BYTES));
+        blocks_per_cu = blocks_per_cu < 1 ? 1 : (blocks_per_cu > 2 ? 2 : blocks_per_cu);
+        const int workers = blocks_per_cu * prop.multiProcessorCount;
+        DagPlan plan = dag_build_tasks(1, P, workers, -1, Mt);
+        const size_t arrive_off = sizeof(DagCtl) + sizeof(MatFlags);
+        const size_t dag_bytes = arrive_off + sizeof(int) * ((size_t)plan.n_ctrs + 4);
+        PR_TRY(hipMalloc(&dColx, sizeof(double) * colx.size()));
+        PR_TRY(hipMemcpy(dColx, colx.data(), sizeof(double) * colx.size(), hipMemcpyHostToDevice));
+        PR_TRY(hipMalloc(&dDag, dag_bytes));
+        PR_TRY(hipMemset(dDag, 0, dag_bytes));
+        PR_TRY(hipMalloc(&dTasks, sizeof(DagTask) * plan.tasks.size()));
+        PR_TRY(hipMemcpy(dTasks, plan.tasks.data(), sizeof(DagTask) * plan.tasks.size(), hipMemcpyHostToDevice));
+        PR_TRY(hipMalloc(&dWs, sizeof(double) * NB * NB * ((size_t)plan.n_slots + 1)));
+        PR_TRY(hipMemset(dW, 0, sizeof(double) * NB * NB));      // the strictly upper part of W stays zero
+        hipLaunchKernelGGL(k_init_rhs, dim3((Npad + 255) / 256, 1), dim3(256), 0, 0, dR, Npad, N, dFl, offset, dAcc);
+        const int grid = (int)(plan.tasks.size() < (size_t)workers ? plan.tasks.size() : (size_t)workers);
+        const DagAug aug{P + Mt, Rq, Rq_pad, dColx};
+        MatFlags* fl_ = reinterpret_cast<MatFlags*>(dDag + sizeof(DagCtl));
+        DagCtl* ctl_ = reinterpret_cast<DagCtl*>(dDag);
+#define PSOAP_LAUNCH_AUG(CC)                                                                                      \
+    hipLaunchKernelGGL((k_chol_dag<CC, true>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dK, (size_t)0,  \
+                       (int)ld, P, dTasks, plan.queues, dW, dR, Npad, dAcc, fl_,                                   \
+                       reinterpret_cast<int*>(dDag + arrive_off), dWs, ctl_, (unsigned long long*)nullptr, dLwl,   \
+                       dGp, dSig, N, aug)
+        if (c == 1) PSOAP_LAUNCH_AUG(1);
+        else if (c == 2) PSOAP_LAUNCH_AUG(2);
+        else PSOAP_LAUNCH_AUG(3);
+#undef PSOAP_LAUNCH_AUG
+        PR_TRY(hipGetLastError());
+        unsigned int dag_err = 0;
+        PR_TRY(hipMemcpy(&dag_err, dDag + offsetof(DagCtl, error), sizeof(dag_err), hipMemcpyDeviceToHost));
+        if (dag_err != 0) {
+            err = "predict: dependency wait timed out inside the persistent kernel";
+            rc = 1;
+            goto done;
+        }
+    } else {
     // [B | Cx^T]: zero the appended columns (padding rows/cols must be exact zeros), fill B's upper tiles
     hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, 0, dK, (size_t)Npad * ld);
     {
@@ -257,6 +326,7 @@ inline int predict_run(int mode, int c, int N, int M, const double* lwl, const d
 
     factor_augmented(dK, ld, P, Mt, dW, dR, Npad, dAcc);
     PR_TRY(hipGetLastError());
+    }
     PR_TRY(hipMemcpy(&hacc, dAcc, sizeof(MatAcc), hipMemcpyDeviceToHost));
     *status = (hacc.info != 0.0) ? 1 : 0;
 
@@ -301,6 +371,7 @@ inline int predict_run(int mode, int c, int N, int M, const double* lwl, const d
 done:
     (void)hipFree(dK); (void)hipFree(dW); (void)hipFree(dR); (void)hipFree(dAcc); (void)hipFree(dLwl); (void)hipFree(dPred); (void)hipFree(dFl);
     (void)hipFree(dSig); (void)hipFree(dGp); (void)hipFree(dS); (void)hipFree(dMu); (void)hipFree(dM0); (void)hipFree(dPart); (void)hipFree(dOut);
+    (void)hipFree(dColx); (void)hipFree(dWs); (void)hipFree(dDag); (void)hipFree(dTasks);
     return rc;
 }
 

@@ -548,7 +548,7 @@ static int eval_dag(psoap_chunk* h)
     hipLaunchKernelGGL(k_chol_dag<CC>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, h->dK, h->mat_stride,   \
                        h->ld, P, h->dTasks, h->plan_queues, h->dWt, h->dR, h->Npad, h->dAcc, fl_,                 \
                        reinterpret_cast<int*>(h->dDag + h->arrive_off), h->dWs, ctl_, h->dTlog, h->dLwl, h->dGp, \
-                       h->dSigma, N)
+                       h->dSigma, N, DagAug{P, 0, 0, nullptr})
         if (C == 1) PSOAP_LAUNCH_DAG(1);
         else if (C == 2) PSOAP_LAUNCH_DAG(2);
         else PSOAP_LAUNCH_DAG(3);
