@@ -160,7 +160,8 @@ __device__ __forceinline__ void dag_update(Tile& t, double* Km, int ld, int k0, 
 
 // The ONE consumer of the accumulators.  Every task ends its update here:
 //     dest(i, j) <- scale * K(i, j) - acc(i, j) + sum_s prev_s(i, j)
-//   final tasks : dest = the tile (k0, j0) of the matrix, scale = 1, prev = the n_prev partial tiles
+//   final tasks : dest = the tile (k0, j0) of the matrix, scale = 1 (0 in a chain, whose first PART
+//                 carries K instead), prev = the n_prev partial tiles
 //                 left by the tile's PART tasks (all S-1 of them, or the running sum of a chain);
 //   PART tasks  : dest = a workspace slot (row-major 128 x 128), scale = 0, prev = the slot of the
 //                 previous PART of a chain (n_prev = 1) or nothing.
@@ -218,7 +219,7 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* dest, s
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             double kv[4] = {0.0, 0.0, 0.0, 0.0};
-            if (scale != 0.0) kern_elem4_skip<C>(xi, xj[n], g, kv);   // wave-uniform: PART tasks never need K
+            if (scale != 0.0) kern_elem4_skip<C>(xi, xj[n], g, kv);   // wave-uniform: only one task per tile adds K
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = ii[r], j = jj[n];
@@ -374,8 +375,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
             }
             double* dest = is_part ? (wspace + (size_t)task.slot * SLOT) : (Km + (size_t)k0 * ld + j0);
             const double* prev = wspace + (size_t)(is_part ? task.slot - (unsigned int)n_prev : task.slot) * SLOT;
+            // who adds K(i, j): the final task -- except in a chain, where the FIRST PART carries it, so
+            // that the exp() evaluations are off the critical row-to-row path (the final of a chain runs
+            // right after the block row above completes; its PARTs ran ahead)
+            const bool carries_k = chain ? (is_part ? task.S == 0 : task.S <= 1) : !is_part;
             dag_store_updated<C, AUG>(t, dest, is_part ? (size_t)NB : (size_t)ld, k0, j0, lwl + (size_t)b * C * N, g,
-                                      dsum, sigma, N, is_part ? 0.0 : 1.0, prev, n_prev, Npad, aug);
+                                      dsum, sigma, N, carries_k ? 1.0 : 0.0, prev, n_prev, Npad, aug);
         }
         if (is_part) {
             dag_drain();
