@@ -200,7 +200,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trsm_strip(double* __restri
     if (tid < NB) zk[tid] = Rv[k0 + tid];
     Tile t;
     t.zero();
-    tile_gemm_tn(t, Wt + (size_t)bidx * NB * NB, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld, NB);
+    tile_gemm_tn_lower(t, Wt + (size_t)bidx * NB * NB, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld);
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     double part[4] = {0.0, 0.0, 0.0, 0.0};

@@ -252,7 +252,7 @@ __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, in
     const int tid = threadIdx.x;
     if (tid < NB) zk[tid] = Rv[k0 + tid];
     t.zero();
-    tile_gemm_tn(t, Wm, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld, NB, false, NB / 2);
+    tile_gemm_tn_lower(t, Wm, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld);
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     double part[4] = {0.0, 0.0, 0.0, 0.0};

@@ -69,7 +69,9 @@ __device__ __forceinline__ void stage_store(const Staging& s, int buf, int tid)
     }
 }
 
-__device__ __forceinline__ void tile_mma_chunk(Tile& t, int buf, int wr, int wc, int lane)
+// m_first > 0 (wave-uniform): the wave's first m_first 16-row blocks issue no MFMA in this chunk
+template <bool PARTIAL_M = false>
+__device__ __forceinline__ void tile_mma_chunk(Tile& t, int buf, int wr, int wc, int lane, int m_first = 0)
 {
     const int fr = lane & 15, fk = lane >> 4;
     const int baseA = buf * LDS_BUFFER + fk * LDS_LD + wr * 64 + fr;
@@ -82,10 +84,12 @@ __device__ __forceinline__ void tile_mma_chunk(Tile& t, int buf, int wr, int wc,
 #pragma unroll
         for (int n = 0; n < 4; ++n) b[n] = psoap_smem[baseB + ks * 4 * LDS_LD + n * 16];
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m) {
+            if (PARTIAL_M && m < m_first) continue;
 #pragma unroll
             for (int n = 0; n < 4; ++n)
                 t.acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], t.acc[m][n], 0, 0, 0);
+        }
     }
 }
 
@@ -155,6 +159,28 @@ __device__ __forceinline__ void tile_gemm_tn(Tile& t, const double* __restrict__
         if (c + 1 < nchunk) stage_glds(A, lda, B, ldb, (c + 1) * KB, cur ^ 1, tid);
         const bool idle = (skip_lower_left && wr == 1 && wc == 0) || (wr == 0 && c * KB >= k_limit_upper);
         if (!idle) tile_mma_chunk(t, cur, wr, wc, lane);
+        __syncthreads();
+    }
+}
+
+// X = W T for a LOWER-TRIANGULAR left factor given k-major (A[k][i] = W[i][k], zero for k > i) and
+// K = 128: the strip solve with the explicit inverse W = U11^-T.  Row block mb (16 rows) only involves
+// k < 16 (mb + 1), so chunk c (16 k-rows) skips the MFMAs of every row block above the diagonal:
+// 36 of the 64 (chunk, row block) pairs remain (a plain K = 128 product issues all 64).
+__device__ __forceinline__ void tile_gemm_tn_lower(Tile& t, const double* __restrict__ A, size_t lda,
+                                                   const double* __restrict__ B, size_t ldb)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    stage_glds(A, lda, B, ldb, 0, 0, tid);
+    __syncthreads();
+    constexpr int nchunk = NB / KB;
+    for (int c = 0; c < nchunk; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nchunk) stage_glds(A, lda, B, ldb, (c + 1) * KB, cur ^ 1, tid);
+        const int m_first = c - 4 * wr;          // row blocks mb = 4 wr + m < c lie above the diagonal
+        if (m_first < 4) tile_mma_chunk<true>(t, cur, wr, wc, lane, m_first);
         __syncthreads();
     }
 }
