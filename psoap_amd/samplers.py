@@ -85,7 +85,10 @@ class MHSampler:
             return self._random.normal(loc=p[0], scale=np.ravel(self.cov)[0], size=(1,))
         return self._random.multivariate_normal(p, self.cov)
 
-    def sample(self, p0, lnprob0=None, randomstate=None, thin=1, storechain=True, iterations=1):
+    def sample(self, p0, lnprob0=None, randomstate=None, thin=1, storechain=True, iterations=1, incremental_save=0,
+               backup="chain_backup.npy"):
+        """``incremental_save = k > 0`` writes the chain so far to ``backup`` every k iterations
+        (``StateSampler.sample``, samplers.py:153-156)."""
         self.random_state = randomstate
         p = np.array(p0, dtype=np.float64)
         lnprob = self.get_lnprob(p) if lnprob0 is None else lnprob0
@@ -113,6 +116,8 @@ class MHSampler:
                 ind = i0 + int(i / thin)
                 self._chain[ind, :] = p
                 self._lnprob[ind] = lnprob
+            if incremental_save and (i + 1) % incremental_save == 0 and i > 0:
+                np.save(backup, self._chain)
             yield p, lnprob, self.random_state
 
     def run_mcmc(self, pos0, N, rstate0=None, lnprob0=None, **kwargs):
@@ -173,8 +178,11 @@ class MultiChainMHSampler:
             raise ValueError(f"lnprob_batch returned shape {out.shape}, expected ({self.n_chains},)")
         return out
 
-    def sample(self, p0, lnprob0=None, thin=1, storechain=True, iterations=1):
-        """``p0``: (dim,) -- every chain starts there, as B reference runs would -- or (B, dim)."""
+    def sample(self, p0, lnprob0=None, thin=1, storechain=True, iterations=1, incremental_save=0,
+               backup="chain_backup.npy"):
+        """``p0``: (dim,) -- every chain starts there, as B reference runs would -- or (B, dim).
+        ``incremental_save = k > 0`` writes the (B, iterations, dim) chain so far to ``backup`` every k
+        iterations (samplers.py:153-156)."""
         p = np.array(np.broadcast_to(np.asarray(p0, dtype=np.float64), (self.n_chains, self.dim)))
         lnprob = self._eval(p) if lnprob0 is None else np.array(np.broadcast_to(lnprob0, (self.n_chains,)), dtype=np.float64)
         if storechain:
@@ -203,6 +211,8 @@ class MultiChainMHSampler:
                 ind = i0 + int(i / thin)
                 self._chain[:, ind, :] = p
                 self._lnprob[:, ind] = lnprob
+            if incremental_save and (i + 1) % incremental_save == 0 and i > 0:
+                np.save(backup, self._chain)
             yield p.copy(), lnprob.copy()
 
     def run_mcmc(self, p0, N, lnprob0=None, **kwargs):

@@ -53,6 +53,17 @@ def test_mh_sampler_callbacks_and_inf():
     assert s2.naccepted == 0 and np.array_equal(s2.chain, np.zeros((10, 2)))
 
 
+def test_incremental_save(tmp_path):
+    s = samplers.MHSampler(np.eye(2), 2, lambda p: -0.5 * float(p @ p))
+    bk = str(tmp_path / "chain_backup.npy")
+    list(s.sample(np.zeros(2), iterations=25, incremental_save=10, backup=bk))
+    saved = np.load(bk)
+    assert saved.shape == (25, 2) and np.array_equal(saved[:20], s.chain[:20])     # last write at iteration 20
+    m = samplers.MultiChainMHSampler(np.eye(2), 2, lambda P: -0.5 * np.sum(P * P, axis=1), 3, seeds=[1, 2, 3])
+    list(m.sample(np.zeros(2), iterations=12, incremental_save=5, backup=bk))
+    assert np.load(bk).shape == (3, 12, 2)
+
+
 def test_mh_statistics_gaussian_target():
     cov_t = np.array([[1.0, -0.4], [-0.4, 0.5]])
     s = samplers.MHSampler(1.2 * cov_t, 2, _gauss(np.linalg.inv(cov_t)))
