@@ -145,6 +145,19 @@ def predict_f_g_h_sum(lwl_f, lwl_g, lwl_h, fl_fgh, sigma_fgh, lwl_f_predict, lwl
                     [mu_fgh], [amp_f, l_f, amp_g, l_g, amp_h, l_h])
 
 
+def optimize_GP_f(wl_known, fl_known, sigma_known, amp_f, l_f, mu_GP=1.0):
+    """Nelder-Mead fit of the single-component hyper-parameters to one slice of data, starting from
+    ``(amp_f, l_f)`` (covariance.py:405-422); every likelihood evaluation runs on the device."""
+    from scipy.optimize import minimize
+    V11 = None          # the reference passes an N x N scratch matrix; the device path ignores it
+
+    def func(x):
+        a, l = x
+        return -lnlike_f(V11, wl_known, fl_known, sigma_known, a, l, mu_GP)
+
+    return minimize(func, np.array([amp_f, l_f]), method="Nelder-Mead")["x"]
+
+
 # ---- calibration (SURVEY.md 8(f) f-4) ---------------------------------------------------------------
 _CAL_FAIL = {1: "reference-epoch covariance B", 2: "conditional covariance C'", 3: "Chebyshev normal equations"}
 

@@ -9,8 +9,8 @@ image, so the algorithm is restated here from the reference's own copy of the lo
 the uniform deviate is drawn only when ``dlnp < 0``.  Parity with emcee itself is unpinned; parity with
 a plain restatement of samplers.py is tested (tests/test_samplers.py, oracle/sampler_oracle.py).
 
-One proposal per iteration cannot fill a GPU (a single N = 6000 evaluation takes 14 ms, 32 batched take
-40 ms), and the reference's own workflow already runs several independent chains side by side
+One proposal per iteration cannot fill a GPU (a single N = 6000 evaluation takes 7 ms, 32 batched take
+39 ms), and the reference's own workflow already runs several independent chains side by side
 (``run_index`` directories, /root/reference/scripts/psoap_gelman_rubin.py).  ``MultiChainMHSampler``
 advances B such chains in lock-step: every iteration draws one proposal per chain and evaluates all B
 with ONE ``lnprob_batch`` call.  Each chain owns its random stream, so chain b is bit-identical to a

@@ -96,3 +96,15 @@ def test_cycle_calibration_pulls_epochs_together():
     ch.lwl = None
     cov.cycle_calibration_chunk(ch, 0.1, 10.0, 2, order=1, limit_array=3)
     assert np.std(ch.fl / truth, axis=0).mean() < 0.25 * spread_before
+
+
+def test_optimize_GP_f_matches_oracle_driven_fit(oracle):
+    """Same Nelder-Mead driver (covariance.py:405-422) on the device likelihood and on the oracle likelihood."""
+    from scipy.optimize import minimize
+    from psoap_amd import covariance as cov
+    ch = syn.make_chunk(1, 3, 80, seed=321)               # N = 240
+    got = cov.optimize_GP_f(ch.lwls[0], ch.fl, ch.sigma, 0.3, 8.0)
+    want = minimize(lambda x: -oracle.lnlike(ch.lwls, ch.fl, ch.sigma, [x[0], x[1]]), np.array([0.3, 8.0]),
+                    method="Nelder-Mead")["x"]
+    assert np.allclose(got, want, rtol=1e-5)
+    assert cov.lnlike_f(None, ch.lwls[0], ch.fl, ch.sigma, *got) >= cov.lnlike_f(None, ch.lwls[0], ch.fl, ch.sigma, 0.3, 8.0)
