@@ -114,14 +114,17 @@ __device__ __forceinline__ void chol16(d4& t, d4& w, int lane, int& bad)
             const double inv = rsqrt_chain(d);
             const double pA = la * inv, pE = le * inv;
             const double ujj = d * inv;       // U_jj = sqrt(d)
+            // rows below the pivot row are eliminated; rows above it get the multiplier 0 and stay as they
+            // are (no selects on the results); the pivot row itself is one register in the lanes q == rq
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = q + 4 * r;
-                const double m = lm[r] * inv;   // U[jj][i]
-                const double tn = fma(-m, pA, t[r]), en = fma(-m, pE, e[r]);
-                const double tp = (c == jj) ? ujj : pA;
-                t[r] = (i > jj) ? tn : ((i == jj) ? tp : t[r]);
-                e[r] = (i > jj) ? en : ((i == jj) ? pE : e[r]);
+                const double m = (q + 4 * r > jj) ? lm[r] * inv : 0.0;   // U[jj][i], i = q + 4r
+                t[r] = fma(-m, pA, t[r]);
+                e[r] = fma(-m, pE, e[r]);
+            }
+            if (q == rq) {
+                t[rr] = (c == jj) ? ujj : pA;
+                e[rr] = pE;
             }
             __builtin_amdgcn_wave_barrier();
         }
