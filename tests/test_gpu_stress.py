@@ -88,3 +88,18 @@ def test_both_split_schemes_agree_with_oracle(oracle, monkeypatch):
             assert close(got["0"][w], got["1"][w]), (ch.N, w)
         want = oracle.lnlike(lw[B - 1], ch.fl, ch.sigma, gps[B - 1])
         assert close(got["0"][B - 1], want) and close(got["1"][B - 1], want), (ch.N, got, want)
+
+
+def test_large_matrix_against_oracle(oracle):
+    """N = 12288 (96 block rows, 1.2 GB per matrix): beyond every BASELINE shape, single and paired."""
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_chunk(2, 32, 384, seed=4242)
+    assert ch.N == 12288
+    gps = syn.make_walkers(2, 2, seed=4243)
+    lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, 2, seed=4244))
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=2) as h:
+        both = h.lnlike_batch(lw, gps)
+        one = h.lnlike_batch(lw[:1], gps[:1])
+    want = oracle.lnlike(lw[0], ch.fl, ch.sigma, gps[0])
+    assert close(both[0], want) and close(one[0], want), (both, one, want)
+    assert np.isfinite(both[1])
