@@ -168,7 +168,10 @@ int psoap_chunk_get_timings(psoap_chunk *h, psoap_timings *t);
 /* Number of concurrent stream groups a batch is split into (staged mode; default 2). */
 int psoap_chunk_set_stream_groups(psoap_chunk *h, int groups);
 /* Execution mode of psoap_batch_eval: 1 (default) = one persistent dependency-graph kernel
- * for the whole batched factorisation; 0 = staged, three kernels per 128-row panel. */
+ * for the whole batched factorisation; 0 = staged, three kernels per 128-row panel.
+ * Inside mode 1 the tile updates are cut by one of two schemes chosen from the batch size (latency
+ * for small batches, throughput for large ones); the environment variable
+ * PSOAP_DAG_SCHEME=0|1, read when a task list is built, pins one for experiments. */
 int psoap_chunk_set_mode(psoap_chunk *h, int mode);
 
 /* Debug aid for the persistent kernel: the first call allocates a per-task timestamp log, later
