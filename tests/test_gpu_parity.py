@@ -314,3 +314,37 @@ def test_batched_exp_is_bit_identical_to_library_exp():
     _lib.check(_lib.load().psoap_microbench_exp_check(_lib.default_device(), len(x), _lib.dptr(x), ctypes.byref(bad)),
                "psoap_microbench_exp_check")
     assert bad.value == 0
+
+
+@pytest.mark.parametrize("c,ne,npx,M,seed", [
+    (1, 2, 37, 1, 51),        # N = 74 (below one tile), a single prediction point
+    (2, 3, 43, 5, 52),        # N = 129 (one past a tile edge), M far below a tile
+    (2, 5, 60, 130, 53),      # M one past a tile edge
+    (3, 4, 70, 129, 54),      # c M = 387 prediction columns: four column tiles, ragged last one
+    (3, 9, 100, 16, 55),      # N = 900 (ragged), masked epochs
+])
+def test_predict_edge_shapes_vs_oracle(oracle, cov, c, ne, npx, M, seed):
+    """The predict family factors [B | Cx^T] inside the persistent kernel with the prediction columns as
+    extra column tiles; shapes that leave those tiles ragged, for the joint and the summed conditionals."""
+    ch = syn.make_chunk(c, ne, npx, seed=seed, masked_fraction=0.1 if npx >= 60 else 0.0)
+    lo, hi = ch.lwls[0].min(), ch.lwls[0].max()
+    pred = [np.linspace(lo, hi, M) + k * 1e-6 for k in range(c)] if M > 1 else [np.array([0.5 * (lo + hi)])] * c
+    gp = syn.GP_BASE[c]
+    mus = [0.1 * k for k in range(c)]
+    if c == 1:
+        mu, Sig = cov.predict_f(ch.lwls[0], ch.fl, ch.sigma, pred[0], *gp, mu_GP=1.0)
+        mu_o, Sig_o = oracle.predict_components(ch.lwls, ch.fl, ch.sigma, pred, [1.0], gp)
+    elif c == 2:
+        mu, Sig = cov.predict_f_g(ch.lwls[0], ch.lwls[1], ch.fl, ch.sigma, pred[0], pred[1], mus[0], gp[0], gp[1],
+                                  mus[1], gp[2], gp[3])
+        mu_o, Sig_o = oracle.predict_components(ch.lwls, ch.fl, ch.sigma, pred, mus, gp)
+        mu_s, Sig_s = cov.predict_f_g_sum(ch.lwls[0], ch.lwls[1], ch.fl, ch.sigma, pred[0], pred[1], 0.9, *gp)
+        mu_so, Sig_so = oracle.predict_sum(ch.lwls, ch.fl, ch.sigma, pred, 0.9, gp)
+        np.testing.assert_allclose(mu_s, mu_so, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(Sig_s, Sig_so, rtol=0, atol=1e-9)
+    else:
+        mu, Sig = cov.predict_f_g_h(*ch.lwls, ch.fl, ch.sigma, *pred, *mus, *gp)
+        mu_o, Sig_o = oracle.predict_components(ch.lwls, ch.fl, ch.sigma, pred, mus, gp)
+    assert mu.shape == (c * M,) and Sig.shape == (c * M, c * M)
+    np.testing.assert_allclose(mu, mu_o, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(Sig, Sig_o, rtol=0, atol=1e-9)
