@@ -108,3 +108,29 @@ def test_optimize_GP_f_matches_oracle_driven_fit(oracle):
                     method="Nelder-Mead")["x"]
     assert np.allclose(got, want, rtol=1e-5)
     assert cov.lnlike_f(None, ch.lwls[0], ch.fl, ch.sigma, *got) >= cov.lnlike_f(None, ch.lwls[0], ch.fl, ch.sigma, 0.3, 8.0)
+
+
+@pytest.mark.parametrize("c,ne,npx,order,limit,seed", [
+    (1, 2, 9, 0, 1, 971),        # M = 9, N = 9: everything below one tile, constant correction
+    (2, 3, 129, 5, 2, 972),      # M = 129 (one past a tile edge), order 5
+    (3, 5, 200, 2, 4, 973),      # N = 800, three components
+])
+def test_calibration_edge_shapes_vs_oracle(oracle, c, ne, npx, order, limit, seed):
+    from psoap_amd import covariance as cov
+    from make_golden_host import cal_case
+    from test_calibration_oracle import close
+    case = cal_case(syn, c, ne, npx, seed, 0.0, 1.04, limit_array=limit)
+    A, B, C = oracle.calibration_blocks(case["lwls_cal"], case["sigma_cal"], case["lwls_fixed"], case["sigma_fixed"],
+                                        case["gp"])
+    want_fl, want_X = oracle.optimize_calibration(case["lwl0"], case["lwl1"], case["lwl_cal"], case["fl_cal"],
+                                                  case["fl_fixed"], A, B, C, order=order)
+    fl_cor, X = cov.optimize_calibration_components(case["lwl0"], case["lwl1"], case["lwl_cal"], case["lwls_cal"],
+                                                    case["fl_cal"], case["sigma_cal"], case["lwls_fixed"],
+                                                    case["fl_fixed"], case["sigma_fixed"], case["gp"], order=order)
+    assert X.shape == (order + 1,)
+    # high Chebyshev orders make the normal equations ill-conditioned: compare the corrected flux tightly,
+    # the coefficients relative to the largest one
+    assert close(fl_cor, want_fl, 1e-8) and close(X, want_X, 1e-6 if order >= 5 else 1e-8), (X, want_X)
+    fl2, X2 = cov.optimize_calibration(case["lwl0"], case["lwl1"], case["lwl_cal"], case["fl_cal"], case["fl_fixed"],
+                                       A, B, C, order=order)
+    assert close(fl2, want_fl, 1e-8)
