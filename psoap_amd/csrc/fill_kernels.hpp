@@ -182,27 +182,58 @@ __global__ __launch_bounds__(256) void k_fill_sym(double* __restrict__ Kbase, si
     __syncthreads();
 
     double* Km = Kbase + (size_t)b * mat_stride;
-#pragma unroll 4
-    for (int it = 0; it < NB / 4; ++it) {
-        const int r = w + 4 * it;
-        const int i = i0 + r;
-        double xi[C];
+    // Four rows x two columns per step: the eight exponentials of a component go through one batched,
+    // underflow-skipping evaluation.  (With two exp() per element the kernel is close to the fp64 VALU
+    // rate, not only the HBM write rate: 1.1e12 exp/s at N = 6000, c = 2.)
+#pragma unroll 1
+    for (int g4 = 0; g4 < NB / 16; ++g4) {
+        double va[4], vb[4];
 #pragma unroll
-        for (int c = 0; c < C; ++c) xi[c] = xrow[c][r];
-        d2 v;
-        if (i < N) {
-            double va = (ja < N) ? kern_elem<C>(xi, xa, g) : 0.0;
-            double vb = (jb < N) ? kern_elem<C>(xi, xb, g) : 0.0;
-            // diagonal rule (pyx:56-57,144,201) + noise (covariance.py:322)
-            if (ja == i) va = dsum + srow[r];
-            if (jb == i) vb = dsum + srow[r];
-            v.x = va;
-            v.y = vb;
-        } else {
-            v.x = (ja == i) ? 1.0 : 0.0;
-            v.y = (jb == i) ? 1.0 : 0.0;
+        for (int c = 0; c < C; ++c) {
+#pragma clang fp contract(off)
+            double a[8], e[8];
+            bool live = false;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const double xi = xrow[c][w + 4 * (4 * g4 + s4)];
+                const double da = xa[c] - xi, db = xb[c] - xi;
+                a[2 * s4] = g.p2[c] * da * da;
+                a[2 * s4 + 1] = g.p2[c] * db * db;
+                live = live || !(a[2 * s4] <= -746.0) || !(a[2 * s4 + 1] <= -746.0);
+            }
+            if (__builtin_amdgcn_ballot_w64(live) != 0ull) {
+                exp_nonpos_batch<8>(a, e);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e[k] = g.a2[c] * e[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e[k] = 0.0;
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                va[s4] = (c == 0) ? e[2 * s4] : va[s4] + e[2 * s4];
+                vb[s4] = (c == 0) ? e[2 * s4 + 1] : vb[s4] + e[2 * s4 + 1];
+            }
         }
-        *reinterpret_cast<d2*>(Km + (size_t)i * ld + ja) = v;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int r = w + 4 * (4 * g4 + s4);
+            const int i = i0 + r;
+            d2 v;
+            if (i < N) {
+                double x = (ja < N) ? va[s4] : 0.0;
+                double y = (jb < N) ? vb[s4] : 0.0;
+                // diagonal rule (pyx:56-57,144,201) + noise (covariance.py:322)
+                if (ja == i) x = dsum + srow[r];
+                if (jb == i) y = dsum + srow[r];
+                v.x = x;
+                v.y = y;
+            } else {
+                v.x = (ja == i) ? 1.0 : 0.0;
+                v.y = (jb == i) ? 1.0 : 0.0;
+            }
+            *reinterpret_cast<d2*>(Km + (size_t)i * ld + ja) = v;
+        }
     }
 }
 
