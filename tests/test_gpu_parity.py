@@ -348,3 +348,17 @@ def test_predict_edge_shapes_vs_oracle(oracle, cov, c, ne, npx, M, seed):
     assert mu.shape == (c * M,) and Sig.shape == (c * M, c * M)
     np.testing.assert_allclose(mu, mu_o, rtol=0, atol=1e-10)
     np.testing.assert_allclose(Sig, Sig_o, rtol=0, atol=1e-9)
+
+
+def test_non_finite_data_conventions(cov):
+    """NaN in the flux vector: the reference raises ValueError from cho_solve's check_finite
+    (covariance.py:331,354,376); the device path returns NaN, which every sampler rejects.  NaN in the
+    uncertainties poisons the diagonal -> not positive definite -> -inf."""
+    ch = syn.make_chunk(2, 3, 50, seed=77)
+    fl = ch.fl.copy()
+    fl[17] = np.nan
+    assert np.isnan(cov.lnlike_f_g(None, ch.lwls[0], ch.lwls[1], fl, ch.sigma, *syn.GP_BASE[2]))
+    sg = ch.sigma.copy()
+    sg[5] = np.nan
+    assert cov.lnlike_f_g(None, ch.lwls[0], ch.lwls[1], ch.fl, sg, *syn.GP_BASE[2]) == -np.inf
+    cov.release_handles()
