@@ -374,7 +374,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
                 for (int c = 1; c < C; ++c) dsum = dsum + g.a2[c];
             }
             double* dest = is_part ? (wspace + (size_t)task.slot * SLOT) : (Km + (size_t)k0 * ld + j0);
-            const double* prev = wspace + (size_t)(is_part ? task.slot - (unsigned int)n_prev : task.slot) * SLOT;
+            // chained PART: the predecessor's tile sits in the other slot of the even/odd pair
+            const double* prev = wspace + (size_t)(is_part ? task.slot ^ 1u : task.slot) * SLOT;
             // who adds K(i, j): the final task -- except in a chain, where the FIRST PART carries it, so
             // that the exp() evaluations are off the critical row-to-row path (the final of a chain runs
             // right after the block row above completes; its PARTs ran ahead)
@@ -450,14 +451,15 @@ inline int dag_split_factor(int tasks_in_row, int q, int workers)
 //     are CHAINED: PART s adds the tile PART s-1 left in the previous slot to its own, so every task
 //     reads one partial tile.  Right when a queue holds one matrix and the row-to-row chain is the
 //     critical path.
-// Encoding: PART.S = index in the chain (0 when gathered), PART.slot = its output (consecutive);
-// final.S = number of pieces, final.slot = first slot to read (gather: the first PART's, chain: the
-// last PART's).  nsplit == 1: one final over the whole range.
+// Encoding: PART.S = index in the chain (0 when gathered), PART.slot = its output (gathered:
+// consecutive slots; chained: an even/odd pair used alternately); final.S = number of pieces,
+// final.slot = first slot to read (gather: the first PART's, chain: the last PART's).  nsplit == 1: one final over the whole range.
 inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first, int pb_last, int nsplit, int scheme)
 {
     const bool chain = (scheme == 1) && nsplit > 1;
     const int nparts = chain ? nsplit : nsplit - 1;                 // PART tasks
     const unsigned int ctr = (nparts > 0) ? plan.n_ctrs++ : 0u;
+    if (chain) plan.n_slots += plan.n_slots & 1u;                   // a chain ping-pongs between an even/odd slot pair
     const unsigned int slot0 = plan.n_slots;
     const int pb_parts = chain ? pb_last - 1 : pb_last;
     const int span = pb_parts - pa_first;
@@ -471,10 +473,13 @@ inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first,
         t.S = (unsigned char)(chain ? sidx : 0);
         t.pa = (unsigned char)(pa_first + (long long)span * sidx / nsplit);
         t.pb = (unsigned char)(pa_first + (long long)span * (sidx + 1) / nsplit);
-        t.slot = plan.n_slots++;
+        // gathered: one slot per PART; chained: PART s reads slot0 + ((s - 1) & 1) and writes slot0 + (s & 1)
+        // (its predecessor's reader -- itself -- is the only one, so two slots per tile are enough)
+        t.slot = chain ? slot0 + (unsigned int)(sidx & 1) : plan.n_slots++;
         t.ctr = ctr;
         plan.tasks.push_back(t);
     }
+    if (chain) plan.n_slots = slot0 + 2;
     DagTask t{};
     t.type = (unsigned char)type | flag;
     t.b = (unsigned short)b;
@@ -483,7 +488,7 @@ inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first,
     t.S = (unsigned char)(nparts + 1);
     t.pa = (unsigned char)(chain ? pb_last - 1 : pa_first + (long long)span * (nsplit - 1) / nsplit);
     t.pb = (unsigned char)pb_last;
-    t.slot = (nparts > 0) ? (chain ? plan.n_slots - 1 : slot0) : 0u;
+    t.slot = (nparts > 0) ? (chain ? slot0 + (unsigned int)((nparts - 1) & 1) : slot0) : 0u;
     t.ctr = ctr;
     plan.tasks.push_back(t);
 }
@@ -510,8 +515,9 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, 
             const int S_pre = dag_split_factor(Bq, q, workers / 4 > 0 ? workers / 4 : 1);
             for (int b : mats) {
                 const unsigned int ctr = plan.n_ctrs++;
-                const unsigned int slot0 = plan.n_slots;
                 const bool chain = (scheme == 1);
+                if (chain) plan.n_slots += plan.n_slots & 1u;
+                const unsigned int slot0 = plan.n_slots;
                 const unsigned char flag = chain ? DAG_CHAIN : 0;
                 for (int sidx = 0; sidx < S_pre; ++sidx) {
                     DagTask t{};
@@ -522,10 +528,11 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, 
                     t.S = (unsigned char)(chain ? sidx : 0);
                     t.pa = (unsigned char)((long long)q * sidx / S_pre);
                     t.pb = (unsigned char)((long long)q * (sidx + 1) / S_pre);
-                    t.slot = plan.n_slots++;
+                    t.slot = chain ? slot0 + (unsigned int)(sidx & 1) : plan.n_slots++;
                     t.ctr = ctr;
                     plan.tasks.push_back(t);
                 }
+                if (chain) plan.n_slots = slot0 + (S_pre > 1 ? 2 : 1);
                 DagTask fin{};
                 fin.type = DAG_DIAG | flag;
                 fin.b = (unsigned short)b;
@@ -533,7 +540,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, 
                 fin.S = (unsigned char)(S_pre + 1);
                 fin.pa = (unsigned char)q;
                 fin.pb = (unsigned char)(q + 1);
-                fin.slot = chain ? plan.n_slots - 1 : slot0;
+                fin.slot = chain ? slot0 + (unsigned int)((S_pre - 1) & 1) : slot0;
                 fin.ctr = ctr;
                 early_final[q + 1].push_back(fin);
             }

@@ -43,6 +43,7 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
     covered = {}           # (b, q, j) -> list of (pa, pb)
     part_done_ticket = {}  # ctr -> list of tickets of its PARTs
     slots_seen = set()
+    pair_owner = {}        # chained partial sums: slot pair -> arrival counter of the chain
     diag_final_ticket = {}
     row_final_last_ticket = {}   # (b, q) -> max ticket of the row's finals
     for t, k in enumerate(tasks):
@@ -52,7 +53,13 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
         covered.setdefault(key, []).append((int(k["pa"]), int(k["pb"])))
         if k["type"] == PART:
             assert k["slot"] < n_slots and k["ctr"] < n_ctrs
-            assert int(k["slot"]) not in slots_seen
+            if chain[t]:
+                # a chain ping-pongs between the two slots of an even/odd pair that no other chain uses
+                pair = int(k["slot"]) >> 1
+                assert pair_owner.setdefault(pair, int(k["ctr"])) == int(k["ctr"])
+                assert int(k["slot"]) & 1 == int(k["S"]) & 1
+            else:
+                assert int(k["slot"]) not in slots_seen and (int(k["slot"]) >> 1) not in pair_owner
             slots_seen.add(int(k["slot"]))
             part_done_ticket.setdefault(int(k["ctr"]), []).append(t)
         else:
@@ -65,7 +72,7 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
             row_final_last_ticket[rk] = max(row_final_last_ticket.get(rk, -1), t)
     # every upper tile of every matrix has exactly one final
     assert len(finals) == B * P * (P + 1) // 2
-    assert len(slots_seen) == n_slots
+    assert all(sl < n_slots for sl in slots_seen)
     for key, ranges in covered.items():
         b, q, j = key
         ranges.sort()
@@ -87,7 +94,6 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
                 assert len(parts) == k["S"] - 1 and max(parts) < t
                 assert parts == sorted(parts)
                 got = [int(tasks[p]["slot"]) for p in parts]
-                assert got == list(range(got[0], got[0] + len(parts)))        # consecutive slots
                 for p in parts:
                     assert (int(tasks[p]["b"]), int(tasks[p]["q"]), int(tasks[p]["j"])) == (b, q, j)
                     assert chain[p] == chain[t]
@@ -96,11 +102,13 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
                     # the final reads the last PART's slot and covers only the last panel -- the one
                     # that depends on the block row above
                     assert [int(tasks[p]["S"]) for p in parts] == list(range(len(parts)))
+                    assert got == [(got[0] & ~1) + (i & 1) for i in range(len(parts))]     # even/odd ping-pong
                     assert int(k["slot"]) == got[-1]
                     assert int(k["pb"]) - int(k["pa"]) == 1
                 else:
                     # gathered: PARTs wait for nothing, the final reads all of them from the first slot
                     assert all(int(tasks[p]["S"]) == 0 for p in parts)
+                    assert got == list(range(got[0], got[0] + len(parts)))                 # consecutive slots
                     assert int(k["slot"]) == got[0]
             if k["type"] == OFF:
                 assert diag_final_ticket[(b, q)] < t
