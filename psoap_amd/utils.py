@@ -52,3 +52,12 @@ def convert_dict(model, fix_params, **kwargs):
     """Fitted-parameter vector from a ``{name: value}`` dictionary such as config.yaml's ``parameters`` or
     ``jumps`` (utils.py:71-84): the registered parameters that are not fixed, in registered order."""
     return np.array([kwargs[name] for name in registered_params[model] if name not in fix_params], dtype=np.float64)
+
+
+def estimate_covariance(flatchain, ndim=0):
+    """Proposal covariance for the next run from a flatchain, ``2.38**2 / d * cov(flatchain)`` (the
+    ``opt_jump.npy`` of the drivers; utils.py:168-201, written by plot_samples.py:130-131).  The
+    reference also saves a correlation-coefficient plot; that stays with its plotting script."""
+    flatchain = np.asarray(flatchain, dtype=np.float64)
+    d = flatchain.shape[1] if ndim == 0 else ndim
+    return 2.38 ** 2 / d * np.cov(flatchain, rowvar=0)

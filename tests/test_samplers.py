@@ -121,6 +121,16 @@ def test_gelman_rubin():
         samplers.gelman_rubin([c[:999] for c in chains])
 
 
+def test_estimate_covariance_round_trip(tmp_path):
+    # the reference's resume workflow: flatchain -> opt_jump.npy -> proposal covariance of the next run
+    rng = np.random.RandomState(3)
+    true = np.array([[1.0, 0.3], [0.3, 0.5]])
+    chain = rng.multivariate_normal([0, 0], true, size=20000)
+    cov = utils.estimate_covariance(chain)
+    assert np.allclose(cov, 2.38 ** 2 / 2 * true, rtol=0.05, atol=0.02)
+    assert np.array_equal(utils.estimate_covariance(chain, ndim=4), 2.38 ** 2 / 4 * np.cov(chain, rowvar=0))
+
+
 def test_default_priors():
     # sample_parallel.py:330-358: strict inequalities, bounds themselves allowed
     p = dict(q=0.5, K=10.0, e=0.0, omega=-90.0, P=5.0, T0=-3.0, gamma=-20.0, amp_f=0.0, l_f=1.0, amp_g=0.1, l_g=2.0)
