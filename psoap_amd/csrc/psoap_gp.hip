@@ -186,10 +186,11 @@ extern "C" int psoap_chunk_create(psoap_chunk** out, int device, int N, const do
         if (blocks_per_cu > 2) blocks_per_cu = 2;
         h->dag_grid = blocks_per_cu * prop.multiProcessorCount;
     }
-    for (int g = 0; g < MAX_GROUPS; ++g) {
-        HIP_TRY(hipStreamCreateWithFlags(&h->streams[g], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&h->evDone[g], hipEventDisableTiming));
-    }
+    // one stream per handle; the extra streams of the staged mode's groups are created on first use, so
+    // that the streams of several handles spread over the runtime's hardware queues (handles that
+    // evaluate concurrently must not share one)
+    HIP_TRY(hipStreamCreateWithFlags(&h->streams[0], hipStreamNonBlocking));
+    for (int g = 0; g < MAX_GROUPS; ++g) HIP_TRY(hipEventCreateWithFlags(&h->evDone[g], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->evUpload, hipEventDisableTiming));
     HIP_TRY(hipMemcpy(h->dFl, fl, sizeof(double) * N, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->dSigma, sigma, sizeof(double) * N, hipMemcpyHostToDevice));
@@ -574,6 +575,8 @@ extern "C" int psoap_batch_eval(psoap_chunk* h)
     if (h->mode == 1 && h->P <= 255) return eval_dag(h);
     const int B = h->B, C = h->C, N = h->N, P = h->P;
     const int G = h->profiling ? 1 : (h->groups < B ? h->groups : B);
+    for (int g = 1; g < G; ++g)
+        if (!h->streams[g]) HIP_TRY(hipStreamCreateWithFlags(&h->streams[g], hipStreamNonBlocking));
     h->recs.clear();
     int gb0[MAX_GROUPS + 1];
     for (int g = 0; g <= G; ++g) gb0[g] = (int)((long long)B * g / G);
@@ -692,7 +695,8 @@ extern "C" int psoap_chunk_sync(psoap_chunk* h)
 {
     if (!h) FAIL("null handle");
     if (set_dev(h)) return 1;
-    for (int g = 0; g < MAX_GROUPS; ++g) HIP_TRY(hipStreamSynchronize(h->streams[g]));
+    for (int g = 0; g < MAX_GROUPS; ++g)
+        if (h->streams[g]) HIP_TRY(hipStreamSynchronize(h->streams[g]));
     return 0;
 }
 
