@@ -181,6 +181,19 @@ struct DagAug {
     const double* colx;   // (C, Rpad)
 };
 
+// One matrix of the batch.  The batch may be heterogeneous (matrices of several chunks with their own
+// size, data-noise vector and storage); a task reads its matrix's record with scalar loads.
+struct DagMat {
+    double* K;            // (Npad x ld) row-major upper storage, overwritten by the factor
+    double* R;            // (Npad) r -> z
+    double* Wt;           // (128 x 128) U11^-T of the current diagonal block, k-major
+    const double* lw;     // (C, N) ln-wavelengths per component
+    const double* gp;     // (2C) amp, l per component
+    const double* sigma;  // (N)
+    MatAcc* acc;
+    int N, Npad, P, ld;
+};
+
 template <int C, bool AUG>
 __device__ __forceinline__ void dag_store_updated(const Tile& t, double* dest, size_t ldd, int k0, int j0,
                                                   const double* __restrict__ lw, const GpDev& g, double dsum,
@@ -289,14 +302,10 @@ __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, in
 }
 
 template <int C, bool AUG = false>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, size_t mat_stride, int ld, int P,
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __restrict__ mats,
                                                              const DagTask* __restrict__ tasks, DagQueues queues,
-                                                             double* Wt, double* Rbase, int Npad, MatAcc* acc,
                                                              MatFlags* flags, int* arrive, double* wspace,
-                                                             DagCtl* ctl, unsigned long long* tlog,
-                                                             const double* __restrict__ lwl,
-                                                             const double* __restrict__ gp,
-                                                             const double* __restrict__ sigma, int N, DagAug aug)
+                                                             DagCtl* ctl, unsigned long long* tlog, DagAug aug)
 {
     __shared__ double vec1[NB];   // z_k (OFF)
     __shared__ double vec2[NB];   // column sums (OFF)
@@ -346,12 +355,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
         if (__hip_atomic_fetch_or(&ctl->error, 0u, PSOAP_RLX_AGENT) != 0u) return;
         const DagTask task = tasks[ticket];
         const int b = task.b, q = task.q, j = task.j;
-        double* Km = Kbase + (size_t)b * mat_stride;
-        double* Rv = Rbase + (size_t)b * Npad;
-        double* Wm = Wt + (size_t)b * NB * NB;
+        const DagMat mat = mats[b];
+        double* Km = mat.K;
+        double* Rv = mat.R;
+        double* Wm = mat.Wt;
+        const int ld = mat.ld, N = mat.N, Npad = mat.Npad;
         MatFlags* f = flags + b;
         const int k0 = q * NB, j0 = j * NB;
-        const int ntasks_row = (AUG ? aug.Pt : P) - q;
+        const int ntasks_row = (AUG ? aug.Pt : mat.P) - q;
 
         if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 0] = __builtin_amdgcn_s_memrealtime();
         t.zero();
@@ -367,7 +378,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
         if (n_wait > 0) dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);
         {
             GpDev g;
-            load_gp(gp + (size_t)b * 2 * C, C, g);
+            load_gp(mat.gp, C, g);
             double dsum = g.a2[0];
             {
 #pragma clang fp contract(off)
@@ -380,8 +391,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
             // that the exp() evaluations are off the critical row-to-row path (the final of a chain runs
             // right after the block row above completes; its PARTs ran ahead)
             const bool carries_k = chain ? (is_part ? task.S == 0 : task.S <= 1) : !is_part;
-            dag_store_updated<C, AUG>(t, dest, is_part ? (size_t)NB : (size_t)ld, k0, j0, lwl + (size_t)b * C * N, g,
-                                      dsum, sigma, N, carries_k ? 1.0 : 0.0, prev, n_prev, Npad, aug);
+            dag_store_updated<C, AUG>(t, dest, is_part ? (size_t)NB : (size_t)ld, k0, j0, mat.lw, g, dsum, mat.sigma, N,
+                                      carries_k ? 1.0 : 0.0, prev, n_prev, Npad, aug);
         }
         if (is_part) {
             dag_drain();
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(double* Kbase, siz
         dag_drain();  // the tile is re-read below in another layout by other waves of this block
         if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 1] = __builtin_amdgcn_s_memrealtime();
         if (ttype == DAG_DIAG) {
-            potrf_blocked(Km, ld, k0, Wm, Rv, acc + b);
+            potrf_blocked(Km, ld, k0, Wm, Rv, mat.acc);
             dag_drain();
             if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 2] = __builtin_amdgcn_s_memrealtime();
             if (threadIdx.x == 0) {

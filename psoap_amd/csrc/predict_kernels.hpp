@@ -217,6 +217,7 @@ inline int predict_run(int mode, int c, int N, int M, const double* lwl, const d
     MatAcc* dAcc = nullptr;
     unsigned char* dDag = nullptr;
     DagTask* dTasks = nullptr;
+    DagMat* dMat = nullptr;
     // The factorisation of [B | Cx^T] runs as ONE launch of the persistent dependency-graph kernel with
     // the appended columns as extra column tiles (k_chol_dag<C, true>: the cross-covariances are
     // evaluated on the fly like B itself).  The transposed-mean variant (covariance.py:294) needs a
@@ -279,11 +280,15 @@ inline int predict_run(int mode, int c, int N, int M, const double* lwl, const d
         const DagAug aug{P + Mt, Rq, Rq_pad, dColx};
         MatFlags* fl_ = reinterpret_cast<MatFlags*>(dDag + sizeof(DagCtl));
         DagCtl* ctl_ = reinterpret_cast<DagCtl*>(dDag);
+        DagMat hm{};
+        hm.K = dK; hm.R = dR; hm.Wt = dW; hm.lw = dLwl; hm.gp = dGp; hm.sigma = dSig; hm.acc = dAcc;
+        hm.N = N; hm.Npad = Npad; hm.P = P; hm.ld = (int)ld;
+        PR_TRY(hipMalloc(&dMat, sizeof(DagMat)));
+        PR_TRY(hipMemcpy(dMat, &hm, sizeof(DagMat), hipMemcpyHostToDevice));
 #define PSOAP_LAUNCH_AUG(CC)                                                                                      \
-    hipLaunchKernelGGL((k_chol_dag<CC, true>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dK, (size_t)0,  \
-                       (int)ld, P, dTasks, plan.queues, dW, dR, Npad, dAcc, fl_,                                   \
-                       reinterpret_cast<int*>(dDag + arrive_off), dWs, ctl_, (unsigned long long*)nullptr, dLwl,   \
-                       dGp, dSig, N, aug)
+    hipLaunchKernelGGL((k_chol_dag<CC, true>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dMat, dTasks,   \
+                       plan.queues, fl_, reinterpret_cast<int*>(dDag + arrive_off), dWs, ctl_,                     \
+                       (unsigned long long*)nullptr, aug)
         if (c == 1) PSOAP_LAUNCH_AUG(1);
         else if (c == 2) PSOAP_LAUNCH_AUG(2);
         else PSOAP_LAUNCH_AUG(3);
@@ -371,7 +376,7 @@ inline int predict_run(int mode, int c, int N, int M, const double* lwl, const d
 done:
     (void)hipFree(dK); (void)hipFree(dW); (void)hipFree(dR); (void)hipFree(dAcc); (void)hipFree(dLwl); (void)hipFree(dPred); (void)hipFree(dFl);
     (void)hipFree(dSig); (void)hipFree(dGp); (void)hipFree(dS); (void)hipFree(dMu); (void)hipFree(dM0); (void)hipFree(dPart); (void)hipFree(dOut);
-    (void)hipFree(dColx); (void)hipFree(dWs); (void)hipFree(dDag); (void)hipFree(dTasks);
+    (void)hipFree(dColx); (void)hipFree(dWs); (void)hipFree(dDag); (void)hipFree(dTasks); (void)hipFree(dMat);
     return rc;
 }
 

@@ -77,6 +77,8 @@ struct psoap_chunk {
     DagQueues plan_queues{};
     DagTask* dTasks = nullptr;
     size_t tasks_cap = 0;
+    DagMat* dMats = nullptr;   // per-matrix records of the current batch (max_batch entries)
+    int mats_B = 0, mats_C = 0;
     double* dWs = nullptr;   // split-K partial tiles, plan_slots x 128 x 128
     size_t ws_cap = 0;
     size_t arrive_off = 0;   // byte offset of the arrival counters inside dDag
@@ -174,6 +176,7 @@ extern "C" int psoap_chunk_create(psoap_chunk** out, int device, int N, const do
     h->arrive_off = sizeof(DagCtl) + sizeof(MatFlags) * nb;
     h->arrive_cap = nb * (size_t)h->P * (h->P + 1) / 2 + 16;
     HIP_TRY(hipMalloc(&h->dDag, h->arrive_off + sizeof(int) * h->arrive_cap));
+    HIP_TRY(hipMalloc(&h->dMats, sizeof(DagMat) * nb));
     HIP_TRY(hipHostMalloc(&h->hDagErr, 64));
     h->hDagErr[0] = 0;
     {
@@ -207,7 +210,7 @@ extern "C" int psoap_chunk_destroy(psoap_chunk* h)
     (void)hipFree(h->dK); (void)hipFree(h->dWt); (void)hipFree(h->dR); (void)hipFree(h->dAcc);
     (void)hipFree(h->dLwl); (void)hipFree(h->dGp); (void)hipFree(h->dVel); (void)hipFree(h->dOut);
     (void)hipFree(h->dDag); (void)hipHostFree(h->hDagErr); (void)hipFree(h->dTlog);
-    (void)hipFree(h->dTasks); (void)hipFree(h->dWs);
+    (void)hipFree(h->dTasks); (void)hipFree(h->dWs); (void)hipFree(h->dMats);
     (void)hipFree(h->dDates); (void)hipFree(h->dPorb); (void)hipHostFree(h->hPorb); (void)hipFree(h->dTooFast);
     (void)hipHostFree(h->hLwl); (void)hipHostFree(h->hGp); (void)hipHostFree(h->hVel); (void)hipHostFree(h->hOut);
     for (int g = 0; g < MAX_GROUPS; ++g) {
@@ -492,8 +495,36 @@ static void launch_fill(psoap_chunk* h, hipStream_t s, int b0, int nb, int upper
 }
 
 // (re)build the task list of the persistent kernel when the batch size changes
+// per-matrix records of this handle's batch (uniform: every matrix shares N, fl, sigma)
+static void fill_mats(const psoap_chunk* h, DagMat* out)
+{
+    for (int b = 0; b < h->B; ++b) {
+        DagMat m{};
+        m.K = h->dK + (size_t)b * h->mat_stride;
+        m.R = h->dR + (size_t)b * h->Npad;
+        m.Wt = h->dWt + (size_t)b * NB * NB;
+        m.lw = h->dLwl + (size_t)b * h->C * h->N;
+        m.gp = h->dGp + (size_t)b * 2 * h->C;
+        m.sigma = h->dSigma;
+        m.acc = h->dAcc + b;
+        m.N = h->N;
+        m.Npad = h->Npad;
+        m.P = h->P;
+        m.ld = h->ld;
+        out[b] = m;
+    }
+}
+
 static int dag_prepare(psoap_chunk* h)
 {
+    if (h->mats_B != h->B || h->mats_C != h->C) {
+        std::vector<DagMat> mats(h->B);
+        fill_mats(h, mats.data());
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(h->dMats, mats.data(), sizeof(DagMat) * h->B, hipMemcpyHostToDevice));
+        h->mats_B = h->B;
+        h->mats_C = h->C;
+    }
     if (h->plan_B == h->B) return 0;
     if (h->P > 255) FAIL("N too large for the persistent kernel's 8-bit block-row indices (N <= 32640)");
     HIP_TRY(hipDeviceSynchronize());
@@ -546,10 +577,9 @@ static int eval_dag(psoap_chunk* h)
         MatFlags* fl_ = reinterpret_cast<MatFlags*>(h->dDag + sizeof(DagCtl));
         DagCtl* ctl_ = reinterpret_cast<DagCtl*>(h->dDag);
 #define PSOAP_LAUNCH_DAG(CC)                                                                                     \
-    hipLaunchKernelGGL(k_chol_dag<CC>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, h->dK, h->mat_stride,   \
-                       h->ld, P, h->dTasks, h->plan_queues, h->dWt, h->dR, h->Npad, h->dAcc, fl_,                 \
-                       reinterpret_cast<int*>(h->dDag + h->arrive_off), h->dWs, ctl_, h->dTlog, h->dLwl, h->dGp, \
-                       h->dSigma, N, DagAug{P, 0, 0, nullptr})
+    hipLaunchKernelGGL(k_chol_dag<CC>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, h->dMats, h->dTasks,    \
+                       h->plan_queues, fl_, reinterpret_cast<int*>(h->dDag + h->arrive_off), h->dWs, ctl_,         \
+                       h->dTlog, DagAug{P, 0, 0, nullptr})
         if (C == 1) PSOAP_LAUNCH_DAG(1);
         else if (C == 2) PSOAP_LAUNCH_DAG(2);
         else PSOAP_LAUNCH_DAG(3);
