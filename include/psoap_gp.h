@@ -185,6 +185,11 @@ int psoap_chunk_dag_tasks(psoap_chunk *h, void *out, long long max_tasks, long l
  * P block rows on `workers` workgroups, same record format as psoap_chunk_dag_tasks. */
 int psoap_dag_plan(int B, int P, int workers, void *out, long long max_tasks, long long *n_tasks,
                    long long *n_slots, long long *n_ctrs, unsigned int *queue_first /* 9 entries or NULL */);
+/* The same for a heterogeneous batch (matrices of several chunks in one launch): matrix b has Ps[b]
+ * block rows. */
+int psoap_dag_plan_multi(int B, const int *Ps, int workers, void *out, long long max_tasks,
+                         long long *n_tasks, long long *n_slots, long long *n_ctrs,
+                         unsigned int *queue_first);
 
 /* fp64 MFMA / HBM micro-benchmarks used to state the measured peaks beside the
  * spec peaks in bench.py (results in TFLOP/s and GB/s). */

@@ -507,17 +507,39 @@ inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first,
 // task list of ONE queue: the matrices in `mats`, served by about `workers` workgroups
 // `Bq_nominal` (the largest queue's matrix count) decides the split factors, so every matrix of the
 // batch gets the same task structure and identical proposals give identical bits in any batch slot
-inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, int workers, int Bq_nominal, int scheme,
-                            int Mt = 0)
+inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const std::vector<int>& Ps, int workers,
+                            int Bq_nominal, int scheme, int Mt = 0)
 {
-    const int Bq = Bq_nominal;
+    // Ps[b]: block rows of matrix b.  A heterogeneous batch (matrices of several chunks) walks the block
+    // rows of all its matrices together; a matrix simply drops out once its rows are used up.
     if (mats.empty()) return;
+    int P = 0;
+    bool uniform = true;
+    for (int b : mats) {
+        P = Ps[b] > P ? Ps[b] : P;
+        uniform = uniform && Ps[b] == Ps[mats[0]];
+    }
     std::vector<std::vector<DagTask>> early_final(P);   // DIAG finals whose PARTs were emitted a row early
     for (int q = 0; q < P; ++q) {
-        const int S_off = dag_split_factor(Bq * (P + Mt - q), q, workers);
+        // tiles of this block row in the queue; uniform batches use the nominal matrix count so that the
+        // split factors do not depend on the slot a matrix sits in
+        long long row_tiles = 0;
+        int live = 0;
+        for (int b : mats)
+            if (q < Ps[b]) {
+                row_tiles += Ps[b] + Mt - q;
+                ++live;
+            }
+        if (uniform) {
+            row_tiles = (long long)Bq_nominal * (P + Mt - q);
+            live = Bq_nominal;
+        }
+        const int Bq = live;
+        const int S_off = dag_split_factor((int)row_tiles, q, workers);
         // 1. DIAG finals of this row
         if (q <= 1) {
-            for (int b : mats) dag_emit(plan, DAG_DIAG, b, q, q, 0, q, 1, scheme);
+            for (int b : mats)
+                if (q < Ps[b]) dag_emit(plan, DAG_DIAG, b, q, q, 0, q, 1, scheme);
         } else {
             for (const DagTask& t : early_final[q]) plan.tasks.push_back(t);
         }
@@ -525,6 +547,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, 
         if (q + 1 < P && q >= 1) {
             const int S_pre = dag_split_factor(Bq, q, workers / 4 > 0 ? workers / 4 : 1);
             for (int b : mats) {
+                if (q + 1 >= Ps[b]) continue;
                 const unsigned int ctr = plan.n_ctrs++;
                 const bool chain = (scheme == 1);
                 if (chain) plan.n_slots += plan.n_slots & 1u;
@@ -558,7 +581,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, 
         }
         // 3. off-diagonal tiles of this row
         for (int b : mats)
-            for (int j = q + 1; j < P + Mt; ++j) dag_emit(plan, DAG_OFF, b, q, j, 0, q, S_off, scheme);
+            for (int j = q + 1; j < Ps[b] + Mt && q < Ps[b]; ++j) dag_emit(plan, DAG_OFF, b, q, j, 0, q, S_off, scheme);
     }
 }
 
@@ -569,10 +592,13 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, int P, 
 // from B = 24 (B = 32: 39.5 vs 40.3 ms).  (Readiness ordering was also tried for the throughput scheme:
 // 800 -> 776 evals/s, not adopted.)
 constexpr long long DAG_LATENCY_TILES = 20000;
-inline DagPlan dag_build_tasks(int B, int P, int workers, int scheme = -1, int Mt = 0)
+inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int scheme = -1, int Mt = 0)
 {
     DagPlan plan;
-    if (scheme < 0) scheme = ((long long)B * (P * (P + 1) / 2 + P * Mt) <= DAG_LATENCY_TILES) ? 1 : 0;
+    const int B = (int)Ps.size();
+    long long tiles = 0;
+    for (int P : Ps) tiles += (long long)P * (P + 1) / 2 + (long long)P * Mt;
+    if (scheme < 0) scheme = (tiles <= DAG_LATENCY_TILES) ? 1 : 0;
     // workgroups of XCDs whose own queue is empty steal, so the workers are shared by the queues in use
     const int used = B < DAG_QUEUES ? (B > 0 ? B : 1) : DAG_QUEUES;
     const int per_queue = workers / used > 0 ? workers / used : 1;
@@ -580,7 +606,7 @@ inline DagPlan dag_build_tasks(int B, int P, int workers, int scheme = -1, int M
         plan.queues.first[g] = (unsigned int)plan.tasks.size();
         std::vector<int> mats;
         for (int b = g; b < B; b += DAG_QUEUES) mats.push_back(b);
-        dag_build_queue(plan, mats, P, per_queue, (B + DAG_QUEUES - 1) / DAG_QUEUES, scheme, Mt);
+        dag_build_queue(plan, mats, Ps, per_queue, (B + DAG_QUEUES - 1) / DAG_QUEUES, scheme, Mt);
         if (scheme == 1) {
             // Latency scheme: hand the tasks out in order of READINESS instead of block row by block row.
             // A task over panels [pa, pb) can run once block row pb-1 is finished ("stage" pb); within a
@@ -606,5 +632,12 @@ inline DagPlan dag_build_tasks(int B, int P, int workers, int scheme = -1, int M
     plan.queues.first[DAG_QUEUES] = (unsigned int)plan.tasks.size();
     return plan;
 }
+
+// uniform batch: B matrices of P block rows each
+inline DagPlan dag_build_tasks(int B, int P, int workers, int scheme = -1, int Mt = 0)
+{
+    return dag_build_tasks(std::vector<int>((size_t)(B > 0 ? B : 0), P), workers, scheme, Mt);
+}
+
 
 }  // namespace psoap

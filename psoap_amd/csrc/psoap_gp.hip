@@ -297,6 +297,26 @@ extern "C" int psoap_dag_plan(int B, int P, int workers, void* out, long long ma
     return 0;
 }
 
+// The same for a heterogeneous batch: matrix b has Ps[b] block rows.
+extern "C" int psoap_dag_plan_multi(int B, const int* Ps, int workers, void* out, long long max_tasks,
+                                    long long* n_tasks, long long* n_slots, long long* n_ctrs,
+                                    unsigned int* queue_first)
+{
+    if (B < 1 || !Ps || workers < 1 || !n_tasks) FAIL("psoap_dag_plan_multi: bad arguments");
+    for (int b = 0; b < B; ++b)
+        if (Ps[b] < 1 || Ps[b] > 255) FAIL("psoap_dag_plan_multi: 1 <= P <= 255");
+    DagPlan plan = dag_build_tasks(std::vector<int>(Ps, Ps + B), workers);
+    *n_tasks = (long long)plan.tasks.size();
+    if (n_slots) *n_slots = plan.n_slots;
+    if (n_ctrs) *n_ctrs = plan.n_ctrs;
+    if (queue_first) memcpy(queue_first, plan.queues.first, sizeof plan.queues.first);
+    if (out) {
+        const long long n = max_tasks < *n_tasks ? max_tasks : *n_tasks;
+        memcpy(out, plan.tasks.data(), sizeof(DagTask) * n);
+    }
+    return 0;
+}
+
 // Debug: copy the current task list (16-byte DagTask records, ticket order) to the host.
 extern "C" int psoap_chunk_dag_tasks(psoap_chunk* h, void* out, long long max_tasks, long long* n_tasks)
 {

@@ -12,14 +12,21 @@ TYPE_MASK, CHAIN = 0x0F, 0x10
 
 
 def plan(B, P, workers):
+    """``P``: block rows of every matrix (uniform batch) or a list with one entry per matrix."""
     from psoap_amd import _lib
     L = _lib.load()
     n, slots, ctrs = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
     first = (ctypes.c_uint32 * 9)()
-    assert L.psoap_dag_plan(B, P, workers, None, 0, ctypes.byref(n), ctypes.byref(slots), ctypes.byref(ctrs), first) == 0
+    if np.ndim(P) == 0:
+        call = lambda out, cap: L.psoap_dag_plan(B, P, workers, out, cap, ctypes.byref(n), ctypes.byref(slots),   # noqa: E731
+                                                 ctypes.byref(ctrs), first)
+    else:
+        Ps = (ctypes.c_int * B)(*P)
+        call = lambda out, cap: L.psoap_dag_plan_multi(B, Ps, workers, out, cap, ctypes.byref(n),                 # noqa: E731
+                                                       ctypes.byref(slots), ctypes.byref(ctrs), first)
+    assert call(None, 0) == 0
     tasks = np.zeros(n.value, dtype=TASK)
-    assert L.psoap_dag_plan(B, P, workers, tasks.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n),
-                            ctypes.byref(slots), ctypes.byref(ctrs), first) == 0
+    assert call(tasks.ctypes.data_as(ctypes.c_void_p), n.value) == 0
     plan.queue_first = list(first)
     plan.chain = (tasks["type"] & CHAIN) != 0
     tasks["type"] &= TYPE_MASK
@@ -27,13 +34,18 @@ def plan(B, P, workers):
 
 
 @pytest.mark.parametrize("B,P,workers", [(1, 1, 512), (1, 2, 512), (1, 47, 512), (3, 5, 512), (7, 16, 512),
-                                         (32, 47, 512), (32, 64, 512), (5, 20, 8), (200, 4, 512)])
+                                         (32, 47, 512), (32, 64, 512), (5, 20, 8), (200, 4, 512),
+                                         # heterogeneous batches: matrices of several chunks in one launch
+                                         (4, [3, 9, 1, 16], 512), (12, [16, 13, 11, 16, 20, 7, 16, 13, 11, 16, 20, 7], 512),
+                                         (40, [47, 32] * 20, 512), (9, [2, 40, 2, 2, 2, 2, 2, 2, 5], 64)])
 def test_plan_is_complete_and_deadlock_free(B, P, workers):
     tasks, n_slots, n_ctrs = plan(B, P, workers)
     chain = plan.chain
+    Ps = [P] * B if np.ndim(P) == 0 else list(P)
+    n_tiles = sum(p * (p + 1) // 2 for p in Ps)
     assert TASK.itemsize == 16
     # small batches (<= 20,000 tiles): latency scheme, chained partial sums; otherwise gathered
-    assert np.all(chain[tasks["S"] > 1] == (B * P * (P + 1) // 2 <= 20000)) if (tasks["S"] > 1).any() else True
+    assert np.all(chain[tasks["S"] > 1] == (n_tiles <= 20000)) if (tasks["S"] > 1).any() else True
     # one queue per XCD: matrix b lives in queue b mod 8, queues are contiguous ranges of the list
     first = plan.queue_first
     assert first[0] == 0 and first[8] == len(tasks) and all(first[g] <= first[g + 1] for g in range(8))
@@ -48,7 +60,7 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
     row_final_last_ticket = {}   # (b, q) -> max ticket of the row's finals
     for t, k in enumerate(tasks):
         key = (int(k["b"]), int(k["q"]), int(k["j"]))
-        assert k["j"] >= k["q"] and k["q"] < P and k["j"] < P and k["b"] < B
+        assert k["b"] < B and k["j"] >= k["q"] and k["q"] < Ps[int(k["b"])] and k["j"] < Ps[int(k["b"])]
         assert k["pa"] <= k["pb"] <= k["q"]
         covered.setdefault(key, []).append((int(k["pa"]), int(k["pb"])))
         if k["type"] == PART:
@@ -71,7 +83,9 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
             rk = (key[0], key[1])
             row_final_last_ticket[rk] = max(row_final_last_ticket.get(rk, -1), t)
     # every upper tile of every matrix has exactly one final
-    assert len(finals) == B * P * (P + 1) // 2
+    assert len(finals) == n_tiles
+    for b in range(B):
+        assert sum(1 for key in finals if key[0] == b) == Ps[b] * (Ps[b] + 1) // 2
     assert all(sl < n_slots for sl in slots_seen)
     for key, ranges in covered.items():
         b, q, j = key
