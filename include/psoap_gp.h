@@ -143,6 +143,19 @@ int psoap_calibrate_explicit(int device, int M, int N, int order, double lwl0,
                              double mu_GP, double *fl_cor, double *X,
                              int *status_out);
 
+/* ---- several chunks, one launch ---------------------------------------------------
+ * A group evaluates the uploaded batches of several chunk handles (one device, one
+ * component count, sizes may differ) in ONE launch of the persistent kernel over the
+ * heterogeneous batch, so that the matrices of all chunks hide each other's dependency
+ * chains.  The reference evaluates its chunks in separate worker processes
+ * (sample_parallel.py:258-278, :378-387); this is the one-GPU form of that fan-out.
+ * Usage: psoap_batch_upload* on every member, psoap_group_eval, psoap_batch_fetch on
+ * every member (each handle's stream waits for the group launch). */
+typedef struct psoap_group psoap_group;
+int psoap_group_create(psoap_group **out, psoap_chunk *const *handles, int n);
+int psoap_group_eval(psoap_group *g);
+int psoap_group_destroy(psoap_group *g);
+
 /* ---- measurement ----------------------------------------------------------------
  * With profiling on, every kernel launch of psoap_batch_eval is bracketed by
  * hipEvents on its own stream (single stream group, so launches serialise);

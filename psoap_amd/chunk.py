@@ -135,6 +135,43 @@ class ChunkHandle:
         return out
 
 
+class ChunkGroup:
+    """Several chunk handles (one device, one component count; sizes may differ) evaluated by ONE launch
+    of the persistent kernel over the heterogeneous batch -- the one-GPU form of the reference's one
+    worker process per chunk (sample_parallel.py:258-278).  ``upload*`` on every member, ``eval()``,
+    ``fetch()`` on every member.  Small chunks cannot fill the device one at a time; together the
+    matrices of all chunks hide each other's dependency chains."""
+
+    def __init__(self, handles):
+        self.handles = list(handles)
+        if not self.handles:
+            raise ValueError("a group needs at least one chunk handle")
+        self._L = _lib.load()
+        self._g = ctypes.c_void_p()
+        arr = (ctypes.c_void_p * len(self.handles))(*[h._h for h in self.handles])
+        check(self._L.psoap_group_create(ctypes.byref(self._g), arr, len(self.handles)), "psoap_group_create")
+
+    def eval(self):
+        check(self._L.psoap_group_eval(self._g), "psoap_group_eval")
+
+    def close(self):
+        if getattr(self, "_g", None) is not None and self._g:
+            self._L.psoap_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
 def microbench(device: int | None = None) -> dict:
     L = _lib.load()
     dev = _lib.default_device() if device is None else device

@@ -718,6 +718,158 @@ static int collect_timings(psoap_chunk* h)
     return 0;
 }
 
+// ---- several chunks, one launch ------------------------------------------------------------------
+// The uploaded batches of several chunk handles (one device, one component count) are factored by ONE
+// launch of the persistent kernel over the heterogeneous batch: every matrix brings its own size, data
+// and storage (DagMat), the task list walks all of them together, and the matrices of all chunks hide
+// each other's dependency chains -- what a workload of many small chunks needs to fill the device.
+struct psoap_group {
+    int device = 0;
+    std::vector<psoap_chunk*> hs;
+    hipStream_t stream = nullptr;
+    hipEvent_t evDone = nullptr;
+    unsigned char* dDag = nullptr;
+    size_t dag_cap = 0, dag_bytes = 0, arrive_off = 0;
+    DagMat* dMats = nullptr;
+    size_t mats_cap = 0;
+    DagTask* dTasks = nullptr;
+    size_t tasks_cap = 0;
+    double* dWs = nullptr;
+    size_t ws_cap = 0;
+    std::vector<int> key;      // B of every handle, then C: the plan is rebuilt when it changes
+    DagQueues queues{};
+    long long n_tasks = 0;
+    int total_B = 0;
+};
+
+extern "C" int psoap_group_create(psoap_group** out, psoap_chunk* const* handles, int n)
+{
+    if (!out || !handles || n < 1) FAIL("psoap_group_create: bad arguments");
+    for (int k = 0; k < n; ++k) {
+        if (!handles[k]) FAIL("psoap_group_create: null handle");
+        if (handles[k]->device != handles[0]->device) FAIL("psoap_group_create: all chunks must live on one device");
+        if (handles[k]->P > 255) FAIL("psoap_group_create: N too large for the persistent kernel (N <= 32640)");
+    }
+    HIP_TRY(hipSetDevice(handles[0]->device));
+    psoap_group* g = new psoap_group();
+    g->device = handles[0]->device;
+    g->hs.assign(handles, handles + n);
+    HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&g->evDone, hipEventDisableTiming));
+    *out = g;
+    return 0;
+}
+
+extern "C" int psoap_group_destroy(psoap_group* g)
+{
+    if (!g) return 0;
+    (void)hipSetDevice(g->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(g->dDag); (void)hipFree(g->dMats); (void)hipFree(g->dTasks); (void)hipFree(g->dWs);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    if (g->evDone) (void)hipEventDestroy(g->evDone);
+    delete g;
+    return 0;
+}
+
+// Launch the uploaded batches of all member handles; afterwards psoap_batch_fetch on each handle returns
+// its results (every handle's stream waits for the group launch).
+extern "C" int psoap_group_eval(psoap_group* g)
+{
+    if (!g) FAIL("psoap_group_eval: null group");
+    HIP_TRY(hipSetDevice(g->device));
+    const int C = g->hs[0]->C;
+    std::vector<int> key;
+    int total = 0;
+    for (psoap_chunk* h : g->hs) {
+        if (h->B < 1) FAIL("psoap_group_eval: every member needs an uploaded batch");
+        if (h->C != C) FAIL("psoap_group_eval: all members must use the same number of components");
+        key.push_back(h->B);
+        total += h->B;
+    }
+    key.push_back(C);
+    if (total > 65535) FAIL("psoap_group_eval: more than 65535 matrices in one launch");
+    if (key != g->key) {
+        HIP_TRY(hipDeviceSynchronize());
+        std::vector<DagMat> mats((size_t)total);
+        std::vector<int> Ps;
+        int b0 = 0;
+        for (psoap_chunk* h : g->hs) {
+            fill_mats(h, mats.data() + b0);
+            for (int b = 0; b < h->B; ++b) Ps.push_back(h->P);
+            b0 += h->B;
+        }
+        const char* env_scheme = getenv("PSOAP_DAG_SCHEME");
+        DagPlan plan = dag_build_tasks(Ps, g->hs[0]->dag_grid, env_scheme ? atoi(env_scheme) : -1);
+        if (mats.size() > g->mats_cap) {
+            if (g->dMats) HIP_TRY(hipFree(g->dMats));
+            g->dMats = nullptr;
+            HIP_TRY(hipMalloc(&g->dMats, sizeof(DagMat) * mats.size()));
+            g->mats_cap = mats.size();
+        }
+        if (plan.tasks.size() > g->tasks_cap) {
+            if (g->dTasks) HIP_TRY(hipFree(g->dTasks));
+            g->dTasks = nullptr;
+            HIP_TRY(hipMalloc(&g->dTasks, sizeof(DagTask) * plan.tasks.size()));
+            g->tasks_cap = plan.tasks.size();
+        }
+        if ((size_t)plan.n_slots + 1 > g->ws_cap) {
+            if (g->dWs) HIP_TRY(hipFree(g->dWs));
+            g->dWs = nullptr;
+            HIP_TRY(hipMalloc(&g->dWs, sizeof(double) * NB * NB * ((size_t)plan.n_slots + 1)));
+            g->ws_cap = (size_t)plan.n_slots + 1;
+        }
+        g->arrive_off = sizeof(DagCtl) + sizeof(MatFlags) * (size_t)total;
+        g->dag_bytes = g->arrive_off + sizeof(int) * ((size_t)plan.n_ctrs + 4);
+        if (g->dag_bytes > g->dag_cap) {
+            if (g->dDag) HIP_TRY(hipFree(g->dDag));
+            g->dDag = nullptr;
+            HIP_TRY(hipMalloc(&g->dDag, g->dag_bytes));
+            g->dag_cap = g->dag_bytes;
+        }
+        HIP_TRY(hipMemcpy(g->dMats, mats.data(), sizeof(DagMat) * mats.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(g->dTasks, plan.tasks.data(), sizeof(DagTask) * plan.tasks.size(), hipMemcpyHostToDevice));
+        g->queues = plan.queues;
+        g->n_tasks = (long long)plan.tasks.size();
+        g->total_B = total;
+        g->key = key;
+    }
+    hipStream_t s = g->stream;
+    for (psoap_chunk* h : g->hs) {
+        HIP_TRY(hipStreamWaitEvent(s, h->evUpload, 0));
+        hipLaunchKernelGGL(k_init_rhs, dim3((h->Npad + 255) / 256, h->B), dim3(256), 0, s, h->dR, h->Npad, h->N, h->dFl,
+                           h->mu, h->dAcc);
+        h->recs.clear();
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(g->dDag, 0, g->dag_bytes, s));
+    {
+        const int workers = g->hs[0]->dag_grid;
+        const int grid = (int)(g->n_tasks < workers ? g->n_tasks : workers);
+        MatFlags* fl_ = reinterpret_cast<MatFlags*>(g->dDag + sizeof(DagCtl));
+        DagCtl* ctl_ = reinterpret_cast<DagCtl*>(g->dDag);
+#define PSOAP_LAUNCH_GROUP(CC)                                                                                  \
+    hipLaunchKernelGGL(k_chol_dag<CC>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, g->dMats, g->dTasks,   \
+                       g->queues, fl_, reinterpret_cast<int*>(g->dDag + g->arrive_off), g->dWs, ctl_,             \
+                       (unsigned long long*)nullptr, DagAug{0, 0, 0, nullptr})
+        if (C == 1) PSOAP_LAUNCH_GROUP(1);
+        else if (C == 2) PSOAP_LAUNCH_GROUP(2);
+        else PSOAP_LAUNCH_GROUP(3);
+#undef PSOAP_LAUNCH_GROUP
+    }
+    HIP_TRY(hipGetLastError());
+    for (psoap_chunk* h : g->hs) {
+        hipLaunchKernelGGL(k_finalize, dim3((h->B + 63) / 64), dim3(64), 0, s, h->dAcc, h->dOut, h->B, h->dTooFast);
+        HIP_TRY(hipMemcpyAsync(h->hOut, h->dOut, sizeof(double) * h->B, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(h->hDagErr, g->dDag + offsetof(DagCtl, error), 4 * sizeof(unsigned int),
+                               hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(g->evDone, s));
+    for (psoap_chunk* h : g->hs) HIP_TRY(hipStreamWaitEvent(h->streams[0], g->evDone, 0));
+    return 0;
+}
+
 extern "C" int psoap_batch_fetch(psoap_chunk* h, double* out)
 {
     if (!h || !out || h->B < 1) FAIL("psoap_batch_fetch: bad arguments");

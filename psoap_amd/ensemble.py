@@ -113,10 +113,21 @@ class EnsembleEvaluator:
 
         ev = cls(len(chunks), evaluate, world, rank, device_index)
         ev.handles = handles
+        if len(mine) > 1:
+            from .chunk import ChunkGroup
+            ev.group = ChunkGroup([handles[k] for k in mine])     # several chunks on this GPU: one launch
         return ev
 
     def lnprob(self, proposals) -> np.ndarray:
-        local = [np.asarray(self.evaluate(k, proposals), dtype=np.float64) for k in self.mine]
+        group = getattr(self, "group", None)
+        if group is not None:
+            for k in self.mine:
+                lwls, gps = proposals[k]
+                self.handles[k].upload(lwls, gps)
+            group.eval()
+            local = [np.asarray(self.handles[k].fetch(), dtype=np.float64) for k in self.mine]
+        else:
+            local = [np.asarray(self.evaluate(k, proposals), dtype=np.float64) for k in self.mine]
         B = local[0].shape[0] if local else 0
         if self.world > 1 and not local:
             raise ValueError("every rank must own at least one chunk (n_chunks >= world)")
@@ -125,5 +136,7 @@ class EnsembleEvaluator:
         return sum_over_chunks(table)
 
     def close(self):
+        if getattr(self, "group", None) is not None:
+            self.group.close()
         for h in getattr(self, "handles", {}).values():
             h.close()

@@ -32,15 +32,20 @@ class ChunkWorker:
     def close(self):
         self.handle.close()
 
-    def lnprob_batch(self, ps, mu_GP: float = 1.0) -> np.ndarray:
+    def upload_proposals(self, ps, mu_GP: float = 1.0) -> None:
+        """Ship fitted parameter vectors (B, n_fit); the orbit solve and the Doppler shift are queued on the
+        chunk's stream.  Follow with ``handle.eval()`` (or a ``ChunkGroup.eval()``) and ``handle.fetch()``."""
         p_orb, p_gp = convert_vectors(np.atleast_2d(ps), self.model, self.fix_params, **self.defaults)
         B = p_orb.shape[0]
         h = self.handle
         check(h._L.psoap_batch_upload_orbits(h._h, B, MODEL_ID[self.model], dptr(p_orb), dptr(p_gp), float(mu_GP)),
               "psoap_batch_upload_orbits")
         h._B = B
-        h.eval()
-        return h.fetch()
+
+    def lnprob_batch(self, ps, mu_GP: float = 1.0) -> np.ndarray:
+        self.upload_proposals(ps, mu_GP)
+        self.handle.eval()
+        return self.handle.fetch()
 
     def lnprob(self, p, mu_GP: float = 1.0) -> float:
         return float(self.lnprob_batch(np.atleast_2d(p), mu_GP)[0])

@@ -91,8 +91,15 @@ class Posterior:
                                    fix_params=self.fix_params, defaults=self.parameters, max_batch=self.max_batch,
                                    device=device_index, soften=soften)
         self.workers = {k: make_worker(chunks[k]) for k in self.mine}
+        # several chunks on this GPU: ONE launch of the persistent kernel over all of them per evaluation
+        self.group = None
+        if len(self.mine) > 1 and all(hasattr(w, "upload_proposals") and hasattr(w, "handle") for w in self.workers.values()):
+            from .chunk import ChunkGroup
+            self.group = ChunkGroup([self.workers[k].handle for k in self.mine])
 
     def close(self):
+        if self.group is not None:
+            self.group.close()
         for w in self.workers.values():
             if hasattr(w, "close"):
                 w.close()
@@ -108,9 +115,17 @@ class Posterior:
         if n_ok:
             block = np.empty((len(self.mine), n_ok))
             Pok = P[ok]
-            for i, k in enumerate(self.mine):
-                for s in range(0, n_ok, self.max_batch):
-                    block[i, s:s + self.max_batch] = self.workers[k].lnprob_batch(Pok[s:s + self.max_batch])
+            for s in range(0, n_ok, self.max_batch):
+                piece = Pok[s:s + self.max_batch]
+                if self.group is not None:
+                    for k in self.mine:
+                        self.workers[k].upload_proposals(piece)
+                    self.group.eval()
+                    for i, k in enumerate(self.mine):
+                        block[i, s:s + self.max_batch] = self.workers[k].handle.fetch()
+                else:
+                    for i, k in enumerate(self.mine):
+                        block[i, s:s + self.max_batch] = self.workers[k].lnprob_batch(piece)
             table = gather_chunk_lnprobs(block, self.n_chunks, self.world, self.rank, self.device_index)
             out[ok] = sum_over_chunks(table) + lnprior[ok]
         return out

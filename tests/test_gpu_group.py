@@ -1,0 +1,91 @@
+"""GPU: several chunks of different sizes factored by ONE launch of the persistent kernel (ChunkGroup)
+against the same chunks evaluated one at a time and against the oracle."""
+import numpy as np
+import pytest
+
+from psoap_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+LNP_RTOL = 1e-10
+
+
+def close(a, b):
+    return abs(a - b) <= LNP_RTOL * max(1.0, abs(b))
+
+
+@pytest.mark.parametrize("c,shapes,Bs", [
+    (2, [(4, 150), (7, 118), (10, 130), (1, 77)], [5, 3, 5, 1]),     # N = 600, 826 (ragged), 1300, 77
+    (1, [(3, 43), (3, 43), (9, 200)], [2, 2, 9]),                    # two equal chunks and a larger one
+    (3, [(5, 100)], [4]),                                            # a group of one
+])
+def test_group_launch_matches_single_launches_and_oracle(oracle, c, shapes, Bs):
+    from psoap_amd.chunk import ChunkGroup, ChunkHandle
+    chunks = [syn.make_chunk(c, ne, npx, seed=9100 + i, masked_fraction=0.1 if npx > 100 else 0.0)
+              for i, (ne, npx) in enumerate(shapes)]
+    props = []
+    for i, (ch, B) in enumerate(zip(chunks, Bs)):
+        gps = syn.make_walkers(c, B, seed=9200 + i)
+        lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, B, seed=9300 + i))
+        props.append((lw, gps))
+    props[0][1][-1, 1] = -1.0                    # a rejected proposal (l < 0) inside the first chunk's batch
+    handles = [ChunkHandle(ch.fl, ch.sigma, max_batch=max(Bs)) for ch in chunks]
+    try:
+        single = [h.lnlike_batch(*p) for h, p in zip(handles, props)]
+        with ChunkGroup(handles) as g:
+            for rep in range(2):                 # the second pass reuses the cached task list
+                for h, p in zip(handles, props):
+                    h.upload(*p)
+                g.eval()
+                grouped = [h.fetch() for h in handles]
+                for k in range(len(chunks)):
+                    assert grouped[k].shape == (Bs[k],)
+                    for w in range(Bs[k]):
+                        if np.isneginf(single[k][w]):
+                            assert np.isneginf(grouped[k][w])
+                        else:
+                            assert close(grouped[k][w], single[k][w]), (k, w, grouped[k][w], single[k][w])
+            # batch sizes change: the task list is rebuilt
+            handles[0].upload(props[0][0][:1], props[0][1][:1])
+            for h, p in zip(handles[1:], props[1:]):
+                h.upload(*p)
+            g.eval()
+            assert close(handles[0].fetch()[0], single[0][0])
+            assert close(handles[-1].fetch()[0], single[-1][0])
+        assert np.isneginf(single[0][-1])
+        for k, ch in enumerate(chunks):
+            want = oracle.lnlike(props[k][0][0], ch.fl, ch.sigma, props[k][1][0])
+            assert close(grouped[k][0], want), (k, grouped[k][0], want)
+        # the handles still work on their own after the group is gone
+        last = len(handles) - 1
+        assert close(handles[last].lnlike_batch(*props[last])[0], single[last][0])
+    finally:
+        for h in handles:
+            h.close()
+
+
+def test_group_rejects_mixed_component_counts():
+    from psoap_amd._lib import PsoapError
+    from psoap_amd.chunk import ChunkGroup, ChunkHandle
+    a, b = syn.make_chunk(1, 2, 40, seed=1), syn.make_chunk(2, 2, 40, seed=2)
+    with ChunkHandle(a.fl, a.sigma, 2) as ha, ChunkHandle(b.fl, b.sigma, 2) as hb, ChunkGroup([ha, hb]) as g:
+        ha.upload(a.lwls[None], np.array([syn.GP_BASE[1]]))
+        hb.upload(b.lwls[None], np.array([syn.GP_BASE[2]]))
+        with pytest.raises(PsoapError, match="same number of components"):
+            g.eval()
+
+
+def test_ensemble_evaluator_uses_one_launch_for_its_chunks(oracle):
+    from psoap_amd.ensemble import EnsembleEvaluator
+    chunks = [syn.make_chunk(2, 3, 90 + 10 * k, seed=9400 + k) for k in range(3)]
+    B = 4
+    gps = syn.make_walkers(2, B, seed=9500)
+    props = {k: (syn.walker_lwls(chunks[k], syn.make_walker_velocities(chunks[k], B, seed=9600 + k)), gps)
+             for k in range(3)}
+    ev = EnsembleEvaluator.from_chunks(chunks, max_batch=B)
+    try:
+        assert getattr(ev, "group", None) is not None
+        got = ev.lnprob(props)
+    finally:
+        ev.close()
+    want = sum(oracle.lnlike(props[k][0][1], chunks[k].fl, chunks[k].sigma, gps[1]) for k in range(3))
+    assert close(got[1], want)

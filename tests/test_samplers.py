@@ -256,7 +256,7 @@ def test_posterior_skips_rows_outside_prior():
     P[4, 2] = 1.5                                     # e > 1
     out = post.lnprob_batch(P)
     assert out.tolist() == [-3.0, -np.inf, -3.0, -3.0, -np.inf]
-    assert seen == [2, 1, 2, 1]                       # 3 rows evaluated per chunk, in max_batch pieces
+    assert seen == [2, 2, 1, 1]                       # 3 rows evaluated per chunk, in max_batch pieces (piece-major)
     seen.clear()
     assert post.lnprob_batch(P[[1, 4]]).tolist() == [-np.inf, -np.inf] and seen == []
 
