@@ -211,6 +211,22 @@ def main():
     mh_value = 4 * B / (time.perf_counter() - t3)
     worker.close()
 
+    # ---- BASELINE configs[3] on ONE GPU (rank 0, single-GPU runs only): 32 walkers x 8 chunks, all eight
+    # chunks factored by one launch of the persistent kernel over the heterogeneous batch (ChunkGroup).
+    # Reported beside `value`, never as `value`.
+    cfg4_value = None
+    if world == 1 and cfg == 3:
+        from psoap_amd.ensemble import EnsembleEvaluator
+        chunks8 = [syn.make_config_chunk(cfg, k) for k in range(8)]
+        props8 = {k: (np.repeat(chunks8[k].lwls[None], B, axis=0), gps) for k in range(8)}
+        ev8 = EnsembleEvaluator.from_chunks(chunks8, max_batch=B, device_index=local_rank)
+        ev8.lnprob(props8)
+        t4 = time.perf_counter()
+        for _ in range(2):
+            ev8.lnprob(props8)
+        cfg4_value = 2 * 8 * B / (time.perf_counter() - t4)
+        ev8.close()
+
     out = None
     if rank == 0:
         mb = microbench(local_rank)
@@ -253,6 +269,7 @@ def main():
             "pcie_inclusive_evals_per_s": pcie_value,
             "lnprob_of_p_evals_per_s": lnprob_p_value,
             "mh_sampler_evals_per_s": mh_value,
+            "cfg4_one_gpu_evals_per_s": cfg4_value,
             "lnprob_walker0": float(total[0]),
         }
         if world == 1 and not args.no_cpu_baseline:
