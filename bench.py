@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--groups", type=int, default=2, help="concurrent stream groups per batch (staged mode)")
     ap.add_argument("--mode", default="dag", choices=["dag", "staged"], help="execution mode of the batch eval")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cfg4", action="store_true",
+                    help="skip the 8-chunk ensemble on one GPU (profiling runs: keeps every k_chol_dag dispatch alike)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend (nccl = RCCL; gloo only for single-GPU dry runs of the N>1 path)")
     args = ap.parse_args()
@@ -215,7 +217,7 @@ def main():
     # chunks factored by one launch of the persistent kernel over the heterogeneous batch (ChunkGroup).
     # Reported beside `value`, never as `value`.
     cfg4_value = None
-    if world == 1 and cfg == 3:
+    if world == 1 and cfg == 3 and not args.no_cfg4:
         from psoap_amd.ensemble import EnsembleEvaluator
         chunks8 = [syn.make_config_chunk(cfg, k) for k in range(8)]
         props8 = {k: (np.repeat(chunks8[k].lwls[None], B, axis=0), gps) for k in range(8)}

@@ -7,7 +7,7 @@ def one(pattern):
     return g[0] if g else None
 
 print(f"# rocprofv3 summary {tag}\n")
-print("Command profiled: `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` on one MI355X (ROCm 7.2): 32 walkers x SB2")
+print("Command profiled: `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cfg4` on one MI355X (ROCm 7.2): 32 walkers x SB2")
 print("N=6000 per step.  k_chol_dag dispatches: 1 warm-up + 3 timed + 1 event-profiled + 3 PCIe-inclusive + 4 through the")
 print("lnprob(p) boundary + 4 driven by the multi-chain MH sampler; the staged kernels (k_panel_update / k_potrf_diag / k_trsm_strip / k_fill_sym) come from the one")
 print("staged step bench.py runs to time the stand-alone fill kernel; the k_stream_* / k_mfma_f64_peak / k_tile_engine_bench")
