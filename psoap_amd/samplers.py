@@ -147,6 +147,7 @@ class MultiChainMHSampler:
             raise ValueError("need one seed per chain")
         self._random = [s if isinstance(s, np.random.mtrand.RandomState) else np.random.mtrand.RandomState(s)
                         for s in seeds]
+        self._mvn_factor = None
         self.reset()
 
     def reset(self):
@@ -197,7 +198,14 @@ class MultiChainMHSampler:
                 q = np.stack([r.normal(loc=p[b, 0], scale=np.ravel(self.cov)[0], size=(1,))
                               for b, r in enumerate(self._random)])
             else:
-                q = np.stack([r.multivariate_normal(p[b], self.cov) for b, r in enumerate(self._random)])
+                # RandomState.multivariate_normal draws standard normals, then maps them through
+                # sqrt(s) * v of the covariance's SVD -- recomputed on every call.  The factor is the same
+                # for every chain and iteration, so it is computed once; the draws stay bit-identical.
+                if self._mvn_factor is None:
+                    _u, sv, v = np.linalg.svd(self.cov)
+                    self._mvn_factor = np.sqrt(sv)[:, None] * v
+                q = np.stack([np.dot(r.standard_normal(self.dim).reshape(-1, self.dim), self._mvn_factor)[0] + p[b]
+                              for b, r in enumerate(self._random)])
             newlnprob = self._eval(q)
             for b in range(self.n_chains):
                 diff = newlnprob[b] - lnprob[b]
