@@ -111,7 +111,6 @@ inline int calibrate_run(const CalibInputs& in, double* fl_cor, double* X, int* 
     const size_t ld1 = (size_t)Npad + Mpad;
     const size_t ld2 = (size_t)Mpad + NB;
     const int nslab = (Npad + 255) / 256;
-    const int Q = order + 2;
     const double scl = 2.0 / (in.lwl1 - in.lwl0);
     const double off = (in.lwl1 * -1.0 - in.lwl0 * 1.0) / (in.lwl1 - in.lwl0);   // numpy polyutils.mapparms
     *status = 0;
