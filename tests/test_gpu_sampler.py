@@ -76,3 +76,14 @@ def test_command_line_driver(tmp_path, monkeypatch):
     from psoap_amd import samplers
     mean, std, R = samplers.gelman_rubin([np.load(tmp_path / "output" / f"run{5 + b:02d}" / "flatchain.npy") for b in range(3)])
     assert mean.shape == (10,) and np.all(np.isfinite(mean))
+
+
+def test_quickstart_example(tmp_path):
+    """examples/quickstart.py end to end at a tiny size: files -> sampling -> R_hat -> opt_jump -> reconstruction."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import quickstart
+    sampler, res = quickstart.main([str(tmp_path / "work"), "--chunks", "2", "--chains", "3", "--samples", "8"])
+    assert sampler.chain.shape == (3, 8, 10)
+    assert (tmp_path / "work" / "opt_jump.npy").exists()
+    assert (tmp_path / "work" / "plots_chunk_20_5100_5110" / "f.npy").exists()
+    assert np.all(np.isfinite(res["mu"]))
