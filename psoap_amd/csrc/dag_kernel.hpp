@@ -585,20 +585,35 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
     }
 }
 
-// scheme: 0 throughput, 1 latency (dag_emit), -1 automatic: latency while the batch is small enough that
-// the row-to-row dependency chain, not the MFMA work, bounds the run time.  Measured crossover on
-// MI355X (tools/scheme_table.py; N = 2000 .. 8192, B = 1 .. 32): about 20,000 tiles in the batch --
-// e.g. N = 6000: latency wins up to B = 16 (B = 1: 14.9 -> 7.7 ms, B = 8: 19.5 -> 14.8 ms), throughput
-// from B = 24 (B = 32: 39.5 vs 40.3 ms).  (Readiness ordering was also tried for the throughput scheme:
-// 800 -> 776 evals/s, not adopted.)
-constexpr long long DAG_LATENCY_TILES = 20000;
+// scheme: 0 throughput, 1 latency (dag_emit), -1 automatic: latency while the row-to-row dependency chain,
+// not the MFMA work, bounds the run time -- i.e. while a queue has too few block rows in flight to hide the
+// wait for the row above.  Measured on MI355X (tools/scheme_table.py, tools/multichunk_bench.py;
+// N = 2000 .. 8192, B = 1 .. 256): latency wins when the block rows of the matrices of the fullest queue
+// add up to at most ~100 (N = 6000: up to B = 16; B = 1: 14.9 -> 7.3 ms, B = 8: 19.5 -> 14.8 ms), or when
+// no queue holds more than one matrix; throughput otherwise (N = 6000, B = 32: 39.5 vs 40.3 ms).
+// (Readiness ordering was also tried for the throughput scheme: 800 -> 776 evals/s, not adopted.)
+constexpr int DAG_LATENCY_QUEUE_ROWS = 100;
+inline int dag_auto_scheme(const std::vector<int>& Ps)
+{
+    long long rows[DAG_QUEUES] = {};
+    int count[DAG_QUEUES] = {};
+    for (size_t b = 0; b < Ps.size(); ++b) {
+        rows[b % DAG_QUEUES] += Ps[b];
+        ++count[b % DAG_QUEUES];
+    }
+    long long max_rows = 0;
+    int max_count = 0;
+    for (int g = 0; g < DAG_QUEUES; ++g) {
+        max_rows = rows[g] > max_rows ? rows[g] : max_rows;
+        max_count = count[g] > max_count ? count[g] : max_count;
+    }
+    return (max_rows <= DAG_LATENCY_QUEUE_ROWS || max_count <= 1) ? 1 : 0;
+}
 inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int scheme = -1, int Mt = 0)
 {
     DagPlan plan;
     const int B = (int)Ps.size();
-    long long tiles = 0;
-    for (int P : Ps) tiles += (long long)P * (P + 1) / 2 + (long long)P * Mt;
-    if (scheme < 0) scheme = (tiles <= DAG_LATENCY_TILES) ? 1 : 0;
+    if (scheme < 0) scheme = dag_auto_scheme(Ps);
     // workgroups of XCDs whose own queue is empty steal, so the workers are shared by the queues in use
     const int used = B < DAG_QUEUES ? (B > 0 ? B : 1) : DAG_QUEUES;
     const int per_queue = workers / used > 0 ? workers / used : 1;
