@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark: GP lnprob evaluations per second, SB2 chunk at N = 6000.
 
-One "step" = one ensemble step of the hot path on every rank: the rank's own SB2
-chunk (20 epochs x 300 px, N = 6000; BASELINE.json configs[2]/[3]) is evaluated for a
-batch of 32 walkers (fill -> +sigma^2 -> Cholesky -> solve -> logdet -> lnprob), then
-the per-(walker, chunk) lnprobs are gathered over RCCL and summed in fixed chunk order
-(the gather-and-sum of psoap/sample_parallel.py:378-387).  Chunks are independent, so
-per-GPU work is fixed as N grows ("weak"); at 8 GPUs a step is exactly the 32-walker x
-8-chunk ensemble of configs[3].
+One "step" = one ensemble step of the hot path on every rank: the proposals of the NEXT step
+(32 walkers x 2 components x 6000 ln-wavelengths = 3 MB) are copied from host memory to the GPU
+while the rank's SB2 chunk (20 epochs x 300 px, N = 6000; BASELINE.json configs[2]/[3]) is
+evaluated for the current 32 walkers (fill -> +sigma^2 -> Cholesky -> solve -> logdet -> lnprob),
+the 32 lnprobs come back to the host, and the per-(walker, chunk) lnprobs are gathered over RCCL
+and summed in fixed chunk order (the gather-and-sum of psoap/sample_parallel.py:378-387).
+So `value` INCLUDES the per-step H2D of c*N doubles per proposal and the D2H of the results
+(BASELINE.md section 4); the proposals-resident rate is reported beside it.
+Chunks are independent, so per-GPU work is fixed as N grows ("weak"); at 8 GPUs a step is exactly
+the 32-walker x 8-chunk ensemble of configs[3].
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
-    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 ...
+    python bench.py                      # 1 GPU
+    python bench.py --gpus 8             # spawns 8 ranks itself (torch.distributed.run, RCCL)
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8     # or under a launcher
+    python bench.py --gpus 2 --backend gloo    # dry run of the N>1 path on a 1-GPU box
 
-Rank 0 prints ONE JSON line.  Proposals are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.  Every reported lnprob is checked against the committed golden values
+of the reference (tests/golden/*.npz) and, at N = 1, against the CPU baseline timed beside it.
 """
 import argparse
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,6 +38,7 @@ from psoap_amd import synthetic as syn  # noqa: E402
 
 PEAK_FP64_TFLOPS = 78.6   # MI355X spec, fp64 matrix == fp64 vector
 N_WALKERS = 32
+PARITY_RTOL = 1e-10       # |dlnp| <= 1e-10 max(1, |lnp|), the contract of SURVEY.md section 8(c)
 
 
 def flops_eval(N: int) -> float:
@@ -43,6 +52,20 @@ def flops_panel_update(N: int, nb: int = 128) -> float:
     i = np.arange(N, dtype=np.float64)
     k0 = nb * np.floor(i / nb)
     return float(np.sum(2.0 * k0 * (N - i)))
+
+
+def close(a, b, rtol=PARITY_RTOL) -> bool:
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return bool(np.all(np.abs(a - b) <= rtol * np.maximum(1.0, np.abs(b))))
+
+
+def require(ok: bool, what: str):
+    if not ok:
+        raise SystemExit(f"bench.py: PARITY FAILURE: {what}")
+
+
+def golden(name: str):
+    return np.load(os.path.join(ROOT, "tests", "golden", name), allow_pickle=False)
 
 
 def cpu_baseline(chunk, n_evals: int = 14):
@@ -66,11 +89,40 @@ def cpu_baseline(chunk, n_evals: int = 14):
         val = oracle.lnlike(chunk.lwls, chunk.fl, chunk.sigma, gp, V11=V11)
         ts.append(time.perf_counter() - t0)
     med = float(np.median(ts))
+    # the Cython-equivalent fill alone (matrix_functions.pyx:99-146), for the fill drop-in comparison
+    tf = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        oracle.fill_V11_f_g(V11, chunk.lwls[0], chunk.lwls[1], *gp)
+        tf.append(time.perf_counter() - t0)
     return {"value": 1.0 / med, "unit": "evals/s", "cores": int(threads), "kind": "port",
             "sample": f"{n_evals} evals of lnlike_f_g on the same N={chunk.N} SB2 chunk after 1 warm-up, "
                       f"median {med:.3f} s/eval; C fill (1 thread) + SciPy/OpenBLAS dpotrf/dpotrs "
                       f"({threads} threads); host has {os.cpu_count()} cores",
-            "lnprob": float(val)}
+            "lnprob": float(val), "fill_ms": 1e3 * float(np.median(tf))}
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as children (one process per
+    GPU under torch.distributed.run) BEFORE this process touches the GPU, relay rank 0's JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return proc.returncode if proc.returncode != 0 else (0 if line is not None else 1)
 
 
 def main():
@@ -79,15 +131,17 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--walkers", type=int, default=N_WALKERS)
-    ap.add_argument("--config", type=int, default=3, help="BASELINE.json config shape (3 = SB2 N=6000)")
     ap.add_argument("--groups", type=int, default=2, help="concurrent stream groups per batch (staged mode)")
     ap.add_argument("--mode", default="dag", choices=["dag", "staged"], help="execution mode of the batch eval")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-cfg4", action="store_true",
-                    help="skip the 8-chunk ensemble on one GPU (profiling runs: keeps every k_chol_dag dispatch alike)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed loop + roofline (profiling runs: keeps every k_chol_dag dispatch alike)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend (nccl = RCCL; gloo only for single-GPU dry runs of the N>1 path)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -96,7 +150,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if args.backend == "gloo":       # dry run: several ranks may share one GPU
@@ -110,47 +164,95 @@ def main():
             dist.init_process_group(backend="gloo")
 
     from psoap_amd.chunk import ChunkHandle, microbench
-    from psoap_amd.ensemble import gather_and_sum
+    from psoap_amd.ensemble import gather_chunk_lnprobs, sum_over_chunks
 
-    # ---- workload: this rank's chunk + the walker ensemble (identical on every rank by seeding)
-    cfg = args.config
+    # ---- workload.  One GPU: the configs[2] chunk (seed 3000).  N GPUs: rank r owns chunk r of the
+    # configs[3] ensemble (seeds 4000 + r); walkers identical on every rank by seeding.
+    cfg = 3 if world == 1 else 4
     chunk = syn.make_config_chunk(cfg, chunk_index=rank)
     c, N, B = chunk.n_components, chunk.N, args.walkers
     gps = syn.make_walkers(c, B, seed=1000 * cfg + 500)
     vels = syn.make_walker_velocities(chunk, B, seed=1000 * cfg + 501 + rank)
-    lwls = syn.walker_lwls(chunk, vels)
+    lwls_a = syn.walker_lwls(chunk, vels)
+    # a second proposal set (walkers rotated by one) so that consecutive steps upload different bytes
+    lwls_b, gps_b = np.roll(lwls_a, 1, axis=0).copy(), np.roll(gps, 1, axis=0).copy()
+    sets = [(lwls_a, gps), (lwls_b, gps_b)]
 
     h = ChunkHandle(chunk.fl, chunk.sigma, max_batch=B, device=local_rank)
     h.set_stream_groups(args.groups)
     h.set_mode(args.mode)
-    h.upload(lwls, gps)          # proposals resident in HBM before the timed region
-    h.sync()
+
+    def gather(lnp):
+        table = gather_chunk_lnprobs(lnp[None, :], world, world, rank, local_rank)   # (n_chunks, B)
+        return table, sum_over_chunks(table)
+
+    state = {"k": 0}
 
     def step():
+        """eval(k) || upload(k+1), fetch(k), gather.  One H2D, one evaluation, one D2H per step."""
         h.eval()
-        lnp = h.fetch()                                  # (B,) this chunk's lnprob per walker
-        return gather_and_sum(lnp, world, local_rank)    # (B,) summed over chunks, fixed order
+        state["k"] += 1
+        h.upload(*sets[state["k"] & 1])
+        return gather(h.fetch())
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        h.sync()
 
+    h.upload(*sets[0])
     for _ in range(args.warmup):
-        total = step()
+        table, total = step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        total = step()
+        table, total = step()
     fence()
     dt = time.perf_counter() - t0
+    last_set = (state["k"] - 1) & 1          # the proposal set of the last evaluated step
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-
     evals = world * B * args.steps
     value = evals / dt
+    if last_set == 1:                        # back to walker order
+        table, total = np.roll(table, -1, axis=1), np.roll(total, -1)
+
+    # ---- parity gate on what the timed loop produced (reference goldens, no tolerance games)
+    parity = {}
+    if world == 1:
+        g1 = golden("golden_v1.npz")
+        want0 = float(g1["lnlike_vals"][list(g1["lnlike_names"]).index("cfg3_sb2_n6000")])
+        require(close(total[0], want0), f"walker 0 {total[0]!r} vs reference golden {want0!r}")
+        parity["golden_cfg3_walker0"] = want0
+        # the reference's 4-walker batch on this chunk is a prefix of the ensemble (same seeds, drawn in order)
+        nw = min(B, len(g1["walkers_cfg3"]))
+        require(close(total[:nw], g1["walkers_cfg3"][:nw]), f"walkers {total[:nw]} vs reference goldens")
+        parity["golden_cfg3_walkers"] = nw
+    else:
+        gf = golden("golden_full_v1.npz")["cfg4_lnlike"]             # (8 chunks, 4 walkers)
+        nk, nw = min(world, gf.shape[0]), min(B, gf.shape[1])
+        require(close(table[:nk, :nw], gf[:nk, :nw]),
+                f"gathered (chunk, walker) table differs from the reference goldens: {table[:nk, :nw]} vs {gf[:nk, :nw]}")
+        parity["golden_cfg4_table"] = [nk, nw]
+
+    # ---- proposals-resident rate (the round-1 headline; never `value`): eval + fetch + gather only
+    h.upload(*sets[0])
+    h.eval(); h.fetch()
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        h.eval()
+        gather(h.fetch())
+    fence()
+    dt_res = time.perf_counter() - t1
+    if world > 1:
+        tmax = torch.tensor([dt_res], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt_res = float(tmax.item())
+    resident_value = evals / dt_res
 
     # ---- live per-kernel timing (HIP events on the launch stream) for the roofline object
     h.set_profiling(True)
@@ -169,67 +271,13 @@ def main():
         alg_per_launch = B * flops_panel_update(N) / max(1, dom["launches"])
     avg_ms = dom["ms"] / max(1, dom["launches"])
     achieved = alg_per_launch / (avg_ms * 1e-3) / 1e12
-    fill = tm["fill"]
-    if mode == "dag":
-        # the persistent kernel evaluates K on the fly; time the standalone HBM-bound fill kernel
-        # (the fill_V11_* drop-in and the staged path use it) with one event-profiled staged step
-        h.set_mode("staged")
-        h.set_profiling(True)
-        h.eval()
-        h.fetch()
-        fill = h.timings()["fill"]
-        h.set_profiling(False)
-        h.set_mode("dag")
-
-    # ---- PCIe-inclusive rate (never `value`): proposals uploaded from host memory every step
-    t1 = time.perf_counter()
-    for _ in range(3):
-        h.upload(lwls, gps)
-        h.eval()
-        h.fetch()
-    pcie_value = 3 * B / (time.perf_counter() - t1)
-
-    # ---- the lnprob(p) boundary: orbital parameters in, lnprob out; Kepler solve,
-    # Doppler shift and likelihood all on the device.  Reported beside `value`, never as `value`.
-    from psoap_amd.lnprob import ChunkWorker
-    h.close()
-    model = {1: "SB1", 2: "SB2", 3: "ST3"}[c]
-    worker = ChunkWorker(model, chunk.lwl, chunk.fl, chunk.sigma, chunk.epoch_index, chunk.dates, max_batch=B,
-                         device=local_rank)
-    pfit = np.hstack([syn.make_orbit_proposals(model, B, seed=1000 * cfg + 502), gps])
-    worker.lnprob_batch(pfit)
-    t2 = time.perf_counter()
-    for _ in range(3):
-        worker.lnprob_batch(pfit)
-    lnprob_p_value = 3 * B / (time.perf_counter() - t2)
-
-    # ---- the sampler boundary (8(f) f-2): B Metropolis-Hastings chains in lock-step on that worker,
-    # proposals drawn on the host, one batched device evaluation per iteration.
-    from psoap_amd.samplers import MultiChainMHSampler
-    mh = MultiChainMHSampler(1e-6 * np.eye(pfit.shape[1]), pfit.shape[1], worker.lnprob_batch, B,
-                             seeds=[7000 + b for b in range(B)])
-    t3 = time.perf_counter()
-    mh.run_mcmc(pfit, 3)                              # 1 starting + 3 proposal evaluations of B chains
-    mh_value = 4 * B / (time.perf_counter() - t3)
-    worker.close()
-
-    # ---- BASELINE configs[3] on ONE GPU (rank 0, single-GPU runs only): 32 walkers x 8 chunks, all eight
-    # chunks factored by one launch of the persistent kernel over the heterogeneous batch (ChunkGroup).
-    # Reported beside `value`, never as `value`.
-    cfg4_value = None
-    if world == 1 and cfg == 3 and not args.no_cfg4:
-        from psoap_amd.ensemble import EnsembleEvaluator
-        chunks8 = [syn.make_config_chunk(cfg, k) for k in range(8)]
-        props8 = {k: (np.repeat(chunks8[k].lwls[None], B, axis=0), gps) for k in range(8)}
-        ev8 = EnsembleEvaluator.from_chunks(chunks8, max_batch=B, device_index=local_rank)
-        ev8.lnprob(props8)
-        t4 = time.perf_counter()
-        for _ in range(2):
-            ev8.lnprob(props8)
-        cfg4_value = 2 * 8 * B / (time.perf_counter() - t4)
-        ev8.close()
 
     out = None
+    extras = {}
+    if world == 1 and not args.no_extras:
+        extras = run_extras(args, h, chunk, gps, lwls_a, local_rank, mode)
+    h.close()
+
     if rank == 0:
         mb = microbench(local_rank)
         traffic, traffic_src = None, None
@@ -244,10 +292,17 @@ def main():
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "rccl_ranks": world if (world > 1 and args.backend == "nccl") else (0 if world > 1 else 1),
+            "backend": args.backend if world > 1 else None,
             "config": {"workload": f"SB2 chunk 20 epochs x 300 px (N={N}), {B} walkers per step per GPU, "
-                                   f"one chunk per GPU (BASELINE.json configs[2]; configs[3] at 8 GPUs)",
-                       "N": N, "components": c, "walkers": B, "chunks_per_gpu": 1, "mode": args.mode, "stream_groups": args.groups,
+                                   f"one chunk per GPU (BASELINE.json configs[2]; configs[3] at 8 GPUs); "
+                                   f"timed step = H2D of next proposals || eval, D2H of {B} lnprobs, gather",
+                       "N": N, "components": c, "walkers": B, "chunks_per_gpu": 1, "mode": args.mode,
+                       "stream_groups": args.groups,
                        "parallelism": f"chunk-sharded x{world}, RCCL all_gather of walker lnprobs"},
+            "timing_boundary": "pcie_inclusive (per-step H2D of B*c*N doubles double-buffered under the previous eval)",
+            "resident_evals_per_s": resident_value,
+            "inclusive_over_resident": value / resident_value,
             "roofline": {"bound": "mfma", "kernel": dom_name,
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
@@ -260,27 +315,136 @@ def main():
                               "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                               "frac": value / world * flops_eval(N) / 1e12 / PEAK_FP64_TFLOPS,
                               "flops_per_eval": flops_eval(N)},
-            "roofline_fill": {"bound": "hbm", "kernel": "k_fill_sym<2> (upper tiles)",
-                              "achieved": fill["bytes"] / (fill["ms"] * 1e-3) / 1e9 if fill["ms"] > 0 else None,
-                              "peak": 8000.0, "unit": "GB/s",
-                              "frac": fill["bytes"] / (fill["ms"] * 1e-3) / 1e9 / 8000.0 if fill["ms"] > 0 else None,
-                              "measured_write_peak": mb["hbm_write_gbs"]},
             "kernel_ms_profiled_step": {k: round(tm[k]["ms"], 3) for k in
                                         ("fill", "panel_update", "potrf", "trsm", "misc", "dag")},
             "profiled_step_total_ms": tm["total_ms"],
-            "pcie_inclusive_evals_per_s": pcie_value,
-            "lnprob_of_p_evals_per_s": lnprob_p_value,
-            "mh_sampler_evals_per_s": mh_value,
-            "cfg4_one_gpu_evals_per_s": cfg4_value,
             "lnprob_walker0": float(total[0]),
+            "parity_checked": True, "parity": parity,
         }
+        out.update(extras)
+        if "roofline_fill" in extras:
+            out["roofline_fill"]["measured_write_peak"] = mb["hbm_write_gbs"]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(chunk)
-            out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
+            cb = cpu_baseline(chunk)
+            require(close(total[0], cb["lnprob"]), f"walker 0 {total[0]!r} vs CPU baseline {cb['lnprob']!r}")
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu"] = value / cb["value"]
+            if "fill_dropin_ms" in out:
+                out["fill_dropin_vs_cpu_fill"] = cb["fill_ms"] / out["fill_dropin_ms"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_extras(args, h, chunk, gps, lwls, dev, mode):
+    """Side measurements of a single-GPU run (never `value`): the stand-alone fill kernel and its drop-in,
+    the lnprob(p) and sampler boundaries, configs[3] on one GPU, configs[4]'s reconstruction."""
+    from psoap_amd import matrix_functions
+    from psoap_amd.chunk import ChunkHandle
+    from psoap_amd.ensemble import EnsembleEvaluator
+    from psoap_amd.lnprob import ChunkWorker
+    from psoap_amd.samplers import MultiChainMHSampler
+    c, N, B = chunk.n_components, chunk.N, args.walkers
+    ex = {}
+
+    # the HBM-bound stand-alone fill kernel (fill_V11_* drop-in, staged path, predict) by one
+    # event-profiled staged step
+    h.set_mode("staged")
+    h.set_profiling(True)
+    h.eval()
+    h.fetch()
+    fill = h.timings()["fill"]
+    h.set_profiling(False)
+    h.set_mode(mode)
+    gbs = fill["bytes"] / (fill["ms"] * 1e-3) / 1e9 if fill["ms"] > 0 else None
+    ex["roofline_fill"] = {"bound": "hbm", "kernel": f"k_fill_sym<{c}> (upper tiles)", "achieved": gbs, "peak": 8000.0,
+                           "unit": "GB/s", "frac": gbs / 8000.0 if gbs else None}
+    # the drop-in itself, end to end: fill_V11_f_g(mat, ...) into the caller's host matrix (288 MB over PCIe)
+    mat = np.empty((N, N))
+    matrix_functions.fill_V11_f_g(mat, chunk.lwls[0], chunk.lwls[1], *syn.GP_BASE[2])
+    tfs = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        matrix_functions.fill_V11_f_g(mat, chunk.lwls[0], chunk.lwls[1], *syn.GP_BASE[2])
+        tfs.append(time.perf_counter() - t0)
+    ex["fill_dropin_ms"] = 1e3 * float(np.median(tfs))
+    require(bool(np.array_equal(mat, mat.T)), "fill_V11_f_g drop-in: matrix not symmetric")
+    del mat
+
+    # the lnprob(p) boundary (SURVEY.md 8(f) f-1): orbital parameters in, lnprob out
+    model = {1: "SB1", 2: "SB2", 3: "ST3"}[c]
+    worker = ChunkWorker(model, chunk.lwl, chunk.fl, chunk.sigma, chunk.epoch_index, chunk.dates, max_batch=B,
+                         device=dev)
+    pfit = np.hstack([syn.make_orbit_proposals(model, B, seed=3502), gps])
+    worker.lnprob_batch(pfit)
+    t2 = time.perf_counter()
+    for _ in range(3):
+        worker.lnprob_batch(pfit)
+    ex["lnprob_of_p_evals_per_s"] = 3 * B / (time.perf_counter() - t2)
+    # the sampler boundary (8(f) f-2): B Metropolis-Hastings chains in lock-step on that worker
+    mh = MultiChainMHSampler(1e-6 * np.eye(pfit.shape[1]), pfit.shape[1], worker.lnprob_batch, B,
+                             seeds=[7000 + b for b in range(B)])
+    t3 = time.perf_counter()
+    mh.run_mcmc(pfit, 3)                              # 1 starting + 3 proposal evaluations of B chains
+    ex["mh_sampler_evals_per_s"] = 4 * B / (time.perf_counter() - t3)
+    worker.close()
+
+    # BASELINE configs[3] on ONE GPU: 32 walkers x 8 chunks (seeds 4000..4007), all eight chunks factored by
+    # one launch of the persistent kernel over the heterogeneous batch (ChunkGroup); checked against the
+    # reference's per-(chunk, walker) goldens
+    chunks8 = [syn.make_config_chunk(4, k) for k in range(8)]
+    gps4 = syn.make_walkers(2, B, seed=4500)
+    props8 = {k: (syn.walker_lwls(chunks8[k], syn.make_walker_velocities(chunks8[k], B, seed=4501 + k)), gps4)
+              for k in range(8)}
+    ev8 = EnsembleEvaluator.from_chunks(chunks8, max_batch=B, device_index=dev)
+    tot8 = ev8.lnprob(props8)
+    t4 = time.perf_counter()
+    for _ in range(2):
+        tot8 = ev8.lnprob(props8)
+    dt4 = time.perf_counter() - t4
+    ex["cfg4_one_gpu_evals_per_s"] = 2 * 8 * B / dt4
+    ex["cfg4_one_gpu_tflops"] = ex["cfg4_one_gpu_evals_per_s"] * flops_eval(N) / 1e12
+    ex["cfg4_one_gpu_frac"] = ex["cfg4_one_gpu_tflops"] / PEAK_FP64_TFLOPS
+    gf = golden("golden_full_v1.npz")["cfg4_lnlike"]
+    nw = min(B, gf.shape[1])
+    tab8 = np.stack([ev8.handles[k].fetch() for k in range(8)])
+    require(close(tab8[:, :nw], gf[:, :nw]), "configs[3] on one GPU: (chunk, walker) table vs reference goldens")
+    want = np.zeros(nw)
+    for k in range(8):
+        want = want + gf[k, :nw]
+    require(close(tot8[:nw], want), "configs[3] on one GPU: walker sums vs reference goldens")
+    ev8.close()
+
+    # BASELINE configs[4]: predict_f_g_h at the retrieve shape (N = 8192, M = 2 n_pix = 1024), handle-resident
+    ch5 = syn.make_config_chunk(5)
+    M5 = 2 * ch5.n_pix
+    pred = np.linspace(np.min(ch5.lwls[0]), np.max(ch5.lwls[0]), num=M5)
+    h5 = ChunkHandle(ch5.fl, ch5.sigma, max_batch=1, device=dev)
+    args5 = (0, ch5.lwls, np.stack([pred] * 3), np.zeros(3), syn.GP_BASE[3])
+    mu5, Sig5 = h5.predict(*args5)          # first call: allocates the workspace
+    t_first = h5.predict_timings()
+    best = None
+    for _ in range(3):
+        mu5, Sig5 = h5.predict(*args5)
+        t = h5.predict_timings()
+        if best is None or t["total_ms"] < best["total_ms"]:
+            best = t
+    gf5 = golden("golden_full_v1.npz")
+    require(float(np.max(np.abs(mu5 - gf5["cfg5_pred_mu"]))) <= 1e-10, "predict cfg5: mu vs reference golden")
+    require(float(np.max(np.abs(np.diag(Sig5) - gf5["cfg5_pred_diag"]))) <= 1e-9, "predict cfg5: diag(Sigma)")
+    require(float(np.max(np.abs(Sig5[gf5["cfg5_pred_row_index"]] - gf5["cfg5_pred_rows"]))) <= 1e-9,
+            "predict cfg5: Sigma rows")
+    tf = best["flops"] / (best["device_ms"] * 1e-3) / 1e12
+    ex["predict_cfg5"] = {
+        "workload": f"predict_f_g_h, N={ch5.N}, M={M5} (R = {3 * M5} prediction columns), handle-resident workspace",
+        "device_ms": best["device_ms"], "factor_ms": best["factor_ms"], "mean_and_sigma_ms": best["sigma_ms"],
+        "sigma_download_ms": best["download_ms"], "total_ms": best["total_ms"], "first_call_total_ms": t_first["total_ms"],
+        "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tf / PEAK_FP64_TFLOPS, "algorithmic_flops": best["flops"]},
+        "parity_checked": True}
+    h5.close()
+    return ex
 
 
 if __name__ == "__main__":

@@ -60,9 +60,15 @@ int psoap_lnlike(psoap_chunk *h, int c, const double *lwl, const double *gp,
 int psoap_lnlike_batch(psoap_chunk *h, int B, int c, const double *lwl,
                        const double *gp, double mu_GP, double *out);
 
-/* Split-phase form of psoap_lnlike_batch: upload (H2D, async), eval (kernels
- * only, async), fetch (sync + D2H of B doubles).  bench.py times eval+fetch with
- * the proposals already resident in HBM. */
+/* Split-phase form of psoap_lnlike_batch: upload (H2D, async, on a copy stream of
+ * its own), eval (kernels only, async), fetch (sync + D2H of B doubles).
+ * A handle holds TWO proposal batches: an upload always goes to the one that is
+ * not being evaluated, and eval consumes the most recent upload (or re-evaluates
+ * the current batch when nothing new was uploaded).  So
+ *     upload(0); loop { eval(); upload(k+1); fetch() -> results of k }
+ * moves the proposals of step k+1 over PCIe while step k is being factored
+ * (bench.py's timed step: one upload, one eval, one fetch), and the plain
+ * upload / eval / fetch sequence keeps working unchanged. */
 int psoap_batch_upload(psoap_chunk *h, int B, int c, const double *lwl,
                        const double *gp, double mu_GP);
 /* Same, but the Doppler shift runs on the device: vel (B, c, n_epochs) km/s,
@@ -113,6 +119,36 @@ int psoap_predict(int device, int mode, int c, int N, int M, const double *lwl,
                   const double *fl, const double *sigma, const double *lwl_pred,
                   const double *mu_c, const double *gp, double *mu_out,
                   double *Sigma_out, int *status_out);
+/* The same on a chunk handle (fl, sigma and N are the handle's): every device
+ * buffer lives in a grow-only workspace owned by the handle, so the retrieve loop
+ * (scripts/psoap_retrieve_ST3.py:148, one predict per chunk) allocates once.
+ * psoap_chunk_predict_release frees that workspace early (destroy frees it too). */
+int psoap_chunk_predict(psoap_chunk *h, int mode, int c, int M, const double *lwl,
+                        const double *lwl_pred, const double *mu_c, const double *gp,
+                        double *mu_out, double *Sigma_out, int *status_out);
+int psoap_chunk_predict_release(psoap_chunk *h);
+/* Timings of the handle's last predict call, in ms: device_ms = first upload ->
+ * mu and Sigma complete on the device (HIP events), factor_ms = the persistent
+ * launch over [B | Cx^T], sigma_ms = mean + prior fill + Sigma = A - W^T W,
+ * download_ms = Sigma D2H into the caller's array, total_ms = the whole call
+ * (host clock); flops = N^3/3 + N^2 R + N R^2 + 2 N R (SURVEY.md 8(d) F_pred,
+ * padded sizes, R = prediction columns). */
+typedef struct {
+    double device_ms, factor_ms, sigma_ms, download_ms, total_ms, flops;
+} psoap_predict_timings;
+int psoap_chunk_predict_timings(psoap_chunk *h, psoap_predict_timings *t);
+/* A reusable predict workspace that is not tied to a chunk: fl and sigma travel with
+ * every call (2 N doubles), all N^2-sized buffers are kept and only grow.  One
+ * predictor serves the whole retrieve loop (chunk after chunk); psoap_predict is
+ * this with a workspace created and destroyed inside the call. */
+typedef struct psoap_predictor psoap_predictor;
+int psoap_predictor_create(psoap_predictor **out, int device);
+int psoap_predictor_run(psoap_predictor *p, int mode, int c, int N, int M,
+                        const double *lwl, const double *fl, const double *sigma,
+                        const double *lwl_pred, const double *mu_c, const double *gp,
+                        double *mu_out, double *Sigma_out, int *status_out);
+int psoap_predictor_timings(psoap_predictor *p, psoap_predict_timings *t);
+int psoap_predictor_destroy(psoap_predictor *p);
 
 /* ---- calibration ---------------------------------------------
  * Chebyshev re-normalisation of one epoch's flux against reference epochs:

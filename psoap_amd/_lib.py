@@ -26,6 +26,13 @@ class Timings(ctypes.Structure):
                 ("total_ms", ctypes.c_double)]
 
 
+class PredictTimings(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_double) for k in ("device_ms", "factor_ms", "sigma_ms", "download_ms", "total_ms", "flops")]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class PsoapError(RuntimeError):
     pass
 
@@ -54,6 +61,15 @@ SIGNATURES = {
                                         ctypes.c_double, _dp]),
     "psoap_predict": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp,
                                      _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
+    "psoap_chunk_predict": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp,
+                                           _ip]),
+    "psoap_chunk_predict_release": (ctypes.c_int, [_vp]),
+    "psoap_chunk_predict_timings": (ctypes.c_int, [_vp, ctypes.POINTER(PredictTimings)]),
+    "psoap_predictor_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int]),
+    "psoap_predictor_run": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp,
+                                           _dp, _dp, _dp, _dp, _dp, _ip]),
+    "psoap_predictor_timings": (ctypes.c_int, [_vp, ctypes.POINTER(PredictTimings)]),
+    "psoap_predictor_destroy": (ctypes.c_int, [_vp]),
     "psoap_calibrate": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_double, ctypes.c_double, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp,
                                        ctypes.c_double, _dp, _dp, _ip]),

@@ -126,6 +126,33 @@ class ChunkHandle:
     def sync(self):
         check(self._L.psoap_chunk_sync(self._h), "psoap_chunk_sync")
 
+    def predict(self, mode: int, lwls, lwls_predict, mu_c, gp, want_sigma: bool = True):
+        """``predict_*`` on this chunk's resident ``fl`` / ``sigma`` (include/psoap_gp.h: psoap_chunk_predict;
+        mode 0 components, 1 sum, 2 predict_f).  The workspace stays with the handle."""
+        lwls = as_f64(np.atleast_2d(lwls))
+        pred = as_f64(np.atleast_2d(lwls_predict))
+        c = lwls.shape[0]
+        lwls = as_f64(lwls, (c, self.N))
+        M = pred.shape[1]
+        pred = as_f64(pred, (c, M))
+        mu_c = as_f64(mu_c)
+        gp = as_f64(gp, (2 * c,))
+        R = c * M if mode == 0 else M
+        mu = np.empty(R)
+        Sigma = np.empty((R, R)) if want_sigma else None
+        status = ctypes.c_int(0)
+        check(self._L.psoap_chunk_predict(self._h, int(mode), c, M, dptr(lwls), dptr(pred), dptr(mu_c), dptr(gp),
+                                          dptr(mu), None if Sigma is None else dptr(Sigma), ctypes.byref(status)),
+              "psoap_chunk_predict")
+        if status.value != 0:
+            raise np.linalg.LinAlgError("data covariance matrix is not positive definite")
+        return (mu, Sigma) if want_sigma else mu
+
+    def predict_timings(self) -> dict:
+        t = _lib.PredictTimings()
+        check(self._L.psoap_chunk_predict_timings(self._h, ctypes.byref(t)), "psoap_chunk_predict_timings")
+        return t.as_dict()
+
     def timings(self) -> dict:
         t = Timings()
         check(self._L.psoap_chunk_get_timings(self._h, ctypes.byref(t)), "psoap_chunk_get_timings")

@@ -50,10 +50,35 @@ def _chunk_for(fl, sigma) -> ChunkHandle:
 
 
 def release_handles():
-    """Free every cached device chunk."""
+    """Free every cached device chunk and the predict workspaces."""
     while _handles:
         _, h = _handles.popitem()
         h.close()
+    while _predictors:
+        _, p = _predictors.popitem()
+        _lib.load().psoap_predictor_destroy(p)
+
+
+# one reusable predict workspace per device: the retrieve loop predicts chunk after chunk
+# (scripts/psoap_retrieve_ST3.py:148) and allocates only when a chunk outgrows the previous ones
+_predictors: dict = {}
+
+
+def _predictor():
+    dev = _lib.default_device()
+    p = _predictors.get(dev)
+    if p is None:
+        p = ctypes.c_void_p()
+        check(_lib.load().psoap_predictor_create(ctypes.byref(p), dev), "psoap_predictor_create")
+        _predictors[dev] = p
+    return p
+
+
+def last_predict_timings() -> dict:
+    """Timings (ms) and algorithmic flops of the last ``predict_*`` call on the default device."""
+    t = _lib.PredictTimings()
+    check(_lib.load().psoap_predictor_timings(_predictor(), ctypes.byref(t)), "psoap_predictor_timings")
+    return t.as_dict()
 
 
 def _lnlike(lwls, fl, sigma, gp, mu_GP):
@@ -93,10 +118,10 @@ def _predict(mode, lwls, fl, sigma, lwls_predict, mu_c, gp, want_sigma=True):
     mu = np.empty(R)
     Sigma = np.empty((R, R)) if want_sigma else None
     status = ctypes.c_int(0)
-    check(_lib.load().psoap_predict(_lib.default_device(), mode, c, N, M, dptr(lwls), dptr(fl), dptr(sigma),
-                                    dptr(pred), dptr(mu_c), dptr(gp), dptr(mu),
-                                    None if Sigma is None else dptr(Sigma), ctypes.byref(status)),
-          "psoap_predict")
+    check(_lib.load().psoap_predictor_run(_predictor(), mode, c, N, M, dptr(lwls), dptr(fl), dptr(sigma),
+                                          dptr(pred), dptr(mu_c), dptr(gp), dptr(mu),
+                                          None if Sigma is None else dptr(Sigma), ctypes.byref(status)),
+          "psoap_predictor_run")
     if status.value != 0:
         # cho_factor raises here in the reference (covariance.py:113,182,222,292)
         raise np.linalg.LinAlgError("data covariance matrix is not positive definite")

@@ -101,6 +101,17 @@ struct CalibInputs {
     const double* C;  // (M, N)
 };
 
+// every failure leaves through the one cleanup block at `done`
+#define CAL_TRY(expr)                                                \
+    do {                                                             \
+        hipError_t _e = (expr);                                      \
+        if (_e != hipSuccess) {                                      \
+            err = std::string(#expr) + ": " + hipGetErrorString(_e); \
+            rc = 1;                                                  \
+            goto done;                                               \
+        }                                                            \
+    } while (0)
+
 // status: 0 ok, 1 B not positive definite, 2 C' not positive definite, 3 normal equations not positive definite
 inline int calibrate_run(const CalibInputs& in, double* fl_cor, double* X, int* status, std::string& err)
 {
@@ -124,82 +135,82 @@ inline int calibrate_run(const CalibInputs& in, double* fl_cor, double* X, int* 
     GpHost gall;
     for (int k = 0; k < 6; ++k) gall.v[k] = (k < 2 * c) ? in.gp[k] : 0.0;
 
-    PR_TRY(hipMalloc(&dK1, sizeof(double) * (size_t)Npad * ld1));
-    PR_TRY(hipMalloc(&dK2, sizeof(double) * (size_t)Mpad * ld2));
-    PR_TRY(hipMalloc(&dW, sizeof(double) * NB * NB));
-    PR_TRY(hipMalloc(&dR, sizeof(double) * (size_t)std::max(Npad, Mpad)));
-    PR_TRY(hipMalloc(&dAcc, sizeof(MatAcc)));
-    PR_TRY(hipMalloc(&dVec, sizeof(double) * (size_t)(3 * M + 2 * N)));    // lwl_cal, fl_cal, sigma_cal, fl_fixed, sigma_fixed
-    PR_TRY(hipMalloc(&dMu, sizeof(double) * Mpad));
-    PR_TRY(hipMalloc(&dM0, sizeof(double) * Mpad));
-    PR_TRY(hipMalloc(&dPart, sizeof(double) * (size_t)nslab * Mpad));
-    PR_TRY(hipMalloc(&dG, sizeof(double) * NB * NB));
+    CAL_TRY(hipMalloc(&dK1, sizeof(double) * (size_t)Npad * ld1));
+    CAL_TRY(hipMalloc(&dK2, sizeof(double) * (size_t)Mpad * ld2));
+    CAL_TRY(hipMalloc(&dW, sizeof(double) * NB * NB));
+    CAL_TRY(hipMalloc(&dR, sizeof(double) * (size_t)std::max(Npad, Mpad)));
+    CAL_TRY(hipMalloc(&dAcc, sizeof(MatAcc)));
+    CAL_TRY(hipMalloc(&dVec, sizeof(double) * (size_t)(3 * M + 2 * N)));    // lwl_cal, fl_cal, sigma_cal, fl_fixed, sigma_fixed
+    CAL_TRY(hipMalloc(&dMu, sizeof(double) * Mpad));
+    CAL_TRY(hipMalloc(&dM0, sizeof(double) * Mpad));
+    CAL_TRY(hipMalloc(&dPart, sizeof(double) * (size_t)nslab * Mpad));
+    CAL_TRY(hipMalloc(&dG, sizeof(double) * NB * NB));
     {
         double* dLwlCal = dVec;
         double* dFlCal = dVec + M;
         double* dSigCal = dVec + 2 * M;
         double* dFlFix = dVec + 3 * M;
         double* dSigFix = dVec + 3 * M + N;
-        PR_TRY(hipMemcpy(dLwlCal, in.lwl_cal, sizeof(double) * M, hipMemcpyHostToDevice));
-        PR_TRY(hipMemcpy(dFlCal, in.fl_cal, sizeof(double) * M, hipMemcpyHostToDevice));
-        PR_TRY(hipMemcpy(dFlFix, in.fl_fixed, sizeof(double) * N, hipMemcpyHostToDevice));
+        CAL_TRY(hipMemcpy(dLwlCal, in.lwl_cal, sizeof(double) * M, hipMemcpyHostToDevice));
+        CAL_TRY(hipMemcpy(dFlCal, in.fl_cal, sizeof(double) * M, hipMemcpyHostToDevice));
+        CAL_TRY(hipMemcpy(dFlFix, in.fl_fixed, sizeof(double) * N, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_zero, dim3(2048), dim3(256), 0, 0, dK1, (size_t)Npad * ld1);
         hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, 0, dK2, (size_t)Mpad * ld2);
         hipLaunchKernelGGL(k_zero, dim3(64), dim3(256), 0, 0, dG, (size_t)NB * NB);
         if (c > 0) {
-            PR_TRY(hipMalloc(&dCal, sizeof(double) * (size_t)c * M));
-            PR_TRY(hipMalloc(&dFix, sizeof(double) * (size_t)c * N));
-            PR_TRY(hipMalloc(&dGp, sizeof(double) * 6));
-            PR_TRY(hipMemcpy(dCal, in.lwls_cal, sizeof(double) * (size_t)c * M, hipMemcpyHostToDevice));
-            PR_TRY(hipMemcpy(dFix, in.lwls_fixed, sizeof(double) * (size_t)c * N, hipMemcpyHostToDevice));
-            PR_TRY(hipMemcpy(dSigCal, in.sigma_cal, sizeof(double) * M, hipMemcpyHostToDevice));
-            PR_TRY(hipMemcpy(dSigFix, in.sigma_fixed, sizeof(double) * N, hipMemcpyHostToDevice));
-            PR_TRY(hipMemcpy(dGp, in.gp, sizeof(double) * 2 * c, hipMemcpyHostToDevice));
+            CAL_TRY(hipMalloc(&dCal, sizeof(double) * (size_t)c * M));
+            CAL_TRY(hipMalloc(&dFix, sizeof(double) * (size_t)c * N));
+            CAL_TRY(hipMalloc(&dGp, sizeof(double) * 6));
+            CAL_TRY(hipMemcpy(dCal, in.lwls_cal, sizeof(double) * (size_t)c * M, hipMemcpyHostToDevice));
+            CAL_TRY(hipMemcpy(dFix, in.lwls_fixed, sizeof(double) * (size_t)c * N, hipMemcpyHostToDevice));
+            CAL_TRY(hipMemcpy(dSigCal, in.sigma_cal, sizeof(double) * M, hipMemcpyHostToDevice));
+            CAL_TRY(hipMemcpy(dSigFix, in.sigma_fixed, sizeof(double) * N, hipMemcpyHostToDevice));
+            CAL_TRY(hipMemcpy(dGp, in.gp, sizeof(double) * 2 * c, hipMemcpyHostToDevice));
             // B = sum_k K_k(fixed) + sigma_fixed^2 (script :170-176), upper tiles, identity padding
             dim3 grid(P1 * (P1 + 1) / 2, 1);
             if (c == 1) hipLaunchKernelGGL(k_fill_sym<1>, grid, dim3(256), 0, 0, dK1, (size_t)0, (int)ld1, N, P1, dFix, dGp, dSigFix, 1);
             else if (c == 2) hipLaunchKernelGGL(k_fill_sym<2>, grid, dim3(256), 0, 0, dK1, (size_t)0, (int)ld1, N, P1, dFix, dGp, dSigFix, 1);
             else hipLaunchKernelGGL(k_fill_sym<3>, grid, dim3(256), 0, 0, dK1, (size_t)0, (int)ld1, N, P1, dFix, dGp, dSigFix, 1);
             // C^T[j][i] = sum_k K_k(cal_i, fixed_j) (script :160-166): rows = fixed grid, columns = epoch grid
-            launch_region_c(c, dK1, ld1, Npad, N, M, dFix, (size_t)N, dCal, (size_t)M, gall, 0, 0.0);
+            launch_region_c((hipStream_t)0, c, dK1, ld1, Npad, N, M, dFix, (size_t)N, dCal, (size_t)M, gall, 0, 0.0);
             // A = sum_k K_k(cal) + sigma_cal^2 (script :150-158), written into pass 2's buffer
-            launch_region_c(c, dK2, ld2, 0, M, M, dCal, (size_t)M, dCal, (size_t)M, gall, 1, 0.0);
+            launch_region_c((hipStream_t)0, c, dK2, ld2, 0, M, M, dCal, (size_t)M, dCal, (size_t)M, gall, 1, 0.0);
             hipLaunchKernelGGL(k_add_diag_sq, dim3((M + 255) / 256), dim3(256), 0, 0, dK2, ld2, M, dSigCal);
         } else {
-            PR_TRY(hipMemcpy2D(dK1, sizeof(double) * ld1, in.B, sizeof(double) * N, sizeof(double) * N, N, hipMemcpyHostToDevice));
+            CAL_TRY(hipMemcpy2D(dK1, sizeof(double) * ld1, in.B, sizeof(double) * N, sizeof(double) * N, N, hipMemcpyHostToDevice));
             hipLaunchKernelGGL(k_pad_identity, dim3((Npad - N + 255) / 256 + 1), dim3(256), 0, 0, dK1, ld1, N, Npad);
-            PR_TRY(hipMalloc(&dTmp, sizeof(double) * (size_t)M * N));
-            PR_TRY(hipMemcpy(dTmp, in.C, sizeof(double) * (size_t)M * N, hipMemcpyHostToDevice));
+            CAL_TRY(hipMalloc(&dTmp, sizeof(double) * (size_t)M * N));
+            CAL_TRY(hipMemcpy(dTmp, in.C, sizeof(double) * (size_t)M * N, hipMemcpyHostToDevice));
             hipLaunchKernelGGL(k_transpose_in, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, 0, dK1, ld1, Npad, dTmp,
                                (size_t)N, M, N);
-            PR_TRY(hipMemcpy2D(dK2, sizeof(double) * ld2, in.A, sizeof(double) * M, sizeof(double) * M, M, hipMemcpyHostToDevice));
+            CAL_TRY(hipMemcpy2D(dK2, sizeof(double) * ld2, in.A, sizeof(double) * M, sizeof(double) * M, M, hipMemcpyHostToDevice));
         }
-        PR_TRY(hipGetLastError());
+        CAL_TRY(hipGetLastError());
 
         // ---- pass 1
         hipLaunchKernelGGL(k_init_rhs, dim3((Npad + 255) / 256, 1), dim3(256), 0, 0, dR, Npad, N, dFlFix, in.mu, dAcc);
-        factor_augmented(dK1, ld1, P1, Mpad / NB, dW, dR, Npad, dAcc);
-        PR_TRY(hipGetLastError());
-        PR_TRY(hipMemcpy(&hacc, dAcc, sizeof(MatAcc), hipMemcpyDeviceToHost));
+        factor_augmented((hipStream_t)0, dK1, ld1, P1, Mpad / NB, dW, dR, Npad, dAcc);
+        CAL_TRY(hipGetLastError());
+        CAL_TRY(hipMemcpy(&hacc, dAcc, sizeof(MatAcc), hipMemcpyDeviceToHost));
         if (hacc.info != 0.0) { *status = 1; goto done; }
-        PR_TRY(hipMemcpy(dM0, m0.data(), sizeof(double) * M, hipMemcpyHostToDevice));
+        CAL_TRY(hipMemcpy(dM0, m0.data(), sizeof(double) * M, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_gemv_t_partial, dim3((M + 127) / 128, nslab), dim3(256), 0, 0, dK1 + Npad, ld1, Npad, M, dR, dPart);
         hipLaunchKernelGGL(k_gemv_finish, dim3((M + 255) / 256), dim3(256), 0, 0, dPart, nslab, M, dM0, dMu);     // fl'
         hipLaunchKernelGGL(k_syrk_sub, dim3(P2, P2), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dK1 + Npad, ld1, Npad, dK2, ld2);  // C'
         hipLaunchKernelGGL(k_pad_identity, dim3((Mpad - M + 255) / 256 + 1), dim3(256), 0, 0, dK2, ld2, M, Mpad);
         hipLaunchKernelGGL(k_calib_aug, dim3((M + 255) / 256), dim3(256), 0, 0, dK2, ld2, Mpad, M, order, dLwlCal, dFlCal, off,
                            scl, dMu);
-        PR_TRY(hipGetLastError());
+        CAL_TRY(hipGetLastError());
 
         // ---- pass 2
         hipLaunchKernelGGL(k_init_rhs, dim3((Mpad + 255) / 256, 1), dim3(256), 0, 0, dR, Mpad, M, dMu, 0.0, dAcc);
-        factor_augmented(dK2, ld2, P2, 1, dW, dR, Mpad, dAcc);
-        PR_TRY(hipGetLastError());
-        PR_TRY(hipMemcpy(&hacc, dAcc, sizeof(MatAcc), hipMemcpyDeviceToHost));
+        factor_augmented((hipStream_t)0, dK2, ld2, P2, 1, dW, dR, Mpad, dAcc);
+        CAL_TRY(hipGetLastError());
+        CAL_TRY(hipMemcpy(&hacc, dAcc, sizeof(MatAcc), hipMemcpyDeviceToHost));
         if (hacc.info != 0.0) { *status = 2; goto done; }
         hipLaunchKernelGGL(k_syrk_sub, dim3(1, 1), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dK2 + Mpad, ld2, Mpad, dG, (size_t)NB);
-        PR_TRY(hipGetLastError());
-        PR_TRY(hipMemcpy(G.data(), dG, sizeof(double) * NB * NB, hipMemcpyDeviceToHost));
+        CAL_TRY(hipGetLastError());
+        CAL_TRY(hipMemcpy(G.data(), dG, sizeof(double) * NB * NB, hipMemcpyDeviceToHost));
     }
     {
         // normal equations (order+1 unknowns): left = D^T C'^-1 D, right = D^T C'^-1 fl'  (G holds their negatives)

@@ -136,8 +136,11 @@ __device__ __forceinline__ void dag_task_done(MatFlags* f, int q, int ntasks_row
         // last finisher of the row: order after every other task's release, then publish the row
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the reset must be visible before any task of the next row -- released by rows_done -- adds to
+        // cnt: drain the reset, then publish the row with a release store (two relaxed stores are unordered)
         __hip_atomic_store(&f->cnt, 0, PSOAP_RLX_AGENT);
-        __hip_atomic_store(&f->rows_done, q + 1, PSOAP_RLX_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&f->rows_done, q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

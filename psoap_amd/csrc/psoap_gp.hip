@@ -8,6 +8,7 @@
 #include <stddef.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -43,6 +44,36 @@ static thread_local std::string g_err;
 
 static const int MAX_GROUPS = 8;
 
+// Owning device / pinned-host pointer: early returns free whatever was allocated so far.
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) { return hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * (count ? count : 1)); }
+    operator T*() const { return p; }
+};
+
+// One uploaded batch of proposals.  A handle keeps two, so the proposals of step k+1 travel over
+// PCIe (copy stream) while the persistent kernel still factors step k: psoap_batch_upload fills the slot
+// that is not being evaluated, psoap_batch_eval promotes the pending slot.
+struct BatchSlot {
+    double* dLwl = nullptr;    // max_batch x 3 x N
+    double* dGp = nullptr;     // max_batch x 6
+    int* dTooFast = nullptr;   // max_batch: |v| >= c flags (orbit proposals)
+    DagMat* dMats = nullptr;   // per-matrix records of this slot (max_batch entries)
+    int mats_B = 0, mats_C = 0;
+    int B = 0, C = 0;
+    double mu = 1.0;
+    std::vector<char> neg;     // per-proposal: a hyper-parameter was negative -> -inf
+    hipEvent_t evUpload = nullptr;   // copy stream: H2D (+ Doppler shift) of this slot complete
+    hipEvent_t evEval = nullptr;     // compute stream: last evaluation that read this slot complete
+};
+
+namespace psoap { struct PredictWs; }
+
 struct psoap_chunk {
     int device = 0;
     int N = 0, Npad = 0, ld = 0, P = 0;
@@ -59,14 +90,11 @@ struct psoap_chunk {
     double* dWt = nullptr;   // max_batch x 128 x 128
     double* dR = nullptr;    // max_batch x Npad
     MatAcc* dAcc = nullptr;  // max_batch
-    double* dLwl = nullptr;  // max_batch x 3 x N
-    double* dGp = nullptr;   // max_batch x 6
     double* dVel = nullptr;  // max_batch x 3 x n_epochs
     double* dOut = nullptr;  // max_batch
     double* dDates = nullptr;  // n_epochs observation dates (orbit proposals)
     double* dPorb = nullptr;   // max_batch x 13 orbital parameters
     double* hPorb = nullptr;
-    int* dTooFast = nullptr;   // max_batch: |v| >= c flags of the current batch
     char* dDag = nullptr;    // DagCtl followed by max_batch MatFlags (zeroed before every DAG launch)
     unsigned int* hDagErr = nullptr;
     int mode = 1;            // 1 = persistent DAG kernel, 0 = staged panels
@@ -77,27 +105,26 @@ struct psoap_chunk {
     DagQueues plan_queues{};
     DagTask* dTasks = nullptr;
     size_t tasks_cap = 0;
-    DagMat* dMats = nullptr;   // per-matrix records of the current batch (max_batch entries)
-    int mats_B = 0, mats_C = 0;
     double* dWs = nullptr;   // split-K partial tiles, plan_slots x 128 x 128
     size_t ws_cap = 0;
     size_t arrive_off = 0;   // byte offset of the arrival counters inside dDag
     size_t arrive_cap = 0;   // ints
     unsigned long long* dTlog = nullptr;  // optional per-task timestamps (debug)
     long long tlog_tasks = 0;
-    // pinned host staging
+    // pinned host staging (one set: reused once the previous upload's copies have completed)
     double* hLwl = nullptr;
     double* hGp = nullptr;
     double* hVel = nullptr;
     double* hOut = nullptr;
-    // current batch
-    int B = 0, C = 0;
-    double mu = 1.0;
-    std::vector<char> neg;  // per-proposal: a hyper-parameter was negative -> -inf
+    // proposal batches
+    BatchSlot slot[2];
+    int act = -1;            // slot of the last / running evaluation
+    int pend = -1;           // uploaded, not yet evaluated
+    hipStream_t copy = nullptr;
+    hipEvent_t evStaging = nullptr;   // copy stream: the pinned staging buffers have been consumed
     // execution
     int groups = 2;
     hipStream_t streams[MAX_GROUPS] = {};
-    hipEvent_t evUpload = nullptr;
     hipEvent_t evDone[MAX_GROUPS] = {};
     // profiling
     bool profiling = false;
@@ -109,6 +136,8 @@ struct psoap_chunk {
     };
     std::vector<Rec> recs;
     psoap_timings last = {};
+    // predict workspace (grow-only; psoap_chunk_predict)
+    psoap::PredictWs* pws = nullptr;
 };
 
 static int set_dev(const psoap_chunk* h) { HIP_TRY(hipSetDevice(h->device)); return 0; }
@@ -122,22 +151,94 @@ extern "C" int psoap_device_count(int* count)
     return 0;
 }
 
-static int configure_kernels()
+// hipFuncSetAttribute applies to the CURRENT device's function object: one pass per device, under a lock
+// (a process may open handles on several GPUs, from several host threads).
+static int configure_kernels(int device)
 {
-    static bool done = false;
-    if (done) return 0;
+    static std::mutex mu;
+    static std::vector<char> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (device < 0) FAIL("negative device index");
+    if ((size_t)device < done.size() && done[device]) return 0;
+    const int lds = (int)GEMM_LDS_BYTES;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_panel_update),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_strip),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag<2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag<3>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(predict_configure_kernels());
-    done = true;
+    if (done.size() <= (size_t)device) done.resize((size_t)device + 1, 0);
+    done[device] = 1;
+    return 0;
+}
+
+// hipSetDevice + the per-device kernel attributes: the first thing every entry point that launches does
+static int enter_device(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return configure_kernels(device);
+}
+
+// persistent workgroups of the dependency-graph kernel on this device (2 per CU when they fit)
+static int dag_workers(int device, int* out)
+{
+    int blocks_per_cu = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_chol_dag<3, true>, GEMM_THREADS,
+                                                         GEMM_LDS_BYTES));
+    if (blocks_per_cu < 1) blocks_per_cu = 1;
+    if (blocks_per_cu > 2) blocks_per_cu = 2;
+    *out = blocks_per_cu * prop.multiProcessorCount;
+    return 0;
+}
+
+static int chunk_alloc(psoap_chunk* h, const double* fl, const double* sigma)
+{
+    const int N = h->N;
+    const size_t nb = (size_t)h->max_batch;
+    HIP_TRY(hipMalloc(&h->dFl, sizeof(double) * N));
+    HIP_TRY(hipMalloc(&h->dSigma, sizeof(double) * N));
+    HIP_TRY(hipMalloc(&h->dK, sizeof(double) * nb * h->mat_stride));
+    HIP_TRY(hipMalloc(&h->dWt, sizeof(double) * nb * NB * NB));
+    HIP_TRY(hipMemset(h->dWt, 0, sizeof(double) * nb * NB * NB));   // the strictly upper part of every W stays zero
+    HIP_TRY(hipMalloc(&h->dR, sizeof(double) * nb * h->Npad));
+    HIP_TRY(hipMalloc(&h->dAcc, sizeof(MatAcc) * nb));
+    HIP_TRY(hipMalloc(&h->dOut, sizeof(double) * nb));
+    HIP_TRY(hipMalloc(&h->dPorb, sizeof(double) * nb * 13));
+    HIP_TRY(hipHostMalloc(&h->hPorb, sizeof(double) * nb * 13));
+    HIP_TRY(hipHostMalloc(&h->hLwl, sizeof(double) * nb * 3 * N));
+    HIP_TRY(hipHostMalloc(&h->hGp, sizeof(double) * nb * 6));
+    HIP_TRY(hipHostMalloc(&h->hOut, sizeof(double) * nb));
+    for (BatchSlot& sl : h->slot) {
+        HIP_TRY(hipMalloc(&sl.dLwl, sizeof(double) * nb * 3 * N));
+        HIP_TRY(hipMalloc(&sl.dGp, sizeof(double) * nb * 6));
+        HIP_TRY(hipMalloc(&sl.dTooFast, sizeof(int) * nb));
+        HIP_TRY(hipMemset(sl.dTooFast, 0, sizeof(int) * nb));
+        HIP_TRY(hipMalloc(&sl.dMats, sizeof(DagMat) * nb));
+        HIP_TRY(hipEventCreateWithFlags(&sl.evUpload, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.evEval, hipEventDisableTiming));
+    }
+    h->arrive_off = sizeof(DagCtl) + sizeof(MatFlags) * nb;
+    h->arrive_cap = nb * (size_t)h->P * (h->P + 1) / 2 + 16;
+    HIP_TRY(hipMalloc(&h->dDag, h->arrive_off + sizeof(int) * h->arrive_cap));
+    HIP_TRY(hipHostMalloc(&h->hDagErr, 64));
+    h->hDagErr[0] = 0;
+    if (int rc = dag_workers(h->device, &h->dag_grid)) return rc;
+    // one compute stream per handle; the extra streams of the staged mode's groups are created on first
+    // use, so that the streams of several handles spread over the runtime's hardware queues (handles that
+    // evaluate concurrently must not share one).  Uploads run on a stream of their own.
+    HIP_TRY(hipStreamCreateWithFlags(&h->streams[0], hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking));
+    for (int g = 0; g < MAX_GROUPS; ++g) HIP_TRY(hipEventCreateWithFlags(&h->evDone[g], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->evStaging, hipEventDisableTiming));
+    HIP_TRY(hipMemcpy(h->dFl, fl, sizeof(double) * N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->dSigma, sigma, sizeof(double) * N, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -145,8 +246,8 @@ extern "C" int psoap_chunk_create(psoap_chunk** out, int device, int N, const do
                                   int max_batch)
 {
     if (!out || N <= 0 || max_batch <= 0 || !fl || !sigma) FAIL("psoap_chunk_create: bad arguments");
-    HIP_TRY(hipSetDevice(device));
-    if (configure_kernels()) return 1;
+    *out = nullptr;
+    if (int rc = enter_device(device)) return rc;
     psoap_chunk* h = new psoap_chunk();
     h->device = device;
     h->N = N;
@@ -155,51 +256,18 @@ extern "C" int psoap_chunk_create(psoap_chunk** out, int device, int N, const do
     h->P = h->Npad / NB;
     h->max_batch = max_batch;
     h->mat_stride = (size_t)h->Npad * h->ld;
-    const size_t nb = (size_t)max_batch;
-    HIP_TRY(hipMalloc(&h->dFl, sizeof(double) * N));
-    HIP_TRY(hipMalloc(&h->dSigma, sizeof(double) * N));
-    HIP_TRY(hipMalloc(&h->dK, sizeof(double) * nb * h->mat_stride));
-    HIP_TRY(hipMalloc(&h->dWt, sizeof(double) * nb * NB * NB));
-    HIP_TRY(hipMemset(h->dWt, 0, sizeof(double) * nb * NB * NB));   // the strictly upper part of every W stays zero
-    HIP_TRY(hipMalloc(&h->dR, sizeof(double) * nb * h->Npad));
-    HIP_TRY(hipMalloc(&h->dAcc, sizeof(MatAcc) * nb));
-    HIP_TRY(hipMalloc(&h->dLwl, sizeof(double) * nb * 3 * N));
-    HIP_TRY(hipMalloc(&h->dGp, sizeof(double) * nb * 6));
-    HIP_TRY(hipMalloc(&h->dOut, sizeof(double) * nb));
-    HIP_TRY(hipMalloc(&h->dPorb, sizeof(double) * nb * 13));
-    HIP_TRY(hipHostMalloc(&h->hPorb, sizeof(double) * nb * 13));
-    HIP_TRY(hipMalloc(&h->dTooFast, sizeof(int) * nb));
-    HIP_TRY(hipMemset(h->dTooFast, 0, sizeof(int) * nb));
-    HIP_TRY(hipHostMalloc(&h->hLwl, sizeof(double) * nb * 3 * N));
-    HIP_TRY(hipHostMalloc(&h->hGp, sizeof(double) * nb * 6));
-    HIP_TRY(hipHostMalloc(&h->hOut, sizeof(double) * nb));
-    h->arrive_off = sizeof(DagCtl) + sizeof(MatFlags) * nb;
-    h->arrive_cap = nb * (size_t)h->P * (h->P + 1) / 2 + 16;
-    HIP_TRY(hipMalloc(&h->dDag, h->arrive_off + sizeof(int) * h->arrive_cap));
-    HIP_TRY(hipMalloc(&h->dMats, sizeof(DagMat) * nb));
-    HIP_TRY(hipHostMalloc(&h->hDagErr, 64));
-    h->hDagErr[0] = 0;
-    {
-        int blocks_per_cu = 0;
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_chol_dag<3>, GEMM_THREADS,
-                                                             GEMM_LDS_BYTES));
-        if (blocks_per_cu < 1) blocks_per_cu = 1;
-        if (blocks_per_cu > 2) blocks_per_cu = 2;
-        h->dag_grid = blocks_per_cu * prop.multiProcessorCount;
+    if (int rc = chunk_alloc(h, fl, sigma)) {
+        // e.g. out of memory half way: give everything back (the message of the failing call is kept)
+        const std::string keep = g_err;
+        (void)psoap_chunk_destroy(h);
+        g_err = keep;
+        return rc;
     }
-    // one stream per handle; the extra streams of the staged mode's groups are created on first use, so
-    // that the streams of several handles spread over the runtime's hardware queues (handles that
-    // evaluate concurrently must not share one)
-    HIP_TRY(hipStreamCreateWithFlags(&h->streams[0], hipStreamNonBlocking));
-    for (int g = 0; g < MAX_GROUPS; ++g) HIP_TRY(hipEventCreateWithFlags(&h->evDone[g], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&h->evUpload, hipEventDisableTiming));
-    HIP_TRY(hipMemcpy(h->dFl, fl, sizeof(double) * N, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->dSigma, sigma, sizeof(double) * N, hipMemcpyHostToDevice));
     *out = h;
     return 0;
 }
+
+
 
 extern "C" int psoap_chunk_destroy(psoap_chunk* h)
 {
@@ -208,17 +276,24 @@ extern "C" int psoap_chunk_destroy(psoap_chunk* h)
     (void)hipDeviceSynchronize();
     (void)hipFree(h->dFl); (void)hipFree(h->dSigma); (void)hipFree(h->dGrid); (void)hipFree(h->dEpoch);
     (void)hipFree(h->dK); (void)hipFree(h->dWt); (void)hipFree(h->dR); (void)hipFree(h->dAcc);
-    (void)hipFree(h->dLwl); (void)hipFree(h->dGp); (void)hipFree(h->dVel); (void)hipFree(h->dOut);
+    (void)hipFree(h->dVel); (void)hipFree(h->dOut);
     (void)hipFree(h->dDag); (void)hipHostFree(h->hDagErr); (void)hipFree(h->dTlog);
-    (void)hipFree(h->dTasks); (void)hipFree(h->dWs); (void)hipFree(h->dMats);
-    (void)hipFree(h->dDates); (void)hipFree(h->dPorb); (void)hipHostFree(h->hPorb); (void)hipFree(h->dTooFast);
+    (void)hipFree(h->dTasks); (void)hipFree(h->dWs);
+    (void)hipFree(h->dDates); (void)hipFree(h->dPorb); (void)hipHostFree(h->hPorb);
     (void)hipHostFree(h->hLwl); (void)hipHostFree(h->hGp); (void)hipHostFree(h->hVel); (void)hipHostFree(h->hOut);
+    for (BatchSlot& sl : h->slot) {
+        (void)hipFree(sl.dLwl); (void)hipFree(sl.dGp); (void)hipFree(sl.dTooFast); (void)hipFree(sl.dMats);
+        if (sl.evUpload) (void)hipEventDestroy(sl.evUpload);
+        if (sl.evEval) (void)hipEventDestroy(sl.evEval);
+    }
     for (int g = 0; g < MAX_GROUPS; ++g) {
         if (h->streams[g]) (void)hipStreamDestroy(h->streams[g]);
         if (h->evDone[g]) (void)hipEventDestroy(h->evDone[g]);
     }
-    if (h->evUpload) (void)hipEventDestroy(h->evUpload);
+    if (h->copy) (void)hipStreamDestroy(h->copy);
+    if (h->evStaging) (void)hipEventDestroy(h->evStaging);
     for (auto e : h->evPool) (void)hipEventDestroy(e);
+    delete h->pws;
     delete h;
     return 0;
 }
@@ -344,18 +419,37 @@ extern "C" int psoap_chunk_set_profiling(psoap_chunk* h, int enabled)
     return 0;
 }
 
-static int stage_gp(psoap_chunk* h, int B, int c, const double* gp, double mu_GP)
+// Begin an upload: pick the slot that is not being evaluated, make sure its previous readers and the
+// previous user of the pinned staging buffers are done, and record the batch's host-side state.
+static int upload_begin(psoap_chunk* h, int B, int c, const double* gp, double mu_GP, BatchSlot** out)
 {
     if (B < 1 || B > h->max_batch) FAIL("batch size outside [1, max_batch]");
     if (c < 1 || c > 3) FAIL("number of components must be 1, 2 or 3");
-    h->B = B;
-    h->C = c;
-    h->mu = mu_GP;
-    h->neg.assign(B, 0);
+    const int target = (h->pend >= 0) ? h->pend : (h->act < 0 ? 0 : (h->act ^ 1));
+    BatchSlot& sl = h->slot[target];
+    // the staging buffers are free once the previous upload's copies have run (they were queued one
+    // evaluation ago: normally long finished)
+    HIP_TRY(hipEventSynchronize(h->evStaging));
+    // the slot's device arrays: the evaluation that last read them must be over before they are rewritten
+    HIP_TRY(hipStreamWaitEvent(h->copy, sl.evEval, 0));
+    sl.B = B;
+    sl.C = c;
+    sl.mu = mu_GP;
+    sl.neg.assign(B, 0);
     for (int b = 0; b < B; ++b)
         for (int k = 0; k < 2 * c; ++k)
-            if (gp[(size_t)b * 2 * c + k] < 0.0) h->neg[b] = 1;  // covariance.py:317,339,362
+            if (gp[(size_t)b * 2 * c + k] < 0.0) sl.neg[b] = 1;  // covariance.py:317,339,362
     memcpy(h->hGp, gp, sizeof(double) * (size_t)B * 2 * c);
+    h->pend = target;
+    *out = &sl;
+    return 0;
+}
+
+static int upload_end(psoap_chunk* h, BatchSlot& sl)
+{
+    HIP_TRY(hipMemcpyAsync(sl.dGp, h->hGp, sizeof(double) * (size_t)sl.B * 2 * sl.C, hipMemcpyHostToDevice, h->copy));
+    HIP_TRY(hipEventRecord(h->evStaging, h->copy));
+    HIP_TRY(hipEventRecord(sl.evUpload, h->copy));
     return 0;
 }
 
@@ -363,17 +457,13 @@ extern "C" int psoap_batch_upload(psoap_chunk* h, int B, int c, const double* lw
 {
     if (!h || !lwl || !gp) FAIL("psoap_batch_upload: bad arguments");
     if (set_dev(h)) return 1;
-    // staging buffers are reused: the previous batch must have been consumed
-    HIP_TRY(hipStreamSynchronize(h->streams[0]));
-    if (int rc = stage_gp(h, B, c, gp, mu_GP)) return rc;
+    BatchSlot* sl = nullptr;
+    if (int rc = upload_begin(h, B, c, gp, mu_GP, &sl)) return rc;
     const size_t nl = (size_t)B * c * h->N;
     memcpy(h->hLwl, lwl, sizeof(double) * nl);
-    hipStream_t s = h->streams[0];
-    HIP_TRY(hipMemsetAsync(h->dTooFast, 0, sizeof(int) * (size_t)B, s));
-    HIP_TRY(hipMemcpyAsync(h->dLwl, h->hLwl, sizeof(double) * nl, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(h->dGp, h->hGp, sizeof(double) * (size_t)B * 2 * c, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipEventRecord(h->evUpload, s));
-    return 0;
+    HIP_TRY(hipMemsetAsync(sl->dTooFast, 0, sizeof(int) * (size_t)B, h->copy));
+    HIP_TRY(hipMemcpyAsync(sl->dLwl, h->hLwl, sizeof(double) * nl, hipMemcpyHostToDevice, h->copy));
+    return upload_end(h, *sl);
 }
 
 extern "C" int psoap_batch_upload_velocities(psoap_chunk* h, int B, int c, const double* vel, const double* gp,
@@ -382,20 +472,18 @@ extern "C" int psoap_batch_upload_velocities(psoap_chunk* h, int B, int c, const
     if (!h || !vel || !gp) FAIL("psoap_batch_upload_velocities: bad arguments");
     if (!h->dGrid) FAIL("psoap_batch_upload_velocities: call psoap_chunk_set_grid first");
     if (set_dev(h)) return 1;
-    HIP_TRY(hipStreamSynchronize(h->streams[0]));
-    if (int rc = stage_gp(h, B, c, gp, mu_GP)) return rc;
+    BatchSlot* sl = nullptr;
+    if (int rc = upload_begin(h, B, c, gp, mu_GP, &sl)) return rc;
     const size_t nv = (size_t)B * c * h->n_epochs;
     memcpy(h->hVel, vel, sizeof(double) * nv);
-    hipStream_t s = h->streams[0];
-    HIP_TRY(hipMemsetAsync(h->dTooFast, 0, sizeof(int) * (size_t)B, s));
+    hipStream_t s = h->copy;
+    HIP_TRY(hipMemsetAsync(sl->dTooFast, 0, sizeof(int) * (size_t)B, s));
     HIP_TRY(hipMemcpyAsync(h->dVel, h->hVel, sizeof(double) * nv, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(h->dGp, h->hGp, sizeof(double) * (size_t)B * 2 * c, hipMemcpyHostToDevice, s));
     dim3 grid((h->N + 255) / 256, B * c);
-    hipLaunchKernelGGL(k_doppler_shift, grid, dim3(256), 0, s, h->dLwl, h->dGrid, h->dEpoch, h->dVel, h->N,
+    hipLaunchKernelGGL(k_doppler_shift, grid, dim3(256), 0, s, sl->dLwl, h->dGrid, h->dEpoch, h->dVel, h->N,
                        h->n_epochs, B * c);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(h->evUpload, s));
-    return 0;
+    return upload_end(h, *sl);
 }
 
 extern "C" int psoap_chunk_set_dates(psoap_chunk* h, const double* dates, int n_epochs)
@@ -437,23 +525,21 @@ extern "C" int psoap_batch_upload_orbits(psoap_chunk* h, int B, int model, const
     if (set_dev(h)) return 1;
     if (B < 1 || B > h->max_batch) FAIL("batch size outside [1, max_batch]");
     if (int rc = check_orbits(model, B, p_orb)) return rc;
-    HIP_TRY(hipStreamSynchronize(h->streams[0]));
     const int c = orbit_n_components(model), np = orbit_n_params(model);
-    if (int rc = stage_gp(h, B, c, gp, mu_GP)) return rc;
+    BatchSlot* sl = nullptr;
+    if (int rc = upload_begin(h, B, c, gp, mu_GP, &sl)) return rc;
     memcpy(h->hPorb, p_orb, sizeof(double) * (size_t)B * np);
-    hipStream_t s = h->streams[0];
+    hipStream_t s = h->copy;
     HIP_TRY(hipMemcpyAsync(h->dPorb, h->hPorb, sizeof(double) * (size_t)B * np, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(h->dGp, h->hGp, sizeof(double) * (size_t)B * 2 * c, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(h->dTooFast, 0, sizeof(int) * (size_t)B, s));
+    HIP_TRY(hipMemsetAsync(sl->dTooFast, 0, sizeof(int) * (size_t)B, s));
     hipLaunchKernelGGL(k_orbit_velocities, dim3((h->n_epochs + 63) / 64, B), dim3(64), 0, s, model, B, h->n_epochs,
-                       h->dPorb, h->dDates, h->dVel, h->dTooFast);
+                       h->dPorb, h->dDates, h->dVel, sl->dTooFast);
     HIP_TRY(hipGetLastError());
     dim3 grid((h->N + 255) / 256, B * c);
-    hipLaunchKernelGGL(k_doppler_shift, grid, dim3(256), 0, s, h->dLwl, h->dGrid, h->dEpoch, h->dVel, h->N,
+    hipLaunchKernelGGL(k_doppler_shift, grid, dim3(256), 0, s, sl->dLwl, h->dGrid, h->dEpoch, h->dVel, h->N,
                        h->n_epochs, B * c);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(h->evUpload, s));
-    return 0;
+    return upload_end(h, *sl);
 }
 
 // stand-alone batched orbit evaluation: vel_out (B, c, n_dates)
@@ -464,17 +550,16 @@ extern "C" int psoap_orbit_velocities(int device, int model, int B, const double
     if (int rc = check_orbits(model, B, p_orb)) return rc;
     HIP_TRY(hipSetDevice(device));
     const int c = orbit_n_components(model), np = orbit_n_params(model);
-    double *dP = nullptr, *dD = nullptr, *dV = nullptr;
-    HIP_TRY(hipMalloc(&dP, sizeof(double) * (size_t)B * np));
-    HIP_TRY(hipMalloc(&dD, sizeof(double) * n_dates));
-    HIP_TRY(hipMalloc(&dV, sizeof(double) * (size_t)B * c * n_dates));
+    DevBuf<double> dP, dD, dV;
+    HIP_TRY(dP.alloc((size_t)B * np));
+    HIP_TRY(dD.alloc(n_dates));
+    HIP_TRY(dV.alloc((size_t)B * c * n_dates));
     HIP_TRY(hipMemcpy(dP, p_orb, sizeof(double) * (size_t)B * np, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dD, dates, sizeof(double) * n_dates, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_orbit_velocities, dim3((n_dates + 63) / 64, B), dim3(64), 0, 0, model, B, n_dates, dP, dD, dV,
-                       (int*)nullptr);
+    hipLaunchKernelGGL(k_orbit_velocities, dim3((n_dates + 63) / 64, B), dim3(64), 0, 0, model, B, n_dates, dP.p, dD.p,
+                       dV.p, (int*)nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(vel_out, dV, sizeof(double) * (size_t)B * c * n_dates, hipMemcpyDeviceToHost));
-    (void)hipFree(dP); (void)hipFree(dD); (void)hipFree(dV);
     return 0;
 }
 
@@ -506,25 +591,24 @@ static int prof_end(psoap_chunk* h, hipStream_t s)
 }
 
 template <int C>
-static void launch_fill(psoap_chunk* h, hipStream_t s, int b0, int nb, int upper_only)
+static void launch_fill(psoap_chunk* h, const BatchSlot& sl, hipStream_t s, int b0, int nb, int upper_only)
 {
     const int tiles = upper_only ? h->P * (h->P + 1) / 2 : h->P * h->P;
     hipLaunchKernelGGL(k_fill_sym<C>, dim3(tiles, nb), dim3(256), 0, s, h->dK + (size_t)b0 * h->mat_stride,
-                       h->mat_stride, h->ld, h->N, h->P, h->dLwl + (size_t)b0 * C * h->N,
-                       h->dGp + (size_t)b0 * 2 * C, h->dSigma, upper_only);
+                       h->mat_stride, h->ld, h->N, h->P, sl.dLwl + (size_t)b0 * C * h->N,
+                       sl.dGp + (size_t)b0 * 2 * C, h->dSigma, upper_only);
 }
 
-// (re)build the task list of the persistent kernel when the batch size changes
-// per-matrix records of this handle's batch (uniform: every matrix shares N, fl, sigma)
-static void fill_mats(const psoap_chunk* h, DagMat* out)
+// per-matrix records of a slot's batch (uniform: every matrix shares N, fl, sigma)
+static void fill_mats(const psoap_chunk* h, const BatchSlot& sl, DagMat* out)
 {
-    for (int b = 0; b < h->B; ++b) {
+    for (int b = 0; b < sl.B; ++b) {
         DagMat m{};
         m.K = h->dK + (size_t)b * h->mat_stride;
         m.R = h->dR + (size_t)b * h->Npad;
         m.Wt = h->dWt + (size_t)b * NB * NB;
-        m.lw = h->dLwl + (size_t)b * h->C * h->N;
-        m.gp = h->dGp + (size_t)b * 2 * h->C;
+        m.lw = sl.dLwl + (size_t)b * sl.C * h->N;
+        m.gp = sl.dGp + (size_t)b * 2 * sl.C;
         m.sigma = h->dSigma;
         m.acc = h->dAcc + b;
         m.N = h->N;
@@ -535,37 +619,55 @@ static void fill_mats(const psoap_chunk* h, DagMat* out)
     }
 }
 
+// An evaluation consumes the pending upload, if there is one; otherwise it re-evaluates the active slot.
+static int promote_slot(psoap_chunk* h, const char* who)
+{
+    if (h->pend >= 0) {
+        h->act = h->pend;
+        h->pend = -1;
+    }
+    if (h->act < 0 || h->slot[h->act].B < 1) {
+        g_err = std::string(who) + ": nothing uploaded";
+        return 2;
+    }
+    return 0;
+}
+
+// (re)build the task list of the persistent kernel when the batch size changes
 static int dag_prepare(psoap_chunk* h)
 {
-    if (h->mats_B != h->B || h->mats_C != h->C) {
-        std::vector<DagMat> mats(h->B);
-        fill_mats(h, mats.data());
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipMemcpy(h->dMats, mats.data(), sizeof(DagMat) * h->B, hipMemcpyHostToDevice));
-        h->mats_B = h->B;
-        h->mats_C = h->C;
+    BatchSlot& sl = h->slot[h->act];
+    if (sl.mats_B != sl.B || sl.mats_C != sl.C) {
+        std::vector<DagMat> mats(sl.B);
+        fill_mats(h, sl, mats.data());
+        HIP_TRY(hipStreamSynchronize(h->streams[0]));   // an earlier launch may still read the records
+        HIP_TRY(hipMemcpy(sl.dMats, mats.data(), sizeof(DagMat) * sl.B, hipMemcpyHostToDevice));
+        sl.mats_B = sl.B;
+        sl.mats_C = sl.C;
     }
-    if (h->plan_B == h->B) return 0;
+    if (h->plan_B == sl.B) return 0;
     if (h->P > 255) FAIL("N too large for the persistent kernel's 8-bit block-row indices (N <= 32640)");
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipStreamSynchronize(h->streams[0]));
     // PSOAP_DAG_SCHEME=0|1 pins the split scheme (experiments); default: automatic
     const char* env_scheme = getenv("PSOAP_DAG_SCHEME");
-    DagPlan plan = dag_build_tasks(h->B, h->P, h->dag_grid, env_scheme ? atoi(env_scheme) : -1);
+    DagPlan plan = dag_build_tasks(sl.B, h->P, h->dag_grid, env_scheme ? atoi(env_scheme) : -1);
     if (plan.n_ctrs > h->arrive_cap) FAIL("internal: arrival counter capacity exceeded");
     if (plan.tasks.size() > h->tasks_cap) {
         if (h->dTasks) HIP_TRY(hipFree(h->dTasks));
         h->dTasks = nullptr;
+        h->tasks_cap = 0;
         HIP_TRY(hipMalloc(&h->dTasks, sizeof(DagTask) * plan.tasks.size()));
         h->tasks_cap = plan.tasks.size();
     }
     if (plan.n_slots > h->ws_cap) {
         if (h->dWs) HIP_TRY(hipFree(h->dWs));
         h->dWs = nullptr;
+        h->ws_cap = 0;
         HIP_TRY(hipMalloc(&h->dWs, sizeof(double) * NB * NB * (size_t)plan.n_slots));
         h->ws_cap = plan.n_slots;
     }
     HIP_TRY(hipMemcpy(h->dTasks, plan.tasks.data(), sizeof(DagTask) * plan.tasks.size(), hipMemcpyHostToDevice));
-    h->plan_B = h->B;
+    h->plan_B = sl.B;
     h->plan_tasks = (unsigned int)plan.tasks.size();
     h->plan_ctrs = plan.n_ctrs;
     h->plan_slots = plan.n_slots;
@@ -576,14 +678,16 @@ static int dag_prepare(psoap_chunk* h)
 // One persistent launch for the whole batched factorisation (dag_kernel.hpp).
 static int eval_dag(psoap_chunk* h)
 {
-    const int B = h->B, C = h->C, N = h->N, P = h->P;
+    BatchSlot& sl = h->slot[h->act];
+    const int B = sl.B, C = sl.C, N = h->N, P = h->P;
     hipStream_t s = h->streams[0];
     h->recs.clear();
     if (int rc = dag_prepare(h)) return rc;
+    HIP_TRY(hipStreamWaitEvent(s, sl.evUpload, 0));
     // no fill kernel: the DAG kernel evaluates the covariance tiles on the fly (dag_store_updated)
     if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
     hipLaunchKernelGGL(k_init_rhs, dim3((h->Npad + 255) / 256, B), dim3(256), 0, s, h->dR, h->Npad, N, h->dFl,
-                       h->mu, h->dAcc);
+                       sl.mu, h->dAcc);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(h->dDag, 0, h->arrive_off + sizeof(int) * ((size_t)h->plan_ctrs + 4), s));
     if (prof_end(h, s)) return 1;
@@ -597,7 +701,7 @@ static int eval_dag(psoap_chunk* h)
         MatFlags* fl_ = reinterpret_cast<MatFlags*>(h->dDag + sizeof(DagCtl));
         DagCtl* ctl_ = reinterpret_cast<DagCtl*>(h->dDag);
 #define PSOAP_LAUNCH_DAG(CC)                                                                                     \
-    hipLaunchKernelGGL(k_chol_dag<CC>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, h->dMats, h->dTasks,    \
+    hipLaunchKernelGGL(k_chol_dag<CC>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, sl.dMats, h->dTasks,    \
                        h->plan_queues, fl_, reinterpret_cast<int*>(h->dDag + h->arrive_off), h->dWs, ctl_,         \
                        h->dTlog, DagAug{P, 0, 0, nullptr})
         if (C == 1) PSOAP_LAUNCH_DAG(1);
@@ -608,9 +712,10 @@ static int eval_dag(psoap_chunk* h)
     HIP_TRY(hipGetLastError());
     if (prof_end(h, s)) return 1;
     if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
-    hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, h->dAcc, h->dOut, B, h->dTooFast);
+    hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, h->dAcc, h->dOut, B, sl.dTooFast);
     HIP_TRY(hipGetLastError());
     if (prof_end(h, s)) return 1;
+    HIP_TRY(hipEventRecord(sl.evEval, s));
     HIP_TRY(hipMemcpyAsync(h->hOut, h->dOut, sizeof(double) * B, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(h->hDagErr, h->dDag + offsetof(DagCtl, error), 4 * sizeof(unsigned int),
                            hipMemcpyDeviceToHost, s));
@@ -619,11 +724,13 @@ static int eval_dag(psoap_chunk* h)
 
 extern "C" int psoap_batch_eval(psoap_chunk* h)
 {
-    if (!h || h->B < 1) FAIL("psoap_batch_eval: nothing uploaded");
+    if (!h) FAIL("psoap_batch_eval: null handle");
     if (set_dev(h)) return 1;
+    if (int rc = promote_slot(h, "psoap_batch_eval")) return rc;
     // the persistent kernel indexes block rows with 8 bits; beyond N = 32640 use the staged path
     if (h->mode == 1 && h->P <= 255) return eval_dag(h);
-    const int B = h->B, C = h->C, N = h->N, P = h->P;
+    BatchSlot& sl = h->slot[h->act];
+    const int B = sl.B, C = sl.C, N = h->N, P = h->P;
     const int G = h->profiling ? 1 : (h->groups < B ? h->groups : B);
     for (int g = 1; g < G; ++g)
         if (!h->streams[g]) HIP_TRY(hipStreamCreateWithFlags(&h->streams[g], hipStreamNonBlocking));
@@ -635,17 +742,18 @@ extern "C" int psoap_batch_eval(psoap_chunk* h)
     for (int g = 0; g < G; ++g) {
         hipStream_t s = h->streams[g];
         const int b0 = gb0[g], nb = gb0[g + 1] - gb0[g];
-        if (g != 0) HIP_TRY(hipStreamWaitEvent(s, h->evUpload, 0));
+        HIP_TRY(hipStreamWaitEvent(s, sl.evUpload, 0));
+        if (g != 0) HIP_TRY(hipStreamWaitEvent(s, sl.evEval, 0));   // the workspaces: after the previous evaluation
         const double fbytes = (double)nb * (4.0 * N * (N + 1.0) + 8.0 * (C + 1.0) * N);
         if (prof_begin(h, s, PSOAP_K_FILL, 0.0, fbytes)) return 1;
-        if (C == 1) launch_fill<1>(h, s, b0, nb, 1);
-        else if (C == 2) launch_fill<2>(h, s, b0, nb, 1);
-        else launch_fill<3>(h, s, b0, nb, 1);
+        if (C == 1) launch_fill<1>(h, sl, s, b0, nb, 1);
+        else if (C == 2) launch_fill<2>(h, sl, s, b0, nb, 1);
+        else launch_fill<3>(h, sl, s, b0, nb, 1);
         HIP_TRY(hipGetLastError());
         if (prof_end(h, s)) return 1;
         if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
         hipLaunchKernelGGL(k_init_rhs, dim3((h->Npad + 255) / 256, nb), dim3(256), 0, s,
-                           h->dR + (size_t)b0 * h->Npad, h->Npad, N, h->dFl, h->mu, h->dAcc + b0);
+                           h->dR + (size_t)b0 * h->Npad, h->Npad, N, h->dFl, sl.mu, h->dAcc + b0);
         HIP_TRY(hipGetLastError());
         if (prof_end(h, s)) return 1;
     }
@@ -685,7 +793,7 @@ extern "C" int psoap_batch_eval(psoap_chunk* h)
         const int b0 = gb0[g], nb = gb0[g + 1] - gb0[g];
         if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
         hipLaunchKernelGGL(k_finalize, dim3((nb + 63) / 64), dim3(64), 0, s, h->dAcc + b0, h->dOut + b0, nb,
-                           h->dTooFast + b0);
+                           sl.dTooFast + b0);
         HIP_TRY(hipGetLastError());
         if (prof_end(h, s)) return 1;
         if (g != 0) {
@@ -693,6 +801,7 @@ extern "C" int psoap_batch_eval(psoap_chunk* h)
             HIP_TRY(hipStreamWaitEvent(h->streams[0], h->evDone[g], 0));
         }
     }
+    HIP_TRY(hipEventRecord(sl.evEval, h->streams[0]));
     HIP_TRY(hipMemcpyAsync(h->hOut, h->dOut, sizeof(double) * B, hipMemcpyDeviceToHost, h->streams[0]));
     return 0;
 }
@@ -778,14 +887,17 @@ extern "C" int psoap_group_eval(psoap_group* g)
 {
     if (!g) FAIL("psoap_group_eval: null group");
     HIP_TRY(hipSetDevice(g->device));
-    const int C = g->hs[0]->C;
     std::vector<int> key;
     int total = 0;
+    for (psoap_chunk* h : g->hs)
+        if (int rc = promote_slot(h, "psoap_group_eval (every member needs an uploaded batch)")) return rc;
+    const int C = g->hs[0]->slot[g->hs[0]->act].C;
     for (psoap_chunk* h : g->hs) {
-        if (h->B < 1) FAIL("psoap_group_eval: every member needs an uploaded batch");
-        if (h->C != C) FAIL("psoap_group_eval: all members must use the same number of components");
-        key.push_back(h->B);
-        total += h->B;
+        const BatchSlot& sl = h->slot[h->act];
+        if (sl.C != C) FAIL("psoap_group_eval: all members must use the same number of components");
+        key.push_back(sl.B);
+        key.push_back(h->act);      // the records point into the slot's arrays
+        total += sl.B;
     }
     key.push_back(C);
     if (total > 65535) FAIL("psoap_group_eval: more than 65535 matrices in one launch");
@@ -795,9 +907,10 @@ extern "C" int psoap_group_eval(psoap_group* g)
         std::vector<int> Ps;
         int b0 = 0;
         for (psoap_chunk* h : g->hs) {
-            fill_mats(h, mats.data() + b0);
-            for (int b = 0; b < h->B; ++b) Ps.push_back(h->P);
-            b0 += h->B;
+            const BatchSlot& sl = h->slot[h->act];
+            fill_mats(h, sl, mats.data() + b0);
+            for (int b = 0; b < sl.B; ++b) Ps.push_back(h->P);
+            b0 += sl.B;
         }
         const char* env_scheme = getenv("PSOAP_DAG_SCHEME");
         DagPlan plan = dag_build_tasks(Ps, g->hs[0]->dag_grid, env_scheme ? atoi(env_scheme) : -1);
@@ -836,9 +949,10 @@ extern "C" int psoap_group_eval(psoap_group* g)
     }
     hipStream_t s = g->stream;
     for (psoap_chunk* h : g->hs) {
-        HIP_TRY(hipStreamWaitEvent(s, h->evUpload, 0));
-        hipLaunchKernelGGL(k_init_rhs, dim3((h->Npad + 255) / 256, h->B), dim3(256), 0, s, h->dR, h->Npad, h->N, h->dFl,
-                           h->mu, h->dAcc);
+        const BatchSlot& sl = h->slot[h->act];
+        HIP_TRY(hipStreamWaitEvent(s, sl.evUpload, 0));
+        hipLaunchKernelGGL(k_init_rhs, dim3((h->Npad + 255) / 256, sl.B), dim3(256), 0, s, h->dR, h->Npad, h->N, h->dFl,
+                           sl.mu, h->dAcc);
         h->recs.clear();
     }
     HIP_TRY(hipGetLastError());
@@ -859,8 +973,10 @@ extern "C" int psoap_group_eval(psoap_group* g)
     }
     HIP_TRY(hipGetLastError());
     for (psoap_chunk* h : g->hs) {
-        hipLaunchKernelGGL(k_finalize, dim3((h->B + 63) / 64), dim3(64), 0, s, h->dAcc, h->dOut, h->B, h->dTooFast);
-        HIP_TRY(hipMemcpyAsync(h->hOut, h->dOut, sizeof(double) * h->B, hipMemcpyDeviceToHost, s));
+        const BatchSlot& sl = h->slot[h->act];
+        hipLaunchKernelGGL(k_finalize, dim3((sl.B + 63) / 64), dim3(64), 0, s, h->dAcc, h->dOut, sl.B, sl.dTooFast);
+        HIP_TRY(hipEventRecord(sl.evEval, s));
+        HIP_TRY(hipMemcpyAsync(h->hOut, h->dOut, sizeof(double) * sl.B, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(h->hDagErr, g->dDag + offsetof(DagCtl, error), 4 * sizeof(unsigned int),
                                hipMemcpyDeviceToHost, s));
     }
@@ -872,8 +988,9 @@ extern "C" int psoap_group_eval(psoap_group* g)
 
 extern "C" int psoap_batch_fetch(psoap_chunk* h, double* out)
 {
-    if (!h || !out || h->B < 1) FAIL("psoap_batch_fetch: bad arguments");
+    if (!h || !out || h->act < 0 || h->slot[h->act].B < 1) FAIL("psoap_batch_fetch: nothing evaluated");
     if (set_dev(h)) return 1;
+    const BatchSlot& sl = h->slot[h->act];
     HIP_TRY(hipStreamSynchronize(h->streams[0]));
     if (collect_timings(h)) return 1;
     if (h->mode == 1 && h->P <= 255 && h->hDagErr[0] != 0) {
@@ -889,7 +1006,7 @@ extern "C" int psoap_batch_fetch(psoap_chunk* h, double* out)
         h->hDagErr[0] = 0;
         FAIL(buf);
     }
-    for (int b = 0; b < h->B; ++b) out[b] = h->neg[b] ? -INFINITY : h->hOut[b];
+    for (int b = 0; b < sl.B; ++b) out[b] = sl.neg[b] ? -INFINITY : h->hOut[b];
     return 0;
 }
 
@@ -899,6 +1016,7 @@ extern "C" int psoap_chunk_sync(psoap_chunk* h)
     if (set_dev(h)) return 1;
     for (int g = 0; g < MAX_GROUPS; ++g)
         if (h->streams[g]) HIP_TRY(hipStreamSynchronize(h->streams[g]));
+    HIP_TRY(hipStreamSynchronize(h->copy));
     return 0;
 }
 
@@ -914,7 +1032,7 @@ extern "C" int psoap_lnlike_batch(psoap_chunk* h, int B, int c, const double* lw
 {
     if (int rc = psoap_batch_upload(h, B, c, lwl, gp, mu_GP)) return rc;
     bool all_neg = true;
-    for (int b = 0; b < B; ++b) all_neg = all_neg && h->neg[b];
+    for (int b = 0; b < B; ++b) all_neg = all_neg && h->slot[h->pend].neg[b];
     if (all_neg) {  // covariance.py:317-318: -inf before any work
         for (int b = 0; b < B; ++b) out[b] = -INFINITY;
         return 0;
@@ -935,27 +1053,26 @@ extern "C" int psoap_fill_sym(int device, int c, int N, const double* lwl, const
     if (c < 1 || c > 3 || N <= 0 || !lwl || !gp || !out) FAIL("psoap_fill_sym: bad arguments");
     HIP_TRY(hipSetDevice(device));
     const int Npad = round_up(N, NB), P = Npad / NB;
-    double *dK = nullptr, *dLwl = nullptr, *dGp = nullptr, *dSig = nullptr;
-    HIP_TRY(hipMalloc(&dK, sizeof(double) * (size_t)Npad * Npad));
-    HIP_TRY(hipMalloc(&dLwl, sizeof(double) * (size_t)c * N));
-    HIP_TRY(hipMalloc(&dGp, sizeof(double) * 6));
+    DevBuf<double> dK, dLwl, dGp, dSig;
+    HIP_TRY(dK.alloc((size_t)Npad * Npad));
+    HIP_TRY(dLwl.alloc((size_t)c * N));
+    HIP_TRY(dGp.alloc(6));
     HIP_TRY(hipMemcpy(dLwl, lwl, sizeof(double) * (size_t)c * N, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dGp, gp, sizeof(double) * 2 * c, hipMemcpyHostToDevice));
     if (sigma) {
-        HIP_TRY(hipMalloc(&dSig, sizeof(double) * N));
+        HIP_TRY(dSig.alloc(N));
         HIP_TRY(hipMemcpy(dSig, sigma, sizeof(double) * N, hipMemcpyHostToDevice));
     }
     dim3 grid(P * P, 1);
     if (c == 1)
-        hipLaunchKernelGGL(k_fill_sym<1>, grid, dim3(256), 0, 0, dK, (size_t)0, Npad, N, P, dLwl, dGp, dSig, 0);
+        hipLaunchKernelGGL(k_fill_sym<1>, grid, dim3(256), 0, 0, dK.p, (size_t)0, Npad, N, P, dLwl.p, dGp.p, dSig.p, 0);
     else if (c == 2)
-        hipLaunchKernelGGL(k_fill_sym<2>, grid, dim3(256), 0, 0, dK, (size_t)0, Npad, N, P, dLwl, dGp, dSig, 0);
+        hipLaunchKernelGGL(k_fill_sym<2>, grid, dim3(256), 0, 0, dK.p, (size_t)0, Npad, N, P, dLwl.p, dGp.p, dSig.p, 0);
     else
-        hipLaunchKernelGGL(k_fill_sym<3>, grid, dim3(256), 0, 0, dK, (size_t)0, Npad, N, P, dLwl, dGp, dSig, 0);
+        hipLaunchKernelGGL(k_fill_sym<3>, grid, dim3(256), 0, 0, dK.p, (size_t)0, Npad, N, P, dLwl.p, dGp.p, dSig.p, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy2D(out, sizeof(double) * N, dK, sizeof(double) * Npad, sizeof(double) * N, N,
                         hipMemcpyDeviceToHost));
-    (void)hipFree(dK); (void)hipFree(dLwl); (void)hipFree(dGp); (void)hipFree(dSig);
     return 0;
 }
 
@@ -965,36 +1082,146 @@ extern "C" int psoap_fill_cross(int device, int M, int N, const double* lwl_row,
     if (M <= 0 || N <= 0 || !lwl_row || !lwl_col || !out) FAIL("psoap_fill_cross: bad arguments");
     HIP_TRY(hipSetDevice(device));
     const int ld = round_up(N, 2);
-    double *dO = nullptr, *dRow = nullptr, *dCol = nullptr;
-    HIP_TRY(hipMalloc(&dO, sizeof(double) * (size_t)M * ld));
-    HIP_TRY(hipMalloc(&dRow, sizeof(double) * M));
-    HIP_TRY(hipMalloc(&dCol, sizeof(double) * N));
+    DevBuf<double> dO, dRow, dCol;
+    HIP_TRY(dO.alloc((size_t)M * ld));
+    HIP_TRY(dRow.alloc(M));
+    HIP_TRY(dCol.alloc(N));
     HIP_TRY(hipMemcpy(dRow, lwl_row, sizeof(double) * M, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dCol, lwl_col, sizeof(double) * N, hipMemcpyHostToDevice));
     dim3 grid((N + NB - 1) / NB, (M + NB - 1) / NB);
-    hipLaunchKernelGGL(k_fill_cross, grid, dim3(256), 0, 0, dO, ld, M, N, dRow, dCol, amp, l);
+    hipLaunchKernelGGL(k_fill_cross, grid, dim3(256), 0, 0, dO.p, ld, M, N, dRow.p, dCol.p, amp, l);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy2D(out, sizeof(double) * N, dO, sizeof(double) * ld, sizeof(double) * N, M,
                         hipMemcpyDeviceToHost));
-    (void)hipFree(dO); (void)hipFree(dRow); (void)hipFree(dCol);
     return 0;
 }
 
 // ---- predict ---------------------------------------------------------------------------------
+static int predict_check(int mode, int c, int N, int M, const void* lwl, const void* lwl_pred, const void* mu_c,
+                         const void* gp, const void* mu_out)
+{
+    if (mode < 0 || mode > 2 || c < 1 || c > 3 || N <= 0 || M <= 0 || !lwl || !lwl_pred || !mu_c || !gp || !mu_out)
+        FAIL("psoap_predict: bad arguments");
+    if (mode == 2 && c != 1) FAIL("psoap_predict: mode 2 (predict_f) needs c == 1");
+    return 0;
+}
+
+// handle-less form: a workspace for this one call (freed on every path by its destructor)
 extern "C" int psoap_predict(int device, int mode, int c, int N, int M, const double* lwl, const double* fl,
                              const double* sigma, const double* lwl_pred, const double* mu_c, const double* gp,
                              double* mu_out, double* Sigma_out, int* status_out)
 {
-    if (mode < 0 || mode > 2 || c < 1 || c > 3 || N <= 0 || M <= 0 || !lwl || !fl || !sigma || !lwl_pred || !mu_c ||
-        !gp || !mu_out)
-        FAIL("psoap_predict: bad arguments");
-    if (mode == 2 && c != 1) FAIL("psoap_predict: mode 2 (predict_f) needs c == 1");
-    HIP_TRY(hipSetDevice(device));
-    if (configure_kernels()) return 1;
+    if (!fl || !sigma) FAIL("psoap_predict: bad arguments");
+    if (int rc = predict_check(mode, c, N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
+    if (int rc = enter_device(device)) return rc;
+    PredictWs ws;
+    if (int rc = dag_workers(device, &ws.workers)) return rc;
     int status = 0;
-    int rc = predict_run(mode, c, N, M, lwl, fl, sigma, lwl_pred, mu_c, gp, mu_out, Sigma_out, &status, g_err);
+    const int rc = predict_run(ws, mode, c, N, M, lwl, fl, sigma, nullptr, nullptr, lwl_pred, mu_c, gp, mu_out,
+                               Sigma_out, &status, g_err);
+    (void)hipDeviceSynchronize();
     if (status_out) *status_out = status;
     return rc;
+}
+
+// explicit reusable workspace: the retrieve loop (scripts/psoap_retrieve_ST3.py:148) predicts once per chunk,
+// chunk after chunk; one predictor serves them all and allocates only when a shape outgrows it
+struct psoap_predictor {
+    int device = 0;
+    PredictWs ws;
+};
+
+static void copy_times(const PredictTimes& pt, psoap_predict_timings* t)
+{
+    t->device_ms = pt.device_ms;
+    t->factor_ms = pt.factor_ms;
+    t->sigma_ms = pt.sigma_ms;
+    t->download_ms = pt.download_ms;
+    t->total_ms = pt.total_ms;
+    t->flops = pt.flops;
+}
+
+extern "C" int psoap_predictor_create(psoap_predictor** out, int device)
+{
+    if (!out) FAIL("psoap_predictor_create: bad arguments");
+    *out = nullptr;
+    if (int rc = enter_device(device)) return rc;
+    psoap_predictor* p = new psoap_predictor();
+    p->device = device;
+    if (int rc = dag_workers(device, &p->ws.workers)) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return 0;
+}
+
+extern "C" int psoap_predictor_destroy(psoap_predictor* p)
+{
+    if (!p) return 0;
+    (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();
+    delete p;
+    return 0;
+}
+
+extern "C" int psoap_predictor_run(psoap_predictor* p, int mode, int c, int N, int M, const double* lwl,
+                                   const double* fl, const double* sigma, const double* lwl_pred, const double* mu_c,
+                                   const double* gp, double* mu_out, double* Sigma_out, int* status_out)
+{
+    if (!p || !fl || !sigma) FAIL("psoap_predictor_run: bad arguments");
+    if (int rc = predict_check(mode, c, N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
+    if (int rc = enter_device(p->device)) return rc;
+    int status = 0;
+    const int rc = predict_run(p->ws, mode, c, N, M, lwl, fl, sigma, nullptr, nullptr, lwl_pred, mu_c, gp, mu_out,
+                               Sigma_out, &status, g_err);
+    if (status_out) *status_out = status;
+    return rc;
+}
+
+extern "C" int psoap_predictor_timings(psoap_predictor* p, psoap_predict_timings* t)
+{
+    if (!p || !t) FAIL("psoap_predictor_timings: bad arguments");
+    copy_times(p->ws.times, t);
+    return 0;
+}
+
+// handle-resident form: fl / sigma are the handle's, every device buffer lives in a
+// grow-only workspace owned by the handle, so a second call of the same shape allocates nothing.
+extern "C" int psoap_chunk_predict(psoap_chunk* h, int mode, int c, int M, const double* lwl, const double* lwl_pred,
+                                   const double* mu_c, const double* gp, double* mu_out, double* Sigma_out,
+                                   int* status_out)
+{
+    if (!h) FAIL("psoap_chunk_predict: null handle");
+    if (int rc = predict_check(mode, c, h->N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
+    if (int rc = enter_device(h->device)) return rc;
+    if (!h->pws) {
+        h->pws = new PredictWs();
+        h->pws->workers = h->dag_grid;
+    }
+    int status = 0;
+    const int rc = predict_run(*h->pws, mode, c, h->N, M, lwl, nullptr, nullptr, h->dFl, h->dSigma, lwl_pred, mu_c, gp,
+                               mu_out, Sigma_out, &status, g_err);
+    if (status_out) *status_out = status;
+    return rc;
+}
+
+extern "C" int psoap_chunk_predict_timings(psoap_chunk* h, psoap_predict_timings* t)
+{
+    if (!h || !t) FAIL("psoap_chunk_predict_timings: bad arguments");
+    if (!h->pws) FAIL("psoap_chunk_predict_timings: no predict call on this handle yet");
+    copy_times(h->pws->times, t);
+    return 0;
+}
+
+// drop the handle's predict workspace (it is also freed by psoap_chunk_destroy)
+extern "C" int psoap_chunk_predict_release(psoap_chunk* h)
+{
+    if (!h) FAIL("psoap_chunk_predict_release: null handle");
+    if (set_dev(h)) return 1;
+    delete h->pws;
+    h->pws = nullptr;
+    return 0;
 }
 
 // ---- calibration ------------------------------------------------------------------------------
@@ -1013,8 +1240,7 @@ extern "C" int psoap_calibrate(int device, int c, int M, int N, int order, doubl
     if (c < 1 || c > 3 || calibrate_check(M, N, order, lwl0, lwl1) || !lwl_cal || !lwls_cal || !fl_cal || !sigma_cal ||
         !lwls_fixed || !fl_fixed || !sigma_fixed || !gp || !fl_cor || !X)
         FAIL("psoap_calibrate: bad arguments");
-    HIP_TRY(hipSetDevice(device));
-    if (configure_kernels()) return 1;
+    if (int rc = enter_device(device)) return rc;
     CalibInputs in{};
     in.M = M; in.N = N; in.order = order; in.lwl0 = lwl0; in.lwl1 = lwl1; in.mu = mu_GP;
     in.lwl_cal = lwl_cal; in.fl_cal = fl_cal; in.fl_fixed = fl_fixed;
@@ -1033,8 +1259,7 @@ extern "C" int psoap_calibrate_explicit(int device, int M, int N, int order, dou
 {
     if (calibrate_check(M, N, order, lwl0, lwl1) || !lwl_cal || !fl_cal || !fl_fixed || !A || !B || !C || !fl_cor || !X)
         FAIL("psoap_calibrate_explicit: bad arguments");
-    HIP_TRY(hipSetDevice(device));
-    if (configure_kernels()) return 1;
+    if (int rc = enter_device(device)) return rc;
     CalibInputs in{};
     in.M = M; in.N = N; in.order = order; in.lwl0 = lwl0; in.lwl1 = lwl1; in.mu = mu_GP;
     in.lwl_cal = lwl_cal; in.fl_cal = fl_cal; in.fl_fixed = fl_fixed;

@@ -1,0 +1,155 @@
+"""GPU: the reference's process models on a real device.
+
+* fork-then-INIT workers: ``psoap/sample_parallel.py:258-278`` forks one ``Worker`` per chunk and only then
+  sends ``("INIT", ...)`` and ``("LNPROB", p)`` over a Pipe (:207-249); each child calls
+  ``covariance.lnlike[model](V11, *lwls, fl, sigma, *p_GP)`` (:193).  HIP must come up lazily in the child.
+* one process per GPU with a gather of the per-chunk lnprobs: two ranks on ONE GPU over gloo, including
+  the several-chunks-per-rank (ChunkGroup) branch, must give the single-process sums bit for bit; and
+  ``python bench.py --gpus 2 --backend gloo`` must launch its own ranks and print one JSON line.
+"""
+import json
+import multiprocessing as mp
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from psoap_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------------------------------------- fork workers
+def _worker_brain(conn, model):
+    """The body of Worker.brain / interpret (sample_parallel.py:207-249), talking over the child's Pipe end."""
+    state = {}
+    while True:
+        fname, arg = conn.recv()
+        if fname == "INIT":
+            from psoap_amd import covariance          # first device touch happens in the child, after the fork
+            lwls, fl, sigma = arg
+            state.update(cov=covariance, lwls=lwls, fl=fl, sigma=sigma, V11=np.empty((1, 1)))
+            conn.send(("OK", os.getpid()))
+        elif fname == "LNPROB":
+            cov = state["cov"]
+            lnp = cov.lnlike[model](state["V11"], *state["lwls"], state["fl"], state["sigma"], *arg)
+            conn.send(float(lnp))
+        elif fname == "FINISH":
+            state["cov"].release_handles()
+            conn.send("DONE")
+            return
+
+
+def test_fork_then_init_workers_like_sample_parallel(oracle):
+    ctx = mp.get_context("fork")
+    chunks = [syn.make_chunk(2, 6, 100, seed=7700 + k) for k in range(2)]       # N = 600 each
+    # the parent must not have initialised HIP before forking -- this test process has (other tests ran),
+    # which is exactly the hazard: children created by fork cannot reuse the parent's runtime.  The
+    # reference forks from a master that never calls lnlike; reproduce that with a clean launcher process.
+    code = r'''
+import sys, json, multiprocessing as mp, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from test_gpu_workers import _worker_brain
+from psoap_amd import synthetic as syn
+ctx = mp.get_context("fork")
+chunks = [syn.make_chunk(2, 6, 100, seed=7700 + k) for k in range(2)]
+pconns, procs = [], []
+for ch in chunks:                                  # sample_parallel.py:264-269: fork first ...
+    pc, cc = ctx.Pipe()
+    p = ctx.Process(target=_worker_brain, args=(cc, "SB2"))
+    p.start(); pconns.append(pc); procs.append(p)
+for pc, ch in zip(pconns, chunks):                 # ... then INIT (:271-276)
+    pc.send(("INIT", (ch.lwls, ch.fl, ch.sigma)))
+pids = [pc.recv()[1] for pc in pconns]
+out = []
+for gp in [syn.GP_BASE[2], (0.25, 4.0, 0.12, 6.5), (0.2, 5.0, -0.1, 7.0)]:
+    for pc in pconns:                              # :378-387: send to all, gather, sum
+        pc.send(("LNPROB", gp))
+    out.append([pc.recv() for pc in pconns])
+for pc in pconns:
+    pc.send(("FINISH", None)); pc.recv()
+for p in procs:
+    p.join(60)
+print(json.dumps({"pids": pids, "lnp": [[v if np.isfinite(v) else "-inf" for v in row] for row in out],
+                  "exit": [p.exitcode for p in procs]}))
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    rec = json.loads(res.stdout.strip().splitlines()[-1])
+    assert rec["exit"] == [0, 0] and len(set(rec["pids"])) == 2
+    gps = [syn.GP_BASE[2], (0.25, 4.0, 0.12, 6.5)]
+    for i, gp in enumerate(gps):
+        for k, ch in enumerate(chunks):
+            want = oracle.lnlike(ch.lwls, ch.fl, ch.sigma, gp)
+            got = rec["lnp"][i][k]
+            assert abs(got - want) <= 1e-10 * max(1.0, abs(want)), (i, k, got, want)
+    assert rec["lnp"][2] == ["-inf", "-inf"]            # negative l: -inf from every worker (covariance.py:339)
+
+
+# ---------------------------------------------------------------------------------------------- two ranks, one GPU
+_RANK_CODE = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from psoap_amd import synthetic as syn
+from psoap_amd.ensemble import EnsembleEvaluator
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo")
+n_chunks, B = %d, 5
+chunks = [syn.make_chunk(2, 5 + (k %% 3), 90 + 10 * k, seed=7800 + k) for k in range(n_chunks)]
+gps = syn.make_walkers(2, B, seed=7850)
+props = {k: (syn.walker_lwls(ch, syn.make_walker_velocities(ch, B, seed=7860 + k)), gps) for k, ch in enumerate(chunks)}
+ev = EnsembleEvaluator.from_chunks(chunks, max_batch=B, world=world, rank=rank, device_index=0)
+tot = ev.lnprob(props)
+tot2 = ev.lnprob(props)
+assert np.array_equal(tot, tot2)
+grouped = getattr(ev, "group", None) is not None
+ev.close()
+if rank == 0:
+    print("RESULT " + json.dumps({"tot": [float(x).hex() for x in tot], "grouped": grouped, "mine": ev.mine}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("n_chunks", [2, 5])     # one chunk per rank / several per rank (ChunkGroup branch)
+def test_two_ranks_one_gpu_gloo_bit_identical_to_single_process(tmp_path, n_chunks):
+    prog = tmp_path / "rank_prog.py"
+    prog.write_text(_RANK_CODE % (ROOT, n_chunks))
+    outs = {}
+    for world in (1, 2):
+        port = 29500 + (os.getpid() + 7 * world + n_chunks) % 2000
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(prog)]
+        env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+        outs[world] = json.loads(line[len("RESULT "):])
+    assert outs[1]["tot"] == outs[2]["tot"], (outs[1], outs[2])            # hex strings: bit for bit
+    if n_chunks == 5:
+        assert outs[2]["grouped"] and outs[2]["mine"] == [0, 2, 4]
+    else:
+        assert not outs[2]["grouped"]
+
+
+def test_bench_launches_its_own_ranks_gloo_dry_run():
+    """`python bench.py --gpus 2 --backend gloo` (no launcher, one GPU): the parent spawns both ranks before
+    touching the device and relays ONE JSON line; the gathered table is checked against the reference goldens
+    inside bench.py (parity_checked)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                          "--steps", "2", "--warmup", "1", "--walkers", "8"],
+                         capture_output=True, text=True, timeout=1500, env=env)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["parity_checked"] is True and rec["backend"] == "gloo"
+    assert rec["value"] > 0 and rec["scaling"] == "weak" and rec["parity"]["golden_cfg4_table"] == [2, 4]
