@@ -108,15 +108,20 @@ class Posterior:
         P = np.atleast_2d(np.asarray(P, dtype=np.float64))
         B = P.shape[0]
         lnprior = np.asarray(self.prior(P), dtype=np.float64)
-        ok = np.isfinite(lnprior)                 # -inf prior: never evaluated (:373-375)
+        ok = np.isfinite(lnprior)                 # -inf prior: the reference never evaluates those (:373-375)
         out = np.full(B, -np.inf)
-        n_ok = int(ok.sum())
         # every rank sees the same P, hence the same `ok`: the collective below stays matched
-        if n_ok:
-            block = np.empty((len(self.mine), n_ok))
-            Pok = P[ok]
-            for s in range(0, n_ok, self.max_batch):
-                piece = Pok[s:s + self.max_batch]
+        if ok.any():
+            # The device batch keeps its size: a prior-rejected slot is evaluated on a stand-in (the first
+            # admissible proposal) and overwritten with -inf afterwards.  A batch whose size followed the
+            # number of rejections would rebuild and re-upload the task list on every change, and -- the
+            # split factors depend on the batch size -- give the same proposal different last bits
+            # depending on how many OTHER chains were rejected.
+            Pev = P.copy()
+            Pev[~ok] = P[ok][0]
+            block = np.empty((len(self.mine), B))
+            for s in range(0, B, self.max_batch):
+                piece = Pev[s:s + self.max_batch]
                 if self.group is not None:
                     for k in self.mine:
                         self.workers[k].upload_proposals(piece)
@@ -127,7 +132,7 @@ class Posterior:
                     for i, k in enumerate(self.mine):
                         block[i, s:s + self.max_batch] = self.workers[k].lnprob_batch(piece)
             table = gather_chunk_lnprobs(block, self.n_chunks, self.world, self.rank, self.device_index)
-            out[ok] = sum_over_chunks(table) + lnprior[ok]
+            out[ok] = (sum_over_chunks(table) + lnprior)[ok]
         return out
 
     def lnprob(self, p):
@@ -135,12 +140,20 @@ class Posterior:
 
 
 def run(config, chunks, run_index=0, n_chains=1, seed=None, world=1, rank=0, device_index=None, iterations=None,
-        config_path=None, make_worker=None, prior=None, verbose=True):
+        config_path=None, make_worker=None, prior=None, verbose=True, overwrite=False):
     """Sample ``n_chains`` chains for ``config['samples']`` iterations; returns the sampler.
 
     Chain b uses ``RandomState(seed + b)`` when ``seed`` is given (fresh entropy otherwise -- then every
     rank must be handed the same ``seed``: pass one explicitly under torch.distributed).
+    Chain b is written to ``run{run_index + b}``; existing output directories are only replaced with
+    ``overwrite=True`` (the reference replaces its single ``run{idx}``, sample_parallel.py:24-30 -- with
+    ``n_chains`` directories per invocation a silent replace would wipe earlier runs).
     """
+    routdirs = [os.path.join(config["outdir"], "run{:0>2}".format(run_index + b)) + "/" for b in range(n_chains)]
+    taken = [d for d in routdirs if os.path.exists(d)]
+    if taken and not overwrite:
+        raise FileExistsError("output directories exist (pass overwrite=True / --overwrite to replace them): "
+                              + ", ".join(taken))
     model = config["model"]
     pars = config["parameters"]
     fix = config["fix_params"]
@@ -170,8 +183,7 @@ def run(config, chunks, run_index=0, n_chains=1, seed=None, world=1, rank=0, dev
     if rank == 0:
         if verbose:
             print("Acceptance fraction", sampler.acceptance_fraction)
-        for b in range(n_chains):
-            routdir = os.path.join(config["outdir"], "run{:0>2}".format(run_index + b)) + "/"
+        for b, routdir in enumerate(routdirs):
             if os.path.exists(routdir):
                 shutil.rmtree(routdir)
             os.makedirs(routdir)
@@ -190,6 +202,7 @@ def main(argv=None):
     parser.add_argument("--seed", type=int, default=None)
     parser.add_argument("--config", default="config.yaml")
     parser.add_argument("--prefix", default="", help="Directory prefix of the chunk files.")
+    parser.add_argument("--overwrite", action="store_true", help="Replace existing run directories.")
     args = parser.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -212,7 +225,7 @@ def main(argv=None):
         print("Loaded user defined prior." if prior is not None else "Using default prior.")
     try:
         run(config, chunks, args.run_index, args.chains, seed, world, rank, local if world > 1 else None,
-            config_path=args.config, prior=prior)
+            config_path=args.config, prior=prior, overwrite=args.overwrite)
     finally:
         if world > 1:
             import torch.distributed as dist

@@ -235,19 +235,30 @@ def test_driver_single_process(tmp_path):
     cfg2 = dict(config, opt_jump=str(tmp_path / "opt.npy"))
     s2 = sp.run(cfg2, chunks, n_chains=2, seed=1, make_worker=lambda ch: _OracleWorker(ch, cfg2), verbose=False)
     assert np.abs(s2.chain - p0).max() < 0.05
+    # run00 / run01 exist now: a second invocation must not silently wipe them
+    with pytest.raises(FileExistsError, match="run00"):
+        sp.run(cfg2, chunks, n_chains=2, seed=1, make_worker=lambda ch: _OracleWorker(ch, cfg2), verbose=False)
+    keep = np.load(str(tmp_path / "output" / "run03" / "flatchain.npy"))
+    sp.run(cfg2, chunks, n_chains=2, seed=2, make_worker=lambda ch: _OracleWorker(ch, cfg2), verbose=False, overwrite=True)
+    assert np.array_equal(np.load(str(tmp_path / "output" / "run03" / "flatchain.npy")), keep)   # untouched
     # a starting point outside the prior aborts (sample_parallel.py:405-419)
     bad = dict(config, parameters=dict(config["parameters"], K=-1.0))
     with pytest.raises(RuntimeError, match="-np.inf"):
-        sp.run(bad, chunks, n_chains=2, seed=1, make_worker=lambda ch: _OracleWorker(ch, bad), verbose=False)
+        sp.run(bad, chunks, n_chains=2, seed=1, make_worker=lambda ch: _OracleWorker(ch, bad), verbose=False,
+               overwrite=True)
 
 
-def test_posterior_skips_rows_outside_prior():
+def test_posterior_keeps_batch_size_and_masks_rows_outside_prior():
+    """Prior-rejected rows are -inf without their parameters ever reaching a worker, and the device batch
+    keeps its size (a stand-in proposal fills the slot), so the task list and the split factors -- hence the
+    last bits of the other chains -- do not depend on how many rows were rejected."""
     from psoap_amd import sample_parallel as sp
     seen = []
 
     class W:
         def lnprob_batch(self, P):
             seen.append(len(P))
+            assert np.all(P[:, 1] > 0.0) and np.all(P[:, 2] < 1.0)      # only admissible proposals arrive
             return np.full(len(P), -1.5)
 
     post = sp.Posterior("SB2", _chunks(2), ["gamma"], CONFIG["parameters"], max_batch=2, make_worker=lambda ch: W())
@@ -256,7 +267,7 @@ def test_posterior_skips_rows_outside_prior():
     P[4, 2] = 1.5                                     # e > 1
     out = post.lnprob_batch(P)
     assert out.tolist() == [-3.0, -np.inf, -3.0, -3.0, -np.inf]
-    assert seen == [2, 2, 1, 1]                       # 3 rows evaluated per chunk, in max_batch pieces (piece-major)
+    assert seen == [2, 2, 2, 2, 1, 1]                 # all 5 slots per chunk, in max_batch pieces (piece-major)
     seen.clear()
     assert post.lnprob_batch(P[[1, 4]]).tolist() == [-np.inf, -np.inf] and seen == []
 
