@@ -149,11 +149,6 @@ def run(config, chunks, run_index=0, n_chains=1, seed=None, world=1, rank=0, dev
     ``overwrite=True`` (the reference replaces its single ``run{idx}``, sample_parallel.py:24-30 -- with
     ``n_chains`` directories per invocation a silent replace would wipe earlier runs).
     """
-    routdirs = [os.path.join(config["outdir"], "run{:0>2}".format(run_index + b)) + "/" for b in range(n_chains)]
-    taken = [d for d in routdirs if os.path.exists(d)]
-    if taken and not overwrite:
-        raise FileExistsError("output directories exist (pass overwrite=True / --overwrite to replace them): "
-                              + ", ".join(taken))
     model = config["model"]
     pars = config["parameters"]
     fix = config["fix_params"]
@@ -161,6 +156,11 @@ def run(config, chunks, run_index=0, n_chains=1, seed=None, world=1, rank=0, dev
     p0 = utils.convert_dict(model, fix, **pars)
     if world > 1 and seed is None:
         raise ValueError("multi-rank sampling needs an explicit seed so that all ranks draw the same proposals")
+    routdirs = [os.path.join(config["outdir"], "run{:0>2}".format(run_index + b)) + "/" for b in range(n_chains)]
+    taken = [d for d in routdirs if os.path.exists(d)]
+    if taken and not overwrite:
+        raise FileExistsError("output directories exist (pass overwrite=True / --overwrite to replace them): "
+                              + ", ".join(taken))
     post = Posterior(model, chunks, fix, pars, soften=config.get("soften", 1.0), max_batch=n_chains, world=world,
                      rank=rank, device_index=device_index, prior=prior, make_worker=make_worker)
     try:
