@@ -29,6 +29,7 @@
 // rows < q; it is split so that rows < q-1 are consumed before waiting for row q-1 (look-ahead).
 #pragma once
 #include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "chol_kernels.hpp"
@@ -38,10 +39,14 @@
 namespace psoap {
 
 struct alignas(64) MatFlags {
-    int rows_done;
-    int potrf_done;
-    int cnt;
-    int pad[13];
+    int rows_done;    // block rows completely finished
+    int potrf_done;   // diagonal blocks factored
+    int cnt[2];       // finished tasks of block row q in cnt[q & 1]: the latency scheme starts DIAG(q+1) while
+                      // row q is still being solved, so two rows count at the same time (never three: DIAG(q+2)
+                      // needs all of row q)
+    int next_done;    // q + 1 once U(q, q+1), the tile right of the diagonal, is final (fused into DIAG(q))
+    int off1_ready;   // q + 1 once tile (q, q+1) holds its fully updated value, ready for the strip solve
+    int pad[10];
 };
 
 constexpr int DAG_QUEUES = 8;   // one ticket queue per XCD (MI355X: 8 XCDs, each with its own 4 MiB L2)
@@ -71,7 +76,14 @@ struct DagQueues {
 // over rows < q while block row q is still in flight (its final part is one panel long, so the
 // critical chain per block row is 128-row update -> in-block Cholesky), and the last block rows,
 // which have too few tiles to occupy the persistent grid, are cut into up to 8 parts per tile.
-enum : unsigned char { DAG_PART = 0, DAG_DIAG = 1, DAG_OFF = 2, DAG_TYPE_MASK = 0x0F, DAG_CHAIN = 0x10 };
+// Latency scheme only -- the row-to-row critical path potrf(q) -> strip solve of (q, q+1) -> update of
+// (q+1, q+1) -> potrf(q+1) is kept inside the DIAG tasks, one cross-workgroup hand-off per block row:
+//   DAG_FUSED    (DIAG)  after the in-block Cholesky the same workgroup solves tile (q, q+1) and publishes
+//                        next_done = q + 1;
+//   DAG_WAITNEXT (DIAG)  the final part [q-1, q) waits for next_done >= q instead of the whole block row;
+//   DAG_NOSOLVE  (OFF)   tile (q, q+1): update only, publishes off1_ready = q + 1 (the DIAG task solves it).
+enum : unsigned char { DAG_PART = 0, DAG_DIAG = 1, DAG_OFF = 2, DAG_TYPE_MASK = 0x0F, DAG_CHAIN = 0x10,
+                       DAG_NOSOLVE = 0x20, DAG_WAITNEXT = 0x40, DAG_FUSED = 0x80 };
 struct DagTask {
     unsigned char type, q, j, S;
     unsigned short b;
@@ -129,16 +141,17 @@ __device__ __forceinline__ void dag_release_fence()
 }
 
 // a task of block row q of this matrix is complete (thread 0, after dag_release_fence)
-__device__ __forceinline__ void dag_task_done(MatFlags* f, int q, int ntasks_row)
+__device__ __forceinline__ void dag_task_done(MatFlags* f, int q, int ntasks_row, int n = 1)
 {
-    const int old = __hip_atomic_fetch_add(&f->cnt, 1, PSOAP_RLX_AGENT);
-    if (old + 1 == ntasks_row) {
+    int* cnt = &f->cnt[q & 1];
+    const int old = __hip_atomic_fetch_add(cnt, n, PSOAP_RLX_AGENT);
+    if (old + n == ntasks_row) {
         // last finisher of the row: order after every other task's release, then publish the row
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // the reset must be visible before any task of the next row -- released by rows_done -- adds to
         // cnt: drain the reset, then publish the row with a release store (two relaxed stores are unordered)
-        __hip_atomic_store(&f->cnt, 0, PSOAP_RLX_AGENT);
+        __hip_atomic_store(cnt, 0, PSOAP_RLX_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&f->rows_done, q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -147,7 +160,7 @@ __device__ __forceinline__ void dag_task_done(MatFlags* f, int q, int ntasks_row
 // left-looking update over finished block rows [pa, pb) with look-ahead: all but the last panel
 // need rows_done >= pb-1, the last one rows_done >= pb
 __device__ __forceinline__ void dag_update(Tile& t, double* Km, int ld, int k0, int j0, int pa, int pb, MatFlags* f,
-                                           DagCtl* ctl)
+                                           DagCtl* ctl, bool wait_next, unsigned long long* tl)
 {
     if (pb <= pa) return;
     const bool diag = (k0 == j0);
@@ -156,18 +169,21 @@ __device__ __forceinline__ void dag_update(Tile& t, double* Km, int ld, int k0, 
         const size_t r0 = (size_t)pa * NB;
         tile_gemm_tn(t, Km + r0 * ld + k0, (size_t)ld, Km + r0 * ld + j0, (size_t)ld, (pb - 1 - pa) * NB, diag);
     }
-    dag_wait_ge(&f->rows_done, pb, ctl, 2u);
+    // the last panel: the whole block row above, or (diagonal tile of the latency scheme) only its tile
+    // right of the diagonal -- U(pb-1, pb), all this tile reads of that row
+    dag_wait_ge(wait_next ? &f->next_done : &f->rows_done, pb, ctl, 2u);
+    if (tl && threadIdx.x == 0) tl[4] = __builtin_amdgcn_s_memrealtime();
     const size_t r1 = (size_t)(pb - 1) * NB;
     tile_gemm_tn(t, Km + r1 * ld + k0, (size_t)ld, Km + r1 * ld + j0, (size_t)ld, NB, diag);
 }
 
 // The ONE consumer of the accumulators.  Every task ends its update here:
-//     dest(i, j) <- scale * K(i, j) - acc(i, j) + sum_s prev_s(i, j)
+//     dest(i, j) <- scale * K(i, j) - acc(i, j)
 //   final tasks : dest = the tile (k0, j0) of the matrix, scale = 1 (0 in a chain, whose first PART
-//                 carries K instead), prev = the n_prev partial tiles
-//                 left by the tile's PART tasks (all S-1 of them, or the running sum of a chain);
-//   PART tasks  : dest = a workspace slot (row-major 128 x 128), scale = 0, prev = the slot of the
-//                 previous PART of a chain (n_prev = 1) or nothing.
+//                 carries K instead);
+//   PART tasks  : dest = a workspace slot (row-major 128 x 128), scale = 0.
+// The partial tiles left by a tile's PART tasks (all S-1 of them, or the running sum of a chain) have
+// been folded into the accumulators before (dag_sub_partials).
 // K is evaluated on the fly in the MFMA accumulator layout (same arithmetic as k_fill_sym:
 // squared-exponential sum, diagonal rule, sigma^2 on the diagonal, identity padding), so the
 // covariance matrix is never materialised in HBM: each tile is written once, already updated.
@@ -189,7 +205,8 @@ struct DagAug {
 struct DagMat {
     double* K;            // (Npad x ld) row-major upper storage, overwritten by the factor
     double* R;            // (Npad) r -> z
-    double* Wt;           // (128 x 128) U11^-T of the current diagonal block, k-major
+    double* Wt;           // 2 x (128 x 128): U11^-T of diagonal block q, k-major, in buffer q & 1 (DIAG(q+1) may
+                          // factor while the strip solves of row q still read theirs)
     const double* lw;     // (C, N) ln-wavelengths per component
     const double* gp;     // (2C) amp, l per component
     const double* sigma;  // (N)
@@ -198,10 +215,10 @@ struct DagMat {
 };
 
 template <int C, bool AUG>
-__device__ __forceinline__ void dag_store_updated(const Tile& t, double* dest, size_t ldd, int k0, int j0,
+__device__ __forceinline__ void dag_store_updated(const Tile& t, double* __restrict__ dest, size_t ldd, int k0, int j0,
                                                   const double* __restrict__ lw, const GpDev& g, double dsum,
                                                   const double* __restrict__ sigma, int N, double scale,
-                                                  const double* prev, int n_prev, int Npad, const DagAug& aug)
+                                                  int Npad, const DagAug& aug)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -252,12 +269,30 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* dest, s
                     v = (i == j) ? 1.0 : 0.0;
                 }
                 const int jc = tile_col(wc, n, lane);                          // column inside the tile
-                const size_t off = (size_t)(i - k0) * NB + (size_t)jc;         // inside a 128 x 128 slot
-                double x = scale * v - t.acc[m][n][r];
-                for (int sidx = 0; sidx < n_prev; ++sidx) x += prev[(size_t)sidx * NB * NB + off];
-                dest[(size_t)(i - k0) * ldd + (size_t)jc] = x;
+                dest[(size_t)(i - k0) * ldd + (size_t)jc] = scale * v - t.acc[m][n][r];
             }
         }
+    }
+}
+
+// accumulators -= partial tiles prev[0 .. n_prev), in slot order (row-major 128 x 128 workspace slots).
+// All 64 loads of a slot are in flight together; folding the partial sums into the accumulators keeps
+// the store routine free of them (a load per element between its stores serialised on the memory
+// latency: 64 round trips, 44 us per tile).  A chain's final calls this BEFORE it waits for the block row
+// above -- its PARTs ran ahead -- so the running sum is read off the row-to-row path.
+__device__ __forceinline__ void dag_sub_partials(Tile& t, const double* __restrict__ prev, int n_prev)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    for (int sidx = 0; sidx < n_prev; ++sidx) {
+        const double* __restrict__ ps = prev + (size_t)sidx * NB * NB;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    t.acc[m][n][r] -= ps[(size_t)tile_row(wr, m, lane, r) * NB + (size_t)tile_col(wc, n, lane)];
     }
 }
 
@@ -361,24 +396,40 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         const DagMat mat = mats[b];
         double* Km = mat.K;
         double* Rv = mat.R;
-        double* Wm = mat.Wt;
+        double* Wm = mat.Wt + (size_t)(q & 1) * NB * NB;
         const int ld = mat.ld, N = mat.N, Npad = mat.Npad;
         MatFlags* f = flags + b;
         const int k0 = q * NB, j0 = j * NB;
         const int ntasks_row = (AUG ? aug.Pt : mat.P) - q;
 
-        if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 0] = __builtin_amdgcn_s_memrealtime();
-        t.zero();
-        dag_update(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl);
+        if (tlog && threadIdx.x == 0) {
+            tlog[ticket * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+            tlog[ticket * 8 + 7] = __builtin_amdgcn_s_memtime();     // shader clock = d(memtime) / d(realtime) x 100 MHz
+        }
         const int ttype = task.type & DAG_TYPE_MASK;
         const bool chain = (task.type & DAG_CHAIN) != 0;
         const bool is_part = (ttype == DAG_PART);
         // partial sums of a split tile, two schemes (dag_emit): gathered -- the final waits for all S-1
         // PARTs and adds their S-1 tiles; chained -- PART s waits for PART s-1 and adds its tile to its
-        // own, the final adds the last one
+        // own, the final starts from the last one
         const int n_wait = is_part ? (chain ? (int)task.S : 0) : (int)task.S - 1;
-        const int n_prev = is_part ? (n_wait > 0 ? 1 : 0) : (chain ? (n_wait > 0 ? 1 : 0) : n_wait);
-        if (n_wait > 0) dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);
+        int n_prev = is_part ? (n_wait > 0 ? 1 : 0) : (chain ? (n_wait > 0 ? 1 : 0) : n_wait);
+        // chained PART: the predecessor's tile sits in the other slot of the even/odd pair
+        const double* prev = wspace + (size_t)(is_part ? task.slot ^ 1u : task.slot) * SLOT;
+        const bool preload = !is_part && chain && n_wait > 0;
+        t.zero();
+        if (preload) {
+            // the chain ran ahead (its PARTs need older block rows): normally no wait at all
+            dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);
+            dag_sub_partials(t, prev, 1);
+            n_prev = 0;
+        }
+        dag_update(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl, (task.type & DAG_WAITNEXT) != 0,
+                   tlog ? tlog + ticket * 8 : nullptr);
+        if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+        if (!preload && n_wait > 0) dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);
+        if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+        dag_sub_partials(t, prev, n_prev);
         {
             GpDev g;
             load_gp(mat.gp, C, g);
@@ -388,14 +439,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
                 for (int c = 1; c < C; ++c) dsum = dsum + g.a2[c];
             }
             double* dest = is_part ? (wspace + (size_t)task.slot * SLOT) : (Km + (size_t)k0 * ld + j0);
-            // chained PART: the predecessor's tile sits in the other slot of the even/odd pair
-            const double* prev = wspace + (size_t)(is_part ? task.slot ^ 1u : task.slot) * SLOT;
             // who adds K(i, j): the final task -- except in a chain, where the FIRST PART carries it, so
             // that the exp() evaluations are off the critical row-to-row path (the final of a chain runs
             // right after the block row above completes; its PARTs ran ahead)
             const bool carries_k = chain ? (is_part ? task.S == 0 : task.S <= 1) : !is_part;
             dag_store_updated<C, AUG>(t, dest, is_part ? (size_t)NB : (size_t)ld, k0, j0, mat.lw, g, dsum, mat.sigma, N,
-                                      carries_k ? 1.0 : 0.0, prev, n_prev, Npad, aug);
+                                      carries_k ? 1.0 : 0.0, Npad, aug);
         }
         if (is_part) {
             dag_drain();
@@ -403,23 +452,46 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
                 dag_release_fence();
                 __hip_atomic_fetch_add(&arrive[task.ctr], 1, PSOAP_RLX_AGENT);
             }
-            if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+            if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
             continue;
         }
         dag_drain();  // the tile is re-read below in another layout by other waves of this block
-        if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+        if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 1] = __builtin_amdgcn_s_memrealtime();
         if (ttype == DAG_DIAG) {
+            // the diagonal task is the row-to-row critical path: let its waves win the issue arbitration
+            // against the co-resident workgroup (N = 2000, B = 32: -4 % with the deferred W output)
+            __builtin_amdgcn_s_setprio(3);
             potrf_blocked(Km, ld, k0, Wm, Rv, mat.acc);
             dag_drain();
-            if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+            if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 2] = __builtin_amdgcn_s_memrealtime();
             if (threadIdx.x == 0) {
                 dag_release_fence();
                 __hip_atomic_store(&f->potrf_done, q + 1, PSOAP_RLX_AGENT);
+            }
+            if (task.type & DAG_FUSED) {
+                // the critical path stays in this workgroup: solve the tile right of the diagonal now (its
+                // updated value was prepared by a DAG_NOSOLVE task while the block was being factored) and
+                // hand U(q, q+1) -- all that the next diagonal tile needs from this block row -- to DIAG(q+1)
+                dag_wait_ge(&f->off1_ready, q + 1, ctl, 5u);
+                dag_trsm(t, Km, ld, k0, k0 + NB, Wm, Rv, Npad, vec1, vec2);
+                dag_drain();
+                if (threadIdx.x == 0) {
+                    dag_release_fence();
+                    __hip_atomic_store(&f->next_done, q + 1, PSOAP_RLX_AGENT);
+                    dag_task_done(f, q, ntasks_row, 2);
+                }
+            } else if (threadIdx.x == 0) {
                 dag_task_done(f, q, ntasks_row);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        } else if (task.type & DAG_NOSOLVE) {
+            if (threadIdx.x == 0) {
+                dag_release_fence();
+                __hip_atomic_store(&f->off1_ready, q + 1, PSOAP_RLX_AGENT);
             }
         } else {
             dag_wait_ge(&f->potrf_done, q + 1, ctl, 3u + 16u * (unsigned int)q + 4096u * (unsigned int)b);
-            if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+            if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 2] = __builtin_amdgcn_s_memrealtime();
             dag_trsm(t, Km, ld, k0, j0, Wm, Rv, Npad, vec1, vec2);
             dag_drain();
             if (threadIdx.x == 0) {
@@ -427,7 +499,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
                 dag_task_done(f, q, ntasks_row);
             }
         }
-        if (tlog && threadIdx.x == 0) tlog[ticket * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+        if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -468,7 +540,8 @@ inline int dag_split_factor(int tasks_in_row, int q, int workers)
 // Encoding: PART.S = index in the chain (0 when gathered), PART.slot = its output (gathered:
 // consecutive slots; chained: an even/odd pair used alternately); final.S = number of pieces,
 // final.slot = first slot to read (gather: the first PART's, chain: the last PART's).  nsplit == 1: one final over the whole range.
-inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first, int pb_last, int nsplit, int scheme)
+inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first, int pb_last, int nsplit, int scheme,
+                     unsigned char final_flags = 0)
 {
     const bool chain = (scheme == 1) && nsplit > 1;
     const int nparts = chain ? nsplit : nsplit - 1;                 // PART tasks
@@ -495,7 +568,7 @@ inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first,
     }
     if (chain) plan.n_slots = slot0 + 2;
     DagTask t{};
-    t.type = (unsigned char)type | flag;
+    t.type = (unsigned char)type | flag | final_flags;
     t.b = (unsigned short)b;
     t.q = (unsigned char)q;
     t.j = (unsigned char)j;
@@ -539,14 +612,21 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
         }
         const int Bq = live;
         const int S_off = dag_split_factor((int)row_tiles, q, workers);
+        // latency scheme: DIAG(q) also solves the tile right of the diagonal (DAG_FUSED) whenever a next
+        // diagonal tile exists, and DIAG(q >= 1) waits only for that tile of the row above (DAG_WAITNEXT)
+        auto fused = [&](int b) { return scheme == 1 && q + 1 < Ps[b]; };
         // 1. DIAG finals of this row
         if (q <= 1) {
             for (int b : mats)
-                if (q < Ps[b]) dag_emit(plan, DAG_DIAG, b, q, q, 0, q, 1, scheme);
+                if (q < Ps[b])
+                    dag_emit(plan, DAG_DIAG, b, q, q, 0, q, 1, scheme,
+                             (unsigned char)((fused(b) ? DAG_FUSED : 0) | (scheme == 1 && q == 1 ? DAG_WAITNEXT : 0)));
         } else {
             for (const DagTask& t : early_final[q]) plan.tasks.push_back(t);
         }
-        // 2. pre-accumulate the diagonal tile of row q+1 over rows [0, q): PARTs now, final (panel q) later
+        // 2. pre-accumulate the diagonal tile of row q+1 over rows [0, q): PARTs now, final (panel q) later.
+        // Latency scheme: the PART that needs the block row just above (panel q-1, available only when ALL
+        // of row q-1 is finished) is one panel long; the long ones cover [0, q-1) and run a row earlier.
         if (q + 1 < P && q >= 1) {
             const int S_pre = dag_split_factor(Bq, q, workers / 4 > 0 ? workers / 4 : 1);
             for (int b : mats) {
@@ -556,35 +636,53 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
                 if (chain) plan.n_slots += plan.n_slots & 1u;
                 const unsigned int slot0 = plan.n_slots;
                 const unsigned char flag = chain ? DAG_CHAIN : 0;
-                for (int sidx = 0; sidx < S_pre; ++sidx) {
+                // ranges of the PARTs
+                std::vector<std::pair<int, int>> ranges;
+                if (chain && q >= 2) {
+                    int S_long = S_pre;
+                    while (S_long > 1 && (q - 1) / S_long < 1) S_long /= 2;
+                    for (int sidx = 0; sidx < S_long; ++sidx)
+                        ranges.emplace_back((int)((long long)(q - 1) * sidx / S_long),
+                                            (int)((long long)(q - 1) * (sidx + 1) / S_long));
+                    ranges.emplace_back(q - 1, q);
+                } else {
+                    for (int sidx = 0; sidx < S_pre; ++sidx)
+                        ranges.emplace_back((int)((long long)q * sidx / S_pre), (int)((long long)q * (sidx + 1) / S_pre));
+                }
+                const int n_parts = (int)ranges.size();
+                for (int sidx = 0; sidx < n_parts; ++sidx) {
                     DagTask t{};
                     t.type = DAG_PART | flag;
                     t.b = (unsigned short)b;
                     t.q = (unsigned char)(q + 1);
                     t.j = (unsigned char)(q + 1);
                     t.S = (unsigned char)(chain ? sidx : 0);
-                    t.pa = (unsigned char)((long long)q * sidx / S_pre);
-                    t.pb = (unsigned char)((long long)q * (sidx + 1) / S_pre);
+                    t.pa = (unsigned char)ranges[sidx].first;
+                    t.pb = (unsigned char)ranges[sidx].second;
                     t.slot = chain ? slot0 + (unsigned int)(sidx & 1) : plan.n_slots++;
                     t.ctr = ctr;
                     plan.tasks.push_back(t);
                 }
-                if (chain) plan.n_slots = slot0 + (S_pre > 1 ? 2 : 1);
+                if (chain) plan.n_slots = slot0 + (n_parts > 1 ? 2 : 1);
                 DagTask fin{};
                 fin.type = DAG_DIAG | flag;
+                if (chain) fin.type |= DAG_WAITNEXT;
+                if (chain && q + 2 < Ps[b]) fin.type |= DAG_FUSED;
                 fin.b = (unsigned short)b;
                 fin.q = fin.j = (unsigned char)(q + 1);
-                fin.S = (unsigned char)(S_pre + 1);
+                fin.S = (unsigned char)(n_parts + 1);
                 fin.pa = (unsigned char)q;
                 fin.pb = (unsigned char)(q + 1);
-                fin.slot = chain ? slot0 + (unsigned int)((S_pre - 1) & 1) : slot0;
+                fin.slot = chain ? slot0 + (unsigned int)((n_parts - 1) & 1) : slot0;
                 fin.ctr = ctr;
                 early_final[q + 1].push_back(fin);
             }
         }
         // 3. off-diagonal tiles of this row
         for (int b : mats)
-            for (int j = q + 1; j < Ps[b] + Mt && q < Ps[b]; ++j) dag_emit(plan, DAG_OFF, b, q, j, 0, q, S_off, scheme);
+            for (int j = q + 1; j < Ps[b] + Mt && q < Ps[b]; ++j)
+                dag_emit(plan, DAG_OFF, b, q, j, 0, q, S_off, scheme,
+                         (unsigned char)((j == q + 1 && fused(b)) ? DAG_NOSOLVE : 0));
     }
 }
 
@@ -633,8 +731,11 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
             // far-away rows thus run as soon as their panels exist instead of arriving in a burst when
             // their row comes up, and a worker rarely takes a ticket it then has to spin on.  Every wait
             // still targets a smaller ticket: a chain's PARTs have increasing pb, its final the largest.
+            // (the update-only task of tile (q, q+1), which DIAG(q) waits for after its factorisation, goes in
+            // front of it: every wait still targets a smaller ticket)
             auto cls = [](const DagTask& t) {
                 const int ty = t.type & DAG_TYPE_MASK;
+                if (ty == DAG_OFF && (t.type & DAG_NOSOLVE)) return -1;
                 return ty == DAG_DIAG ? 0 : (ty == DAG_OFF ? 1 : 2);
             };
             std::stable_sort(plan.tasks.begin() + plan.queues.first[g], plan.tasks.end(),

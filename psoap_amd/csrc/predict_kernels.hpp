@@ -319,7 +319,7 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
     }
     hipStream_t st = ws.stream;
     PR_TRY(ws.K.need((size_t)Npad * ld));
-    PR_TRY(ws.W.need((size_t)NB * NB));
+    PR_TRY(ws.W.need((size_t)2 * NB * NB));
     PR_TRY(ws.R.need(Npad));
     PR_TRY(ws.Acc.need(1));
     PR_TRY(ws.Lwl.need((size_t)c * N));
@@ -388,7 +388,7 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         PR_TRY(ws.Mat.need(1));
         PR_TRY(hipMemcpyAsync(ws.Colx, h_colx, sizeof(double) * (size_t)c * Rq_pad, hipMemcpyHostToDevice, st));
         PR_TRY(hipMemsetAsync(ws.Dag, 0, dag_bytes, st));
-        PR_TRY(hipMemsetAsync(dW, 0, sizeof(double) * NB * NB, st));      // the strictly upper part of W stays zero
+        PR_TRY(hipMemsetAsync(dW, 0, sizeof(double) * 2 * NB * NB, st));  // the strictly upper part of W stays zero
         hipLaunchKernelGGL(k_init_rhs, dim3((Npad + 255) / 256, 1), dim3(256), 0, st, dR, Npad, N, dFl, offset, dAcc);
         const int grid = (int)(plan.tasks.size() < (size_t)ws.workers ? plan.tasks.size() : (size_t)ws.workers);
         const DagAug aug{P + Mt, Rq, Rq_pad, ws.Colx};

@@ -87,7 +87,7 @@ struct psoap_chunk {
     int n_epochs = 0;
     // workspaces
     double* dK = nullptr;    // max_batch x Npad x ld
-    double* dWt = nullptr;   // max_batch x 128 x 128
+    double* dWt = nullptr;   // max_batch x 2 x 128 x 128 (the persistent kernel alternates two per matrix)
     double* dR = nullptr;    // max_batch x Npad
     MatAcc* dAcc = nullptr;  // max_batch
     double* dVel = nullptr;  // max_batch x 3 x n_epochs
@@ -205,8 +205,8 @@ static int chunk_alloc(psoap_chunk* h, const double* fl, const double* sigma)
     HIP_TRY(hipMalloc(&h->dFl, sizeof(double) * N));
     HIP_TRY(hipMalloc(&h->dSigma, sizeof(double) * N));
     HIP_TRY(hipMalloc(&h->dK, sizeof(double) * nb * h->mat_stride));
-    HIP_TRY(hipMalloc(&h->dWt, sizeof(double) * nb * NB * NB));
-    HIP_TRY(hipMemset(h->dWt, 0, sizeof(double) * nb * NB * NB));   // the strictly upper part of every W stays zero
+    HIP_TRY(hipMalloc(&h->dWt, sizeof(double) * nb * 2 * NB * NB));
+    HIP_TRY(hipMemset(h->dWt, 0, sizeof(double) * nb * 2 * NB * NB));   // the strictly upper part of every W stays zero
     HIP_TRY(hipMalloc(&h->dR, sizeof(double) * nb * h->Npad));
     HIP_TRY(hipMalloc(&h->dAcc, sizeof(MatAcc) * nb));
     HIP_TRY(hipMalloc(&h->dOut, sizeof(double) * nb));
@@ -342,14 +342,14 @@ extern "C" int psoap_chunk_dag_tasklog(psoap_chunk* h, unsigned long long* out, 
     if (set_dev(h)) return 1;
     const long long tasks = 9ll * h->max_batch * h->P * (h->P + 1) / 2 + 1024;   // <= 8 parts per tile + early DIAG parts
     if (!h->dTlog) {
-        HIP_TRY(hipMalloc(&h->dTlog, sizeof(unsigned long long) * 4 * tasks));
-        HIP_TRY(hipMemset(h->dTlog, 0, sizeof(unsigned long long) * 4 * tasks));
+        HIP_TRY(hipMalloc(&h->dTlog, sizeof(unsigned long long) * 8 * tasks));
+        HIP_TRY(hipMemset(h->dTlog, 0, sizeof(unsigned long long) * 8 * tasks));
         h->tlog_tasks = tasks;
         return 0;
     }
     if (out) {
         const long long n = max_tasks < tasks ? max_tasks : tasks;
-        HIP_TRY(hipMemcpy(out, h->dTlog, sizeof(unsigned long long) * 4 * n, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out, h->dTlog, sizeof(unsigned long long) * 8 * n, hipMemcpyDeviceToHost));
     }
     return 0;
 }
@@ -606,7 +606,7 @@ static void fill_mats(const psoap_chunk* h, const BatchSlot& sl, DagMat* out)
         DagMat m{};
         m.K = h->dK + (size_t)b * h->mat_stride;
         m.R = h->dR + (size_t)b * h->Npad;
-        m.Wt = h->dWt + (size_t)b * NB * NB;
+        m.Wt = h->dWt + (size_t)b * 2 * NB * NB;
         m.lw = sl.dLwl + (size_t)b * sl.C * h->N;
         m.gp = sl.dGp + (size_t)b * 2 * sl.C;
         m.sigma = h->dSigma;

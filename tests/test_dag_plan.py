@@ -8,7 +8,7 @@ import pytest
 TASK = np.dtype([("type", "u1"), ("q", "u1"), ("j", "u1"), ("S", "u1"), ("b", "<u2"), ("pa", "u1"), ("pb", "u1"),
                  ("slot", "<u4"), ("ctr", "<u4")])
 PART, DIAG, OFF = 0, 1, 2
-TYPE_MASK, CHAIN = 0x0F, 0x10
+TYPE_MASK, CHAIN, NOSOLVE, WAITNEXT, FUSED = 0x0F, 0x10, 0x20, 0x40, 0x80
 
 
 def plan(B, P, workers):
@@ -29,6 +29,7 @@ def plan(B, P, workers):
     assert call(tasks.ctypes.data_as(ctypes.c_void_p), n.value) == 0
     plan.queue_first = list(first)
     plan.chain = (tasks["type"] & CHAIN) != 0
+    plan.flags = tasks["type"].copy()
     tasks["type"] &= TYPE_MASK
     return tasks, slots.value, ctrs.value
 
@@ -101,11 +102,30 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
             pos = pb
         assert pos == q
     # dependency order: every wait targets a smaller ticket
+    flags = plan.flags
     for t, k in enumerate(tasks):
         b, q, j = int(k["b"]), int(k["q"]), int(k["j"])
         # the update over block rows [pa, pb) needs rows < pb complete: all finals of those rows are earlier
-        for m in range(int(k["pb"])):
+        # -- except a diagonal final of the latency scheme (WAITNEXT), which reads of the last row only the
+        # tile right of its diagonal, solved by that row's DIAG task itself (FUSED)
+        wait_next = bool(flags[t] & WAITNEXT)
+        if wait_next:
+            assert want_chain and k["type"] == DIAG and int(k["pb"]) == q and int(k["pb"]) - int(k["pa"]) == 1
+            prev = diag_final_ticket[(b, q - 1)]
+            assert prev < t and flags[prev] & FUSED
+        for m in range(int(k["pb"]) - (1 if wait_next else 0)):
             assert row_final_last_ticket[(b, m)] < t
+        if flags[t] & FUSED:
+            # DIAG(q) also solves tile (q, q+1): its update-only task comes earlier in the list
+            assert k["type"] == DIAG and q + 1 < Ps[b]
+            upd = finals[(b, q, q + 1)]
+            assert upd < t and flags[upd] & NOSOLVE
+        if flags[t] & NOSOLVE:
+            assert k["type"] == OFF and j == q + 1 and flags[diag_final_ticket[(b, q)]] & FUSED
+        if want_chain and k["type"] == DIAG:
+            assert bool(flags[t] & FUSED) == (q + 1 < Ps[b]) and wait_next == (q >= 1)
+        if not want_chain:
+            assert not flags[t] & (NOSOLVE | WAITNEXT | FUSED)
         if k["type"] != PART:
             if k["S"] > 1:
                 parts = part_done_ticket[int(k["ctr"])]
@@ -128,7 +148,7 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
                     assert all(int(tasks[p]["S"]) == 0 for p in parts)
                     assert got == list(range(got[0], got[0] + len(parts)))                 # consecutive slots
                     assert int(k["slot"]) == got[0]
-            if k["type"] == OFF:
+            if k["type"] == OFF and not flags[t] & NOSOLVE:
                 assert diag_final_ticket[(b, q)] < t
 
 

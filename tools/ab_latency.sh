@@ -1,9 +1,12 @@
 #!/bin/bash
-# A/B two builds of the HIP library: dag-mode latency table (B = 1, 4, 32) for every config shape.
-for v in old new; do
-  echo "== $v"
-  PSOAP_GP_LIB=$PWD/ab_libs/$v.so python tools/latency_table.py 2>/dev/null | grep '"dag"' | python -c "
+# A/B builds of the HIP library on the same box (ab_libs/<name>.so), interleaved:
+#   tools/ab_latency.sh "base new" "3" "1,4,32"
+for rep in 1 2; do
+  for v in $1; do
+    echo "== $v (rep $rep)"
+    PSOAP_GP_LIB=$PWD/ab_libs/$v.so python tools/latency_quick.py "$2" "$3" nopredict 2>/dev/null | python -c "
 import sys, json
-for l in sys.stdin:
-    d = json.loads(l); print(f\"N={d['N']:5d} c={d['c']} B={d['B']:2d}: {d['ms_per_batch']:8.2f} ms  {d['evals_per_s']:8.1f} evals/s  {d['tflops']:5.1f} TF\")"
+for ln in sys.stdin:
+    d = json.loads(ln); print('  N=%d B=%d  %.3f ms  frac %.3f' % (d['N'], d['B'], d['ms'], d['frac']))"
+  done
 done

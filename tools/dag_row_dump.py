@@ -18,11 +18,17 @@ with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
     h._L.psoap_chunk_dag_tasks(h._h, None, 0, ctypes.byref(n)); nt = n.value
     tasks = np.zeros(nt, dtype=task_dt)
     h._L.psoap_chunk_dag_tasks(h._h, tasks.ctypes.data_as(ctypes.c_void_p), nt, ctypes.byref(n))
-    log = np.zeros(nt * 4, dtype=np.uint64)
+    log = np.zeros(nt * 8, dtype=np.uint64)
     h._L.psoap_chunk_dag_tasklog(h._h, log.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), nt)
 tasks["type"] &= 0x0F   # strip the chain flag
-log = log.reshape(nt, 4).astype(np.float64) / 100.0
+raw = log.reshape(nt, 8).astype(np.float64)
+log = raw / 100.0
+log[:, 7] = 0.0
 log -= log[:, 0].min()
+dd = np.where((tasks["type"] & 0x0F) == 1)[0]
+dd = dd[np.argsort(raw[dd, 0])]
+clk = np.diff(raw[dd, 7]) / np.diff(raw[dd, 0]) * 100.0     # MHz, between consecutive DIAG task starts (any CU: rough)
+print("shader clock between consecutive DIAG starts [MHz]: median %.0f  min %.0f  max %.0f" % (np.median(clk), clk.min(), clk.max()))
 names = {0: "PART", 1: "DIAG", 2: "OFF "}
 print(f"span {log[:,3].max()/1e3:.2f} ms, tasks {nt}")
 for q in range(q0, q1 + 1):
@@ -32,8 +38,8 @@ for q in range(q0, q1 + 1):
     for i in idx[-6:]:
         t = tasks[i]
         st = log[i]
-        print(f"  ticket {i:6d} {names[int(t['type'])]} j={t['j']:2d} S={t['S']} panels [{t['pa']:2d},{t['pb']:2d})  start {st[0]:8.0f}  +upd {st[1]-st[0]:7.0f}  +wait/potrf {st[2]-st[1]:6.0f}  +trsm {st[3]-st[2]:6.0f}  end {st[3]:8.0f}")
+        print(f"  ticket {i:6d} {names[int(t['type'])]} j={t['j']:2d} S={t['S']} panels [{t['pa']:2d},{t['pb']:2d})  start {st[0]:8.0f}  dep {st[4]:8.0f} gemm {st[5]:8.0f} chain {st[6]:8.0f} upd {st[1]:8.0f}  +wait/potrf {st[2]-st[1]:6.0f}  +trsm {st[3]-st[2]:6.0f}  end {st[3]:8.0f}")
     d = idx[tasks["type"][idx] == 1]
     for i in d:
         st = log[i]; t = tasks[i]
-        print(f"  DIAG ticket {i} panels [{t['pa']},{t['pb']}) start {st[0]:.0f} upd-end {st[1]:.0f} potrf-end {st[2]:.0f} end {st[3]:.0f}")
+        print(f"  DIAG ticket {i} panels [{t['pa']},{t['pb']}) start {st[0]:.0f} dep-ready {st[4]:.0f} gemm-end {st[5]:.0f} chain-ready {st[6]:.0f} upd-end {st[1]:.0f} potrf-end {st[2]:.0f} end {st[3]:.0f}")

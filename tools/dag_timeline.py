@@ -22,10 +22,10 @@ with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
     ntask = n.value
     tasks = np.zeros(ntask, dtype=task_dt)
     h._L.psoap_chunk_dag_tasks(h._h, tasks.ctypes.data_as(ctypes.c_void_p), ntask, ctypes.byref(n))
-    log = np.zeros(ntask * 4, dtype=np.uint64)
+    log = np.zeros(ntask * 8, dtype=np.uint64)
     h._L.psoap_chunk_dag_tasklog(h._h, log.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), ntask)
 tasks["type"] &= 0x0F   # strip the chain flag
-log = log.reshape(ntask, 4).astype(np.float64) / 100.0   # us
+log = log.reshape(ntask, 8).astype(np.float64) / 100.0   # us
 base = log[:, 0].min()
 log -= base
 span = log[:, 3].max()
