@@ -220,7 +220,12 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* __restr
                                                   const double* __restrict__ sigma, int N, double scale,
                                                   int Npad, const DagAug& aug)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the thread id passes through an opaque statement: everything below (coordinate loads, addresses)
+    // depends on it and so cannot be hoisted above the K-loops of the update, where it would sit in
+    // registers the MFMA loop then has to spill around
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int lane = tid_ & 63, wave = tid_ >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     double xj[4][C];
     int jj[4];
@@ -339,7 +344,51 @@ __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, in
     }
 }
 
-template <int C, bool AUG = false>
+// Diagonal tile of the latency scheme, the row-to-row critical path: the running sum of its PART chain,
+// the last K = 128 symmetric update and the in-block Cholesky all happen in the registers of potrf_blocked
+// (FUSED) -- no tile engine, no store / drain / reload of the tile in between -- and, when the task is
+// DAG_FUSED, the strip solve of the tile right of the diagonal follows in the same workgroup.
+// A function of its own (not inlined): inside the kernel body a second instance of the factorisation makes
+// hipcc spill in the MFMA loops of every other task (32-walker batch: 39.5 -> 44.2 ms).
+__device__ __attribute__((noinline)) void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double* Rv, MatAcc* acc,
+                                                        const double* prev, int Npad, MatFlags* f, DagCtl* ctl, int q,
+                                                        int ntasks_row, bool fused, double* zk, double* colsum,
+                                                        unsigned long long* tl)
+{
+    __builtin_amdgcn_s_setprio(3);
+    auto wait_dep = [f, ctl, q, tl]() {
+        dag_wait_ge(&f->next_done, q, ctl, 2u);
+        if (tl && threadIdx.x == 0) tl[4] = __builtin_amdgcn_s_memrealtime();
+    };
+    potrf_blocked<0, true>(Km, ld, k0, Wm, Rv, acc, prev, Km + (size_t)(k0 - NB) * ld + k0, wait_dep);
+    dag_drain();
+    if (tl && threadIdx.x == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        dag_release_fence();
+        __hip_atomic_store(&f->potrf_done, q + 1, PSOAP_RLX_AGENT);
+    }
+    if (fused) {
+        Tile t;
+        dag_wait_ge(&f->off1_ready, q + 1, ctl, 5u);
+        dag_trsm(t, Km, ld, k0, k0 + NB, Wm, Rv, Npad, zk, colsum);
+        dag_drain();
+        if (threadIdx.x == 0) {
+            dag_release_fence();
+            __hip_atomic_store(&f->next_done, q + 1, PSOAP_RLX_AGENT);
+            dag_task_done(f, q, ntasks_row, 2);
+        }
+    } else if (threadIdx.x == 0) {
+        dag_task_done(f, q, ntasks_row);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (tl && threadIdx.x == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
+}
+
+// LAT: the instantiation launched for task lists of the latency scheme; only it contains the fused diagonal
+// fast path (dag_diag_fast).  With that path compiled into the one kernel, hipcc keeps a spilled value in the
+// MFMA loops of every task (a scratch load per 64-MFMA stage: 32-walker batch 39.5 -> 43.7 ms); the
+// throughput scheme never runs it, so it gets a kernel without it.
+template <int C, bool AUG = false, bool LAT = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __restrict__ mats,
                                                              const DagTask* __restrict__ tasks, DagQueues queues,
                                                              MatFlags* flags, int* arrive, double* wspace,
@@ -417,6 +466,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         // chained PART: the predecessor's tile sits in the other slot of the even/odd pair
         const double* prev = wspace + (size_t)(is_part ? task.slot ^ 1u : task.slot) * SLOT;
         const bool preload = !is_part && chain && n_wait > 0;
+        if (LAT && preload && ttype == DAG_DIAG && (task.type & DAG_WAITNEXT) && task.pb - task.pa == 1) {
+            dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);         // the chain ran ahead: normally no wait
+            dag_diag_fast(Km, ld, k0, Wm, Rv, mat.acc, prev, Npad, f, ctl, q, ntasks_row, (task.type & DAG_FUSED) != 0,
+                          vec1, vec2, tlog ? tlog + ticket * 8 : nullptr);
+            continue;
+        }
         t.zero();
         if (preload) {
             // the chain ran ahead (its PARTs need older block rows): normally no wait at all
@@ -516,6 +571,7 @@ struct DagPlan {
     DagQueues queues{};
     unsigned int n_slots = 0;
     unsigned int n_ctrs = 0;
+    int scheme = 0;            // 0 throughput, 1 latency: selects the kernel instantiation (k_chol_dag<.., LAT>)
 };
 
 inline int dag_split_factor(int tasks_in_row, int q, int workers)
@@ -715,6 +771,7 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
     DagPlan plan;
     const int B = (int)Ps.size();
     if (scheme < 0) scheme = dag_auto_scheme(Ps);
+    plan.scheme = scheme;
     // workgroups of XCDs whose own queue is empty steal, so the workers are shared by the queues in use
     const int used = B < DAG_QUEUES ? (B > 0 ? B : 1) : DAG_QUEUES;
     const int per_queue = workers / used > 0 ? workers / used : 1;

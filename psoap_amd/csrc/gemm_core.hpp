@@ -73,7 +73,13 @@ __device__ __forceinline__ void stage_store(const Staging& s, int buf, int tid)
 template <bool PARTIAL_M = false>
 __device__ __forceinline__ void tile_mma_chunk(Tile& t, int buf, int wr, int wc, int lane, int m_first = 0)
 {
-    const int fr = lane & 15, fk = lane >> 4;
+    // the fragment offsets are recomputed per stage from the lane id (opaque to the optimiser) instead of
+    // being hoisted out of the K-loop: as loop invariants they are the values hipcc spills first when the
+    // kernel around the loop grows (a scratch reload in front of the fragment reads also waits for the
+    // LDS-DMA of the next stage -- vmcnt counts both -- and serialises it with the MFMAs)
+    int l = lane;
+    asm volatile("" : "+v"(l));
+    const int fr = l & 15, fk = l >> 4;
     const int baseA = buf * LDS_BUFFER + fk * LDS_LD + wr * 64 + fr;
     const int baseB = buf * LDS_BUFFER + LDS_OPERAND + fk * LDS_LD + wc * 64 + fr;
 #pragma unroll
@@ -143,12 +149,27 @@ __device__ __forceinline__ void stage_glds(const double* __restrict__ A, size_t 
     }
 }
 
+// one operand only (the symmetric update of a diagonal tile multiplies a strip with itself): the A half
+// of LDS buffer `buf`
+__device__ __forceinline__ void stage_glds_one(const double* __restrict__ A, size_t lda, int k, int buf, int tid)
+{
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = wave + 4 * it;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(A + (size_t)(k + row) * lda + 2 * lane),
+                                         (lds_ptr)(psoap_smem + buf * LDS_BUFFER + row * LDS_LD), 16, 0, 0);
+    }
+}
+
 __device__ __forceinline__ void tile_gemm_tn(Tile& t, const double* __restrict__ A, size_t lda,
                                                   const double* __restrict__ B, size_t ldb, int K,
                                                   bool skip_lower_left = false, int k_limit_upper = 0x7fffffff)
 {
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar offsets
     const int wr = wave >> 1, wc = wave & 1;
     if (K <= 0) return;
     stage_glds(A, lda, B, ldb, 0, 0, tid);

@@ -184,8 +184,24 @@ __device__ __forceinline__ void trail_row(d4 (&blk)[16], d4 (&rhs)[2], int bb, i
 // (its upper triangle is read); Wm's strictly upper part must be zero (it is never written).
 // ABLATE: timing diagnostics for the microbenchmark only (1 no in-wave factorisation, 2 no MFMA
 // phases, 3 no W output, 9 phase stamps); 0 is the shipped routine.
-template <int ABLATE = 0>
-__device__ __forceinline__ void potrf_blocked(double* Km, int ld, int k0, double* Wm, double* Rv, MatAcc* acc)
+struct PotrfNoWait {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// FUSED (the diagonal task of the latency scheme): the tile does not come from the matrix but is formed here,
+// in the registers the factorisation works on --
+//     T = part - strip^T strip,
+// `part` = the running sum the tile's PART chain left in a workspace slot (row-major 128 x 128: K minus the
+// contributions of all block rows but the last), `strip` = the 128 x 128 tile right above the diagonal
+// (k-major, leading dimension ld), i.e. the final K = 128 symmetric update.  `part` is read BEFORE
+// wait_dep() -- the wait for the strip -- and the update runs on the 16 x 16 blocks each wave owns (12 of
+// its 16 slots can hold an upper block; dead ones get a zero multiplier), so compared with
+// "tile engine -> store -> drain -> reload" the row-to-row path loses a round trip through memory, the
+// B-operand staging and a quarter of the MFMAs.
+template <int ABLATE = 0, bool FUSED = false, class WaitFn = PotrfNoWait>
+__device__ __forceinline__ void potrf_blocked(double* Km, int ld, int k0, double* Wm, double* Rv, MatAcc* acc,
+                                              const double* __restrict__ part = nullptr,
+                                              const double* __restrict__ strip = nullptr, WaitFn wait_dep = WaitFn())
 {
     using namespace pb;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -194,18 +210,63 @@ __device__ __forceinline__ void potrf_blocked(double* Km, int ld, int k0, double
     const int rhs_row = (3 * wave) & 3;   // this wave owns the rhs blocks of block rows rhs_row and rhs_row + 4
     d4 blk[16];                           // slot 2I + h holds block (I, J), J = ((wave - 3I) & 3) + 4h
     d4 rhs[2];                            // slot k holds block (rhs_row + 4k, 8): r_k in column 0
+    {
+        const double* src = FUSED ? part : Km + (size_t)k0 * ld + k0;
+        const size_t lds = FUSED ? (size_t)NB : (size_t)ld;
 #pragma unroll
-    for (int I = 0; I < 8; ++I)
+        for (int I = 0; I < 8; ++I)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int J = ((wave - 3 * I) & 3) + 4 * h;
-            d4 v = {0.0, 0.0, 0.0, 0.0};
-            if (J >= I) {
+            for (int h = 0; h < 2; ++h) {
+                const int J = ((wave - 3 * I) & 3) + 4 * h;
+                d4 v = {0.0, 0.0, 0.0, 0.0};
+                if (J >= I) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = Km[(size_t)(k0 + 16 * I + q + 4 * r) * ld + k0 + 16 * J + c];
+                    for (int r = 0; r < 4; ++r) v[r] = src[(size_t)(16 * I + q + 4 * r) * lds + 16 * J + c];
+                }
+                blk[2 * I + h] = v;
             }
-            blk[2 * I + h] = v;
+    }
+    if (FUSED) {
+        wait_dep();                                   // the strip (and the rhs block) are final from here on
+        // K = 128 in eight LDS stages of 16 k-rows, double-buffered, one operand
+        stage_glds_one(strip, (size_t)ld, 0, 0, tid);
+        __syncthreads();
+        const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll 1
+        for (int ch = 0; ch < NB / KB; ++ch) {
+            const int cur = ch & 1;
+            if (ch + 1 < NB / KB) stage_glds_one(strip, (size_t)ld, (ch + 1) * KB, cur ^ 1, tid);
+            const int base = cur * LDS_BUFFER + fk * LDS_LD + fr;
+#pragma unroll
+            for (int I = 0; I < 8; ++I) {
+                // slot h = 1 of rows 0..3 is always an upper block (J >= 4 > I); slot h = 0 of rows 4..7 never
+                // is (J <= 3 < I); the remaining slot of each row is upper or not depending on the wave
+                const int J0 = (wave - 3 * I) & 3;
+                const int Jc = (I < 4) ? J0 : J0 + 4;             // the conditional slot's column block
+                const double sc = (Jc >= I) ? -1.0 : 0.0;         // dead block: zero multiplier, adds exactly 0
+                double x[4], xc[4], yc[4], y1[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    x[ks] = psoap_smem[base + ks * 4 * LDS_LD + 16 * I];
+                    yc[ks] = psoap_smem[base + ks * 4 * LDS_LD + 16 * Jc];
+                    if (I < 4) y1[ks] = psoap_smem[base + ks * 4 * LDS_LD + 16 * (J0 + 4)];
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    xc[ks] = x[ks] * sc;
+                    x[ks] = -x[ks];
+                }
+                const int hc = (I < 4) ? 0 : 1;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    blk[2 * I + hc] = __builtin_amdgcn_mfma_f64_16x16x4f64(xc[ks], yc[ks], blk[2 * I + hc], 0, 0, 0);
+                    if (I < 4)
+                        blk[2 * I + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ks], y1[ks], blk[2 * I + 1], 0, 0, 0);
+                }
+            }
+            __syncthreads();
         }
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll

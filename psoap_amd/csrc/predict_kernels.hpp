@@ -165,15 +165,17 @@ inline hipError_t predict_configure_kernels()
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_syrk_sub_sym),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag<1, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag<2, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag<3, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+#define PSOAP_SET_LDS(...)                                                                            \
+    if (e == hipSuccess)                                                                              \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)GEMM_LDS_BYTES)
+    PSOAP_SET_LDS(k_chol_dag<1, true, false>);
+    PSOAP_SET_LDS(k_chol_dag<2, true, false>);
+    PSOAP_SET_LDS(k_chol_dag<3, true, false>);
+    PSOAP_SET_LDS(k_chol_dag<1, true, true>);
+    PSOAP_SET_LDS(k_chol_dag<2, true, true>);
+    PSOAP_SET_LDS(k_chol_dag<3, true, true>);
+#undef PSOAP_SET_LDS
     return e;
 }
 
@@ -401,13 +403,14 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         PR_TRY(hipMemcpyAsync(ws.Mat, &hm, sizeof(DagMat), hipMemcpyHostToDevice, st));
         PR_TRY(hipStreamSynchronize(st));   // hm is a stack object; the staging copies are tiny
         PR_TRY(hipEventRecord(ws.ev[1], st));
-#define PSOAP_LAUNCH_AUG(CC)                                                                                      \
-    hipLaunchKernelGGL((k_chol_dag<CC, true>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, ws.Mat.p,       \
+#define PSOAP_LAUNCH_AUG(CC, LAT)                                                                                 \
+    hipLaunchKernelGGL((k_chol_dag<CC, true, LAT>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, ws.Mat.p,  \
                        ws.Tasks.p, plan.queues, fl_, reinterpret_cast<int*>(ws.Dag.p + arrive_off), ws.Ws.p, ctl_,  \
                        (unsigned long long*)nullptr, aug)
-        if (c == 1) PSOAP_LAUNCH_AUG(1);
-        else if (c == 2) PSOAP_LAUNCH_AUG(2);
-        else PSOAP_LAUNCH_AUG(3);
+        const bool lat = plan.scheme == 1;
+        if (c == 1) { if (lat) PSOAP_LAUNCH_AUG(1, true); else PSOAP_LAUNCH_AUG(1, false); }
+        else if (c == 2) { if (lat) PSOAP_LAUNCH_AUG(2, true); else PSOAP_LAUNCH_AUG(2, false); }
+        else { if (lat) PSOAP_LAUNCH_AUG(3, true); else PSOAP_LAUNCH_AUG(3, false); }
 #undef PSOAP_LAUNCH_AUG
         PR_TRY(hipGetLastError());
     } else {

@@ -100,7 +100,7 @@ struct psoap_chunk {
     int mode = 1;            // 1 = persistent DAG kernel, 0 = staged panels
     int dag_grid = 0;
     // task list of the persistent kernel for the current batch size (dag_build_tasks)
-    int plan_B = 0;
+    int plan_B = 0, plan_scheme = 0;
     unsigned int plan_tasks = 0, plan_ctrs = 0, plan_slots = 0;
     DagQueues plan_queues{};
     DagTask* dTasks = nullptr;
@@ -165,12 +165,15 @@ static int configure_kernels(int device)
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm_strip),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag<2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_dag<3>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#define PSOAP_SET_LDS(...) \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+    PSOAP_SET_LDS(k_chol_dag<1, false, false>);
+    PSOAP_SET_LDS(k_chol_dag<2, false, false>);
+    PSOAP_SET_LDS(k_chol_dag<3, false, false>);
+    PSOAP_SET_LDS(k_chol_dag<1, false, true>);
+    PSOAP_SET_LDS(k_chol_dag<2, false, true>);
+    PSOAP_SET_LDS(k_chol_dag<3, false, true>);
+#undef PSOAP_SET_LDS
     HIP_TRY(predict_configure_kernels());
     if (done.size() <= (size_t)device) done.resize((size_t)device + 1, 0);
     done[device] = 1;
@@ -190,7 +193,7 @@ static int dag_workers(int device, int* out)
     int blocks_per_cu = 0;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_chol_dag<3, true>, GEMM_THREADS,
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_chol_dag<3, true, true>, GEMM_THREADS,
                                                          GEMM_LDS_BYTES));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     if (blocks_per_cu > 2) blocks_per_cu = 2;
@@ -668,6 +671,7 @@ static int dag_prepare(psoap_chunk* h)
     }
     HIP_TRY(hipMemcpy(h->dTasks, plan.tasks.data(), sizeof(DagTask) * plan.tasks.size(), hipMemcpyHostToDevice));
     h->plan_B = sl.B;
+    h->plan_scheme = plan.scheme;
     h->plan_tasks = (unsigned int)plan.tasks.size();
     h->plan_ctrs = plan.n_ctrs;
     h->plan_slots = plan.n_slots;
@@ -700,13 +704,14 @@ static int eval_dag(psoap_chunk* h)
     {
         MatFlags* fl_ = reinterpret_cast<MatFlags*>(h->dDag + sizeof(DagCtl));
         DagCtl* ctl_ = reinterpret_cast<DagCtl*>(h->dDag);
-#define PSOAP_LAUNCH_DAG(CC)                                                                                     \
-    hipLaunchKernelGGL(k_chol_dag<CC>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, sl.dMats, h->dTasks,    \
-                       h->plan_queues, fl_, reinterpret_cast<int*>(h->dDag + h->arrive_off), h->dWs, ctl_,         \
-                       h->dTlog, DagAug{P, 0, 0, nullptr})
-        if (C == 1) PSOAP_LAUNCH_DAG(1);
-        else if (C == 2) PSOAP_LAUNCH_DAG(2);
-        else PSOAP_LAUNCH_DAG(3);
+#define PSOAP_LAUNCH_DAG(CC, LAT)                                                                                \
+    hipLaunchKernelGGL((k_chol_dag<CC, false, LAT>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, sl.dMats, \
+                       h->dTasks, h->plan_queues, fl_, reinterpret_cast<int*>(h->dDag + h->arrive_off), h->dWs,   \
+                       ctl_, h->dTlog, DagAug{P, 0, 0, nullptr})
+        const bool lat = h->plan_scheme == 1;
+        if (C == 1) { if (lat) PSOAP_LAUNCH_DAG(1, true); else PSOAP_LAUNCH_DAG(1, false); }
+        else if (C == 2) { if (lat) PSOAP_LAUNCH_DAG(2, true); else PSOAP_LAUNCH_DAG(2, false); }
+        else { if (lat) PSOAP_LAUNCH_DAG(3, true); else PSOAP_LAUNCH_DAG(3, false); }
 #undef PSOAP_LAUNCH_DAG
     }
     HIP_TRY(hipGetLastError());
@@ -849,6 +854,7 @@ struct psoap_group {
     DagQueues queues{};
     long long n_tasks = 0;
     int total_B = 0;
+    int scheme = 0;
 };
 
 extern "C" int psoap_group_create(psoap_group** out, psoap_chunk* const* handles, int n)
@@ -943,6 +949,7 @@ extern "C" int psoap_group_eval(psoap_group* g)
         HIP_TRY(hipMemcpy(g->dMats, mats.data(), sizeof(DagMat) * mats.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(g->dTasks, plan.tasks.data(), sizeof(DagTask) * plan.tasks.size(), hipMemcpyHostToDevice));
         g->queues = plan.queues;
+        g->scheme = plan.scheme;
         g->n_tasks = (long long)plan.tasks.size();
         g->total_B = total;
         g->key = key;
@@ -962,13 +969,14 @@ extern "C" int psoap_group_eval(psoap_group* g)
         const int grid = (int)(g->n_tasks < workers ? g->n_tasks : workers);
         MatFlags* fl_ = reinterpret_cast<MatFlags*>(g->dDag + sizeof(DagCtl));
         DagCtl* ctl_ = reinterpret_cast<DagCtl*>(g->dDag);
-#define PSOAP_LAUNCH_GROUP(CC)                                                                                  \
-    hipLaunchKernelGGL(k_chol_dag<CC>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, g->dMats, g->dTasks,   \
-                       g->queues, fl_, reinterpret_cast<int*>(g->dDag + g->arrive_off), g->dWs, ctl_,             \
+#define PSOAP_LAUNCH_GROUP(CC, LAT)                                                                             \
+    hipLaunchKernelGGL((k_chol_dag<CC, false, LAT>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, g->dMats, \
+                       g->dTasks, g->queues, fl_, reinterpret_cast<int*>(g->dDag + g->arrive_off), g->dWs, ctl_,  \
                        (unsigned long long*)nullptr, DagAug{0, 0, 0, nullptr})
-        if (C == 1) PSOAP_LAUNCH_GROUP(1);
-        else if (C == 2) PSOAP_LAUNCH_GROUP(2);
-        else PSOAP_LAUNCH_GROUP(3);
+        const bool lat = g->scheme == 1;
+        if (C == 1) { if (lat) PSOAP_LAUNCH_GROUP(1, true); else PSOAP_LAUNCH_GROUP(1, false); }
+        else if (C == 2) { if (lat) PSOAP_LAUNCH_GROUP(2, true); else PSOAP_LAUNCH_GROUP(2, false); }
+        else { if (lat) PSOAP_LAUNCH_GROUP(3, true); else PSOAP_LAUNCH_GROUP(3, false); }
 #undef PSOAP_LAUNCH_GROUP
     }
     HIP_TRY(hipGetLastError());
