@@ -360,7 +360,7 @@ __device__ __attribute__((noinline)) void dag_diag_fast(double* Km, int ld, int 
         dag_wait_ge(&f->next_done, q, ctl, 2u);
         if (tl && threadIdx.x == 0) tl[4] = __builtin_amdgcn_s_memrealtime();
     };
-    potrf_blocked<0, true>(Km, ld, k0, Wm, Rv, acc, prev, Km + (size_t)(k0 - NB) * ld + k0, wait_dep);
+    potrf_blocked<0, true>(Km, ld, k0, Wm, Rv, acc, prev, Km + (size_t)(k0 - NB) * ld + k0, wait_dep, tl);
     dag_drain();
     if (tl && threadIdx.x == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0) {

@@ -201,7 +201,8 @@ struct PotrfNoWait {
 template <int ABLATE = 0, bool FUSED = false, class WaitFn = PotrfNoWait>
 __device__ __forceinline__ void potrf_blocked(double* Km, int ld, int k0, double* Wm, double* Rv, MatAcc* acc,
                                               const double* __restrict__ part = nullptr,
-                                              const double* __restrict__ strip = nullptr, WaitFn wait_dep = WaitFn())
+                                              const double* __restrict__ strip = nullptr, WaitFn wait_dep = WaitFn(),
+                                              unsigned long long* tl = nullptr)
 {
     using namespace pb;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -267,6 +268,7 @@ __device__ __forceinline__ void potrf_blocked(double* Km, int ld, int k0, double
             __syncthreads();
         }
     }
+    if (FUSED && tl && tid == 0) tl[5] = __builtin_amdgcn_s_memrealtime();     // debug stamps (DAG task log)
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -355,6 +357,7 @@ __device__ __forceinline__ void potrf_blocked(double* Km, int ld, int k0, double
     }
 #undef PSOAP_STAMP
 
+    if (FUSED && tl && tid == 0) tl[6] = __builtin_amdgcn_s_memrealtime();
     // the strictly lower blocks of W = U11^-T stay in their registers once their block row is finished:
     // written out here, off the eight-step critical loop (transposes + global stores per step; -6 % on a
     // single N = 6000 evaluation, -1 % on the 32-walker batch)
@@ -412,6 +415,7 @@ __device__ __forceinline__ void potrf_blocked(double* Km, int ld, int k0, double
         if (anybad) __hip_atomic_store(&acc->info, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();   // the LDS scratch is handed back to the tile engine
+    if (FUSED && tl && tid == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
 }
 
 }  // namespace psoap

@@ -42,4 +42,4 @@ for q in range(q0, q1 + 1):
     d = idx[tasks["type"][idx] == 1]
     for i in d:
         st = log[i]; t = tasks[i]
-        print(f"  DIAG ticket {i} panels [{t['pa']},{t['pb']}) start {st[0]:.0f} dep-ready {st[4]:.0f} gemm-end {st[5]:.0f} chain-ready {st[6]:.0f} upd-end {st[1]:.0f} potrf-end {st[2]:.0f} end {st[3]:.0f}")
+        print(f"  DIAG ticket {i} panels [{t['pa']},{t['pb']}) start {st[0]:.0f} dep-ready {st[4]:.0f} gemm-end {st[5]:.0f} chain-ready/steps-end {st[6]:.0f} upd-end/potrf-out {st[1]:.0f} potrf-end(drained) {st[2]:.0f} end {st[3]:.0f}")
