@@ -744,12 +744,13 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
 
 // scheme: 0 throughput, 1 latency (dag_emit), -1 automatic: latency while the row-to-row dependency chain,
 // not the MFMA work, bounds the run time -- i.e. while a queue has too few block rows in flight to hide the
-// wait for the row above.  Measured on MI355X (tools/scheme_table.py, tools/multichunk_bench.py;
-// N = 2000 .. 8192, B = 1 .. 256): latency wins when the block rows of the matrices of the fullest queue
-// add up to at most ~100 (N = 6000: up to B = 16; B = 1: 14.9 -> 7.3 ms, B = 8: 19.5 -> 14.8 ms), or when
-// no queue holds more than one matrix; throughput otherwise (N = 6000, B = 32: 39.5 vs 40.3 ms).
+// wait for the row above.  Measured on MI355X (tools/scheme_table.py; N = 2000 .. 8192, B = 1 .. 32, round 2,
+// with the critical path fused into the diagonal tasks): the latency scheme wins or ties while the block
+// rows of the matrices of the fullest queue add up to at most ~150 (N = 6000: B = 1: 12.7 -> 4.8 ms,
+// B = 8: 17.6 -> 12.9 ms, B = 24: 31.1 -> 30.8 ms; N = 2000, B = 32: 3.9 -> 3.1 ms), or when no queue holds
+// more than one matrix; throughput beyond (N = 6000, B = 32: 39.2 vs 39.9 ms; N = 8192, B = 32: 95.0 vs 96.1).
 // (Readiness ordering was also tried for the throughput scheme: 800 -> 776 evals/s, not adopted.)
-constexpr int DAG_LATENCY_QUEUE_ROWS = 100;
+constexpr int DAG_LATENCY_QUEUE_ROWS = 150;
 inline int dag_auto_scheme(const std::vector<int>& Ps)
 {
     long long rows[DAG_QUEUES] = {};

@@ -6,10 +6,9 @@
 // and fuses `V11[diag] += sigma**2` (psoap/covariance.py:322,344,367).
 //
 // Layout: one 256-thread workgroup per 128 x 128 tile.  The tile's row
-// ln-wavelengths (C vectors x 128) are staged in LDS and read back as wave-uniform
-// broadcasts; each lane keeps the ln-wavelengths of its two adjacent columns in
-// registers, so a wave writes one full 1 KiB row segment per store instruction
-// (16 B per lane, coalesced).  Arithmetic mirrors the reference exactly
+// ln-wavelengths (C vectors x 128) are staged in LDS; each lane keeps the
+// ln-wavelengths of its two adjacent columns in registers and stores 16 B per row
+// (a wave writes four 256-byte row segments per instruction).  Arithmetic mirrors the reference exactly
 // (no FMA contraction in p*r*r and in the component sum), so the only
 // difference from libm is the device exp().
 #pragma once
@@ -171,8 +170,14 @@ __global__ __launch_bounds__(256) void k_fill_sym(double* __restrict__ Kbase, si
         double s = (sigma != nullptr && i < N) ? sigma[i] : 0.0;
         srow[tid] = s * s;
     }
-    const int col2 = tid & 63, w = tid >> 6;
-    const int ja = j0 + 2 * col2, jb = ja + 1;
+    // Wave w owns the 32-column block w of the tile; per step it covers a 16 x 32 patch: lane = (row group
+    // 0..3) x (column pair 0..15), four rows (rg + 4 s) and two columns per lane.  A compact patch is what
+    // makes the underflow shortcut bite: the covariance is banded (|dx| beyond ~72 pixels gives exp() = +0
+    // exactly), and a 16 x 32 patch misses the bands far more often than a 4 x 128 strip does (round 1's
+    // shape: 4.3 TB/s at c = 2, bound by exp() throughput, not by the stores).  A store instruction writes
+    // four 256-byte row segments.
+    const int w = tid >> 6, rg = (tid >> 4) & 3, cp = tid & 15;
+    const int ja = j0 + 32 * w + 2 * cp, jb = ja + 1;
     double xa[C], xb[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) {
@@ -182,9 +187,8 @@ __global__ __launch_bounds__(256) void k_fill_sym(double* __restrict__ Kbase, si
     __syncthreads();
 
     double* Km = Kbase + (size_t)b * mat_stride;
-    // Four rows x two columns per step: the eight exponentials of a component go through one batched,
-    // underflow-skipping evaluation.  (With two exp() per element the kernel is close to the fp64 VALU
-    // rate, not only the HBM write rate: 1.1e12 exp/s at N = 6000, c = 2.)
+    // Four rows x two columns per lane and step: the eight exponentials of a component go through one
+    // batched, underflow-skipping evaluation.
 #pragma unroll 1
     for (int g4 = 0; g4 < NB / 16; ++g4) {
         double va[4], vb[4];
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void k_fill_sym(double* __restrict__ Kbase, si
             bool live = false;
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                const double xi = xrow[c][w + 4 * (4 * g4 + s4)];
+                const double xi = xrow[c][16 * g4 + rg + 4 * s4];
                 const double da = xa[c] - xi, db = xb[c] - xi;
                 a[2 * s4] = g.p2[c] * da * da;
                 a[2 * s4 + 1] = g.p2[c] * db * db;
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(256) void k_fill_sym(double* __restrict__ Kbase, si
         }
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            const int r = w + 4 * (4 * g4 + s4);
+            const int r = 16 * g4 + rg + 4 * s4;
             const int i = i0 + r;
             d2 v;
             if (i < N) {
@@ -232,6 +236,7 @@ __global__ __launch_bounds__(256) void k_fill_sym(double* __restrict__ Kbase, si
                 v.x = (ja == i) ? 1.0 : 0.0;
                 v.y = (jb == i) ? 1.0 : 0.0;
             }
+            // (non-temporal stores measured slower here: 5.4 vs 5.75 TB/s at c = 1, no difference at c = 2, 3)
             *reinterpret_cast<d2*>(Km + (size_t)i * ld + ja) = v;
         }
     }

@@ -119,21 +119,39 @@ class EnsembleEvaluator:
         return ev
 
     def lnprob(self, proposals) -> np.ndarray:
+        if getattr(self, "handles", None):
+            self.upload(proposals)
+            self.launch()
+            return self.collect()
+        local = [np.asarray(self.evaluate(k, proposals), dtype=np.float64) for k in self.mine]
+        return self._gather_and_sum(local)
+
+    # split-phase form (device-resident chunks only): the proposals of the NEXT ensemble step may be uploaded
+    # between launch() and collect() -- every chunk handle keeps two proposal batches, so the copy runs
+    # while the current step is being factored
+    def upload(self, proposals):
+        for k in self.mine:
+            lwls, gps = proposals[k]
+            self.handles[k].upload(lwls, gps)
+
+    def launch(self):
         group = getattr(self, "group", None)
         if group is not None:
-            for k in self.mine:
-                lwls, gps = proposals[k]
-                self.handles[k].upload(lwls, gps)
             group.eval()
-            local = [np.asarray(self.handles[k].fetch(), dtype=np.float64) for k in self.mine]
         else:
-            local = [np.asarray(self.evaluate(k, proposals), dtype=np.float64) for k in self.mine]
+            for k in self.mine:
+                self.handles[k].eval()
+
+    def collect(self) -> np.ndarray:
+        return self._gather_and_sum([np.asarray(self.handles[k].fetch(), dtype=np.float64) for k in self.mine])
+
+    def _gather_and_sum(self, local) -> np.ndarray:
         B = local[0].shape[0] if local else 0
         if self.world > 1 and not local:
             raise ValueError("every rank must own at least one chunk (n_chunks >= world)")
         block = np.stack(local) if local else np.zeros((0, B))
-        table = gather_chunk_lnprobs(block, self.n_chunks, self.world, self.rank, self.device_index)
-        return sum_over_chunks(table)
+        self.table = gather_chunk_lnprobs(block, self.n_chunks, self.world, self.rank, self.device_index)
+        return sum_over_chunks(self.table)
 
     def close(self):
         if getattr(self, "group", None) is not None:

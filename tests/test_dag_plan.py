@@ -45,11 +45,11 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
     Ps = [P] * B if np.ndim(P) == 0 else list(P)
     n_tiles = sum(p * (p + 1) // 2 for p in Ps)
     assert TASK.itemsize == 16
-    # latency scheme (chained partial sums) while the fullest queue holds at most ~100 block rows or a
+    # latency scheme (chained partial sums) while the fullest queue holds at most ~150 block rows or a
     # single matrix; gathered otherwise
     q_rows = [sum(Ps[g::8]) for g in range(8)]
     q_count = [len(Ps[g::8]) for g in range(8)]
-    want_chain = max(q_rows) <= 100 or max(q_count) <= 1
+    want_chain = max(q_rows) <= 150 or max(q_count) <= 1
     assert np.all(chain[tasks["S"] > 1] == want_chain) if (tasks["S"] > 1).any() else True
     # one queue per XCD: matrix b lives in queue b mod 8, queues are contiguous ranges of the list
     first = plan.queue_first
