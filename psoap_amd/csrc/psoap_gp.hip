@@ -63,6 +63,7 @@ struct BatchSlot {
     double* dLwl = nullptr;    // max_batch x 3 x N
     double* dGp = nullptr;     // max_batch x 6
     int* dTooFast = nullptr;   // max_batch: |v| >= c flags (orbit proposals)
+    bool toofast_dirty = false;  // an orbit upload may have raised flags: clear before the slot is reused
     DagMat* dMats = nullptr;   // per-matrix records of this slot (max_batch entries)
     int mats_B = 0, mats_C = 0;
     int B = 0, C = 0;
@@ -448,6 +449,17 @@ static int upload_begin(psoap_chunk* h, int B, int c, const double* gp, double m
     return 0;
 }
 
+// The |v| >= c flags of a slot are zero unless an orbit upload used it: only then a memset is queued (it runs
+// as a kernel, and a kernel on the copy stream waits for the persistent kernel to leave the device -- the
+// plain H2D copies of the proposals do not).
+static int clear_too_fast(psoap_chunk* h, BatchSlot& sl)
+{
+    if (!sl.toofast_dirty) return 0;
+    HIP_TRY(hipMemsetAsync(sl.dTooFast, 0, sizeof(int) * (size_t)h->max_batch, h->copy));
+    sl.toofast_dirty = false;
+    return 0;
+}
+
 static int upload_end(psoap_chunk* h, BatchSlot& sl)
 {
     HIP_TRY(hipMemcpyAsync(sl.dGp, h->hGp, sizeof(double) * (size_t)sl.B * 2 * sl.C, hipMemcpyHostToDevice, h->copy));
@@ -464,7 +476,7 @@ extern "C" int psoap_batch_upload(psoap_chunk* h, int B, int c, const double* lw
     if (int rc = upload_begin(h, B, c, gp, mu_GP, &sl)) return rc;
     const size_t nl = (size_t)B * c * h->N;
     memcpy(h->hLwl, lwl, sizeof(double) * nl);
-    HIP_TRY(hipMemsetAsync(sl->dTooFast, 0, sizeof(int) * (size_t)B, h->copy));
+    if (int rc = clear_too_fast(h, *sl)) return rc;
     HIP_TRY(hipMemcpyAsync(sl->dLwl, h->hLwl, sizeof(double) * nl, hipMemcpyHostToDevice, h->copy));
     return upload_end(h, *sl);
 }
@@ -480,7 +492,7 @@ extern "C" int psoap_batch_upload_velocities(psoap_chunk* h, int B, int c, const
     const size_t nv = (size_t)B * c * h->n_epochs;
     memcpy(h->hVel, vel, sizeof(double) * nv);
     hipStream_t s = h->copy;
-    HIP_TRY(hipMemsetAsync(sl->dTooFast, 0, sizeof(int) * (size_t)B, s));
+    if (int rc = clear_too_fast(h, *sl)) return rc;
     HIP_TRY(hipMemcpyAsync(h->dVel, h->hVel, sizeof(double) * nv, hipMemcpyHostToDevice, s));
     dim3 grid((h->N + 255) / 256, B * c);
     hipLaunchKernelGGL(k_doppler_shift, grid, dim3(256), 0, s, sl->dLwl, h->dGrid, h->dEpoch, h->dVel, h->N,
@@ -534,7 +546,8 @@ extern "C" int psoap_batch_upload_orbits(psoap_chunk* h, int B, int model, const
     memcpy(h->hPorb, p_orb, sizeof(double) * (size_t)B * np);
     hipStream_t s = h->copy;
     HIP_TRY(hipMemcpyAsync(h->dPorb, h->hPorb, sizeof(double) * (size_t)B * np, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(sl->dTooFast, 0, sizeof(int) * (size_t)B, s));
+    HIP_TRY(hipMemsetAsync(sl->dTooFast, 0, sizeof(int) * (size_t)h->max_batch, s));
+    sl->toofast_dirty = true;
     hipLaunchKernelGGL(k_orbit_velocities, dim3((h->n_epochs + 63) / 64, B), dim3(64), 0, s, model, B, h->n_epochs,
                        h->dPorb, h->dDates, h->dVel, sl->dTooFast);
     HIP_TRY(hipGetLastError());

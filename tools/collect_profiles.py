@@ -28,6 +28,8 @@ def newest(pattern):
 
 
 shutil.copy(newest("trace/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+if glob.glob(os.path.join(src, "trace_full/*/*_kernel_stats.csv")):
+    shutil.copy(newest("trace_full/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats_full_bench.csv"))
 shutil.copy(os.path.join(src, f"summary_{tag}.md"), os.path.join(dst, f"{tag}_summary.md"))
 means = {}
 for name in ("sq", "fetch", "write"):
@@ -41,7 +43,15 @@ for name in ("sq", "fetch", "write"):
         means.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 fetch_kb = sum(means["FETCH_SIZE"]) / len(means["FETCH_SIZE"])
 write_kb = sum(means["WRITE_SIZE"]) / len(means["WRITE_SIZE"])
-old = json.load(open(os.path.join(dst, f"{tag}_traffic.json")))
+tpath = os.path.join(dst, f"{tag}_traffic.json")
+old = json.load(open(tpath)) if os.path.exists(tpath) else {
+    "round": int(tag[1:]) if tag[1:].isdigit() else tag,
+    "source": f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, "
+              "bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras)",
+    "kernel": "k_chol_dag<2, false, false>",
+    "workload": {"N": 6000, "components": 2, "walkers": 32, "mode": "dag"},
+    "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16 B/lane coalesced reads); "
+            "WRITE_SIZE taken as is"}
 old.update(fetch_size_kb_raw=fetch_kb, write_size_kb_raw=write_kb, fetch_correction=2.0,
            hbm_bytes_per_launch=(2.0 * fetch_kb + write_kb) * 1024.0)
 json.dump(old, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=2)

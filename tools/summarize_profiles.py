@@ -7,11 +7,12 @@ def one(pattern):
     return g[0] if g else None
 
 print(f"# rocprofv3 summary {tag}\n")
-print("Command profiled: `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cfg4` on one MI355X (ROCm 7.2): 32 walkers x SB2")
-print("N=6000 per step.  k_chol_dag dispatches: 1 warm-up + 3 timed + 1 event-profiled + 3 PCIe-inclusive + 4 through the")
-print("lnprob(p) boundary + 4 driven by the multi-chain MH sampler; the staged kernels (k_panel_update / k_potrf_diag / k_trsm_strip / k_fill_sym) come from the one")
-print("staged step bench.py runs to time the stand-alone fill kernel; the k_stream_* / k_mfma_f64_peak / k_tile_engine_bench")
-print("kernels are the micro-benchmarks behind `measured_peak`.\n")
+print("Command profiled: `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras` on one MI355X (ROCm 7.2): 32 walkers x SB2")
+print("N=6000 per step, so every k_chol_dag dispatch is the headline launch: 1 + 1 warm-up, 5 timed (H2D of the next")
+print("proposals under the evaluation), 1 + 5 proposals-resident, 1 event-profiled.  The k_stream_* / k_mfma_f64_peak /")
+print("k_tile_engine_bench kernels are the micro-benchmarks behind `measured_peak`.  The second trace (`trace_full`) is the")
+print("default `bench.py` with its side legs: the staged step that times k_fill_sym, predict at the retrieve shape")
+print("(k_chol_dag<3, true, true> + k_syrk_sub_sym), 8 chunks x 32 walkers in one launch, the lnprob(p) and sampler legs.\n")
 f = one("trace/**/*kernel_stats.csv")
 if f:
     print("## --kernel-trace --stats\n")
@@ -20,6 +21,16 @@ if f:
     for r in csv.DictReader(open(f)):
         name = r["Name"].split("(")[0]
         print(f"| {name} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
+    print()
+f = one("trace_full/**/*kernel_stats.csv")
+if f:
+    print("## --kernel-trace --stats, default bench.py with the side legs\n")
+    print("| kernel | calls | total ms | avg us | % |")
+    print("|---|---|---|---|---|")
+    for r in csv.DictReader(open(f)):
+        name = r["Name"].split("(")[0]
+        if float(r["Percentage"]) >= 0.01:
+            print(f"| {name} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
     print()
 
 def counters(sub):
