@@ -35,6 +35,7 @@
 #include "chol_kernels.hpp"
 #include "fill_kernels.hpp"
 #include "potrf_blocked.hpp"
+#include "potrf_spine.hpp"
 
 namespace psoap {
 
@@ -360,7 +361,11 @@ __device__ __attribute__((noinline)) void dag_diag_fast(double* Km, int ld, int 
         dag_wait_ge(&f->next_done, q, ctl, 2u);
         if (tl && threadIdx.x == 0) tl[4] = __builtin_amdgcn_s_memrealtime();
     };
+#ifdef PSOAP_NO_SPINE
     potrf_blocked<0, true>(Km, ld, k0, Wm, Rv, acc, prev, Km + (size_t)(k0 - NB) * ld + k0, wait_dep, tl);
+#else
+    potrf_spine_fused(Km, ld, k0, Wm, Rv, acc, prev, Km + (size_t)(k0 - NB) * ld + k0, wait_dep, tl);
+#endif
     dag_drain();
     if (tl && threadIdx.x == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0) {

@@ -1,0 +1,361 @@
+// potrf_spine.hpp -- the diagonal task of the latency scheme: form the 128 x 128 diagonal tile
+//     T = part - strip^T strip
+// in registers and factor it, with the serial pivot chain on a wave of its own.
+//
+// Same mathematics and outputs as potrf_blocked<.., FUSED = true> (U11 into the matrix, W = U11^-T k-major
+// into Wm, z = W r into r, sum log U_ii and z^T z into the accumulators), different division of labour.
+// In potrf_blocked every wave owns two blocks of every block row, so the in-wave factorisation of the next
+// diagonal block (16 dependent pivots, 2.6 us -- 40 % of the eight-step loop) can only start when wave 0 is
+// through with its share of the trailing update, and the other three waves wait for it.  Here
+//
+//   wave 0 ("spine")  owns the eight diagonal blocks and does nothing else: right
+//                     after block row bb is published it updates diagonal block bb+1 with it (one 16 x 16 x 16
+//                     product), factors it, parks W^T for the others and raises an LDS flag; the remaining
+//                     diagonal updates with row bb follow while the workers finish row bb+1;
+//   waves 1..3        own the 56 off-diagonal blocks and the 8 right-hand-side blocks (block (I, J) belongs to
+//                     wave 1 + (I + J) mod 3: 21 / 22 / 21 blocks, register slots fixed at compile time per wave): trailing update with row bb (phase C),
+//                     then -- behind the flag -- block row bb+1 = W_(bb+1) x (their blocks of that row)
+//                     (phase B), one workgroup barrier per step.
+//
+// The published block row lives in one of two LDS buffers (step parity): a worker already in phase B of
+// step bb+1 must not overwrite what the spine still reads for its deferred updates with row bb.
+#pragma once
+#include "potrf_blocked.hpp"
+
+namespace psoap {
+namespace ps {
+
+using pb::BLK;
+constexpr int OFF_ROW = 0;              // 2 x 9 blocks: row bb of U (J > bb) / W (J <= bb) / z (slot 8), buffer bb & 1
+constexpr int OFF_V = 18 * BLK;         // W_bb^T
+static_assert(OFF_V + BLK <= pb::OFF_TR, "spine layout must stay below the transpose scratch it shares with potrf_blocked");
+__shared__ int s_flag;                  // diagonal blocks factored and announced so far
+
+__device__ __forceinline__ int row_off(int bb) { return OFF_ROW + (bb & 1) * 9 * BLK; }
+// Wave W (1..3) owns block (I, J), J != I, when (I + J) mod 3 == W - 1; column 8 is the right-hand side
+// (r_k in its first column: it turns into z exactly like a block of U).  In block row I these are the
+// columns J = j0 + 3 s, s = 0..2, with j0 = (W - 1 - I) mod 3 -- register slot 3 I + s.  Slots whose column
+// falls outside 0..8 or on the diagonal are never touched (no register is spent on them): 21 / 22 / 21 blocks.
+constexpr int col0(int W, int I) { return ((W - 1 - I) % 3 + 3) % 3; }
+constexpr bool owned(int W, int I, int s) { return col0(W, I) + 3 * s <= 8 && col0(W, I) + 3 * s != I; }
+
+__device__ __forceinline__ void wait_flag(int target, int lane)
+{
+    if (lane == 0)
+        while (__hip_atomic_load(&s_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Workgroup barrier for LDS traffic only: waits for this wave's LDS operations, not for its global stores
+// (__syncthreads() also drains vmcnt: with the block-row outputs stored inside the step loop every barrier
+// would wait for the memory round trip of those stores).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ d4 neg(const d4& v) { return d4{-v[0], -v[1], -v[2], -v[3]}; }
+
+// ---- the three worker waves ------------------------------------------------------------------------------
+template <int W, class WaitFn>
+__device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, double* Rv,
+                                       const double* __restrict__ part, const double* __restrict__ strip,
+                                       WaitFn& wait_dep)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = lane >> 4, c = lane & 15;
+    d4 blk[24];
+#pragma unroll
+    for (int I = 0; I < 8; ++I)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (owned(W, I, s)) {
+                const int J = col0(W, I) + 3 * s;
+                d4 v = {0.0, 0.0, 0.0, 0.0};
+                if (J > I && J < 8) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = part[(size_t)(16 * I + q + 4 * r) * NB + 16 * J + c];
+                }
+                blk[3 * I + s] = v;
+            }
+    wait_dep();
+    // the right-hand side blocks (final only now: the task above updated them last)
+#pragma unroll
+    for (int I = 0; I < 8; ++I)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (owned(W, I, s) && col0(W, I) + 3 * s == 8) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) blk[3 * I + s][r] = (c == 0) ? Rv[k0 + 16 * I + q + 4 * r] : 0.0;
+            }
+    // ---- T -= strip^T strip on the upper blocks this wave owns (K = 128 in eight LDS stages)
+    stage_glds_one(strip, (size_t)ld, 0, 0, tid);
+    __syncthreads();
+    {
+        const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll 1
+        for (int ch = 0; ch < NB / KB; ++ch) {
+            const int cur = ch & 1;
+            if (ch + 1 < NB / KB) stage_glds_one(strip, (size_t)ld, (ch + 1) * KB, cur ^ 1, tid);
+            const int base = cur * LDS_BUFFER + fk * LDS_LD + fr;
+#pragma unroll
+            for (int I = 0; I < 7; ++I) {
+                double x[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) x[ks] = -psoap_smem[base + ks * 4 * LDS_LD + 16 * I];
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    if (owned(W, I, s) && col0(W, I) + 3 * s > I && col0(W, I) + 3 * s < 8) {
+                        const int J = col0(W, I) + 3 * s;
+                        double y[4];
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) y[ks] = psoap_smem[base + ks * 4 * LDS_LD + 16 * J];
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+                            blk[3 * I + s] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ks], y[ks], blk[3 * I + s], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();   // [S0] the spine has reset the flag; the stage buffers are free for the block rows
+
+#pragma unroll 1
+    for (int bb = 0; bb < 8; ++bb) {
+        // ---- B: block row bb (behind the flag of diagonal block bb).  The (up to three) products of the row
+        // are issued k-step by k-step so that consecutive MFMAs are independent.
+        wait_flag(bb + 1, lane);
+        {
+            const int base = row_off(bb);
+            const d4 x = pb::load_blk(OFF_V, lane);
+#pragma unroll
+            for (int I = 0; I < 8; ++I) {
+                if (I != bb) continue;
+                d4 res[3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) res[s] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+                        if (owned(W, I, s))
+                            res[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ks], blk[3 * I + s][ks], res[s], 0, 0, 0);
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    if (owned(W, I, s)) {
+                        const int J = col0(W, I) + 3 * s;
+                        pb::store_blk(base + J * BLK, lane, res[s]);
+                        blk[3 * I + s] = res[s];
+                    }
+            }
+        }
+        lds_barrier();     // [S1 + bb]
+        // ---- C: trailing update of the rows below with row bb
+        {
+            const int base = row_off(bb);
+#pragma unroll
+            for (int I = 1; I < 8; ++I) {
+                if (I <= bb) continue;
+                const d4 xs = neg(pb::load_blk(base + I * BLK, lane));           // -U_bI
+                // upper blocks, A_IJ -= U_bI^T U_bJ: always active here (J > I > bb), interleaved like phase B
+                d4 y[3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    if (owned(W, I, s) && col0(W, I) + 3 * s > I) y[s] = pb::load_blk(base + (col0(W, I) + 3 * s) * BLK, lane);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+                        if (owned(W, I, s) && col0(W, I) + 3 * s > I)
+                            blk[3 * I + s] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[ks], y[s][ks], blk[3 * I + s], 0, 0, 0);
+                // lower blocks, G_IJ -= U_bI^T W_bJ: active from step J on
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    if (owned(W, I, s) && col0(W, I) + 3 * s < I) {
+                        const int J = col0(W, I) + 3 * s;
+                        if (J <= bb) blk[3 * I + s] = pb::mma16(xs, pb::load_blk(base + J * BLK, lane), blk[3 * I + s]);
+                    }
+            }
+        }
+#ifdef PSOAP_SPINE_INLOOP_OUT
+        // ---- outputs of block row bb, final since phase B (measured slower than writing everything after the
+        // loop, even with a barrier that does not wait for the stores: kept for reference only)
+#pragma unroll
+        for (int I = 0; I < 8; ++I) {
+            if (I != bb) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                if (owned(W, I, s)) {
+                    const int J = col0(W, I) + 3 * s;
+                    if (J < I) {
+                        pb::emit_w(blk[3 * I + s], I, J, lane, W, Wm);
+                    } else if (J < 8) {
+                        const d4& v = blk[3 * I + s];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Km[(size_t)(k0 + 16 * I + q + 4 * r) * ld + k0 + 16 * J + c] = v[r];
+                    }
+                }
+        }
+#endif
+        // W_bb itself (parked by the spine in the row buffer) goes out to memory from here, off the spine's chain
+        if (W == 1) pb::emit_w(pb::load_blk(row_off(bb) + bb * BLK, lane), bb, bb, lane, 1, Wm);
+    }
+    double zz = 0.0;
+#ifndef PSOAP_SPINE_INLOOP_OUT
+    // ---- outputs of this wave: its blocks of W (strictly lower), of U11 (strictly upper) and of z
+#pragma unroll
+    for (int I = 0; I < 8; ++I)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (owned(W, I, s)) {
+                const int J = col0(W, I) + 3 * s;
+                if (J < I) {
+                    pb::emit_w(blk[3 * I + s], I, J, lane, W, Wm);
+                } else if (J < 8) {
+                    const d4& v = blk[3 * I + s];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Km[(size_t)(k0 + 16 * I + q + 4 * r) * ld + k0 + 16 * J + c] = v[r];
+                } else {
+                    // z (column 0 of the rhs block) back into r, and its share of z^T z
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (c == 0) {
+                            const double z = blk[3 * I + s][r];
+                            Rv[k0 + 16 * I + q + 4 * r] = z;
+                            zz = fma(z, z, zz);
+                        }
+                }
+            }
+#endif
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) zz += __shfl_xor(zz, off, 64);
+    if (lane == 0) psoap_smem[pb::OFF_RED + W] = zz;
+}
+
+// ---- wave 0 --------------------------------------------------------------------------------------------
+// factor diagonal block bb (d), park W_bb and W_bb^T (the X operand of W_bb Y) in LDS, announce
+__device__ __forceinline__ void spine_factor(d4& d, int bb, int lane, int& bad, double& logsum)
+{
+    const int q = lane >> 4, c = lane & 15;
+    d4 wdiag;
+    pb::chol16(d, wdiag, lane, bad);
+    pb::store_blk(row_off(bb) + bb * BLK, lane, wdiag);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) psoap_smem[pb::OFF_TR + (q + 4 * r) * 17 + c] = wdiag[r];
+    __builtin_amdgcn_wave_barrier();
+    d4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = psoap_smem[pb::OFF_TR + c * 17 + q + 4 * r];
+    __builtin_amdgcn_wave_barrier();
+    pb::store_blk(OFF_V, lane, v);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&s_flag, bb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    double dg = 1.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dg = (c == q + 4 * r) ? d[r] : dg;
+    logsum += log(dg);
+}
+
+template <class WaitFn>
+__device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* __restrict__ part,
+                                      const double* __restrict__ strip, WaitFn& wait_dep, unsigned long long* tl)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = lane >> 4, c = lane & 15;
+    d4 d[8];
+#pragma unroll
+    for (int I = 0; I < 8; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[I][r] = part[(size_t)(16 * I + q + 4 * r) * NB + 16 * I + c];
+    wait_dep();
+    stage_glds_one(strip, (size_t)ld, 0, 0, tid);
+    __syncthreads();
+    {
+        const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll 1
+        for (int ch = 0; ch < NB / KB; ++ch) {
+            const int cur = ch & 1;
+            if (ch + 1 < NB / KB) stage_glds_one(strip, (size_t)ld, (ch + 1) * KB, cur ^ 1, tid);
+            const int base = cur * LDS_BUFFER + fk * LDS_LD + fr;
+#pragma unroll
+            for (int I = 0; I < 8; ++I) {
+                double x[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) x[ks] = psoap_smem[base + ks * 4 * LDS_LD + 16 * I];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) d[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[ks], x[ks], d[I], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+    if (tl && lane == 0) tl[5] = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) __hip_atomic_store(&s_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();   // [S0]
+    int bad = 0;
+    double logsum = 0.0;
+    spine_factor(d[0], 0, lane, bad, logsum);
+#pragma unroll 1
+    for (int bb = 0; bb < 7; ++bb) {
+        lds_barrier();     // [S1 + bb] block row bb is published
+        const int base = row_off(bb);
+        // ---- the next diagonal block first: update with row bb, factor, announce
+#pragma unroll
+        for (int I = 1; I < 8; ++I)
+            if (I == bb + 1) {
+                const d4 xi = pb::load_blk(base + I * BLK, lane);
+                d[I] = pb::mma16(neg(xi), xi, d[I]);
+                spine_factor(d[I], I, lane, bad, logsum);
+            }
+        // ---- deferred: the other diagonal blocks, while the workers finish row bb+1
+#pragma unroll
+        for (int I = 2; I < 8; ++I)
+            if (I > bb + 1) {
+                const d4 xi = pb::load_blk(base + I * BLK, lane);
+                d[I] = pb::mma16(neg(xi), xi, d[I]);
+            }
+    }
+    lds_barrier();         // [S1 + 7]
+    if (tl && lane == 0) tl[6] = __builtin_amdgcn_s_memrealtime();
+    // ---- outputs: the diagonal blocks of U11; log-determinant share and the not-positive-definite flag for
+    // the caller (through LDS: the accumulators are updated after the closing barrier)
+#pragma unroll
+    for (int I = 0; I < 8; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Km[(size_t)(k0 + 16 * I + q + 4 * r) * ld + k0 + 16 * I + c] = d[I][r];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) logsum += __shfl_xor(logsum, off, 64);
+    if (lane == 0) {
+        psoap_smem[pb::OFF_RED + 0] = logsum;
+        psoap_smem[pb::OFF_RED + 4] = bad ? 1.0 : 0.0;
+    }
+}
+
+}  // namespace ps
+
+// All 256 threads call this.  part: the tile's running sum (row-major 128 x 128, read before wait_dep());
+// strip: the tile above the diagonal (k-major, leading dimension ld), final once wait_dep() returns.
+// wait_dep() is called by every thread exactly once (it may contain a workgroup barrier).
+template <class WaitFn>
+__device__ __forceinline__ void potrf_spine_fused(double* Km, int ld, int k0, double* Wm, double* Rv, MatAcc* acc,
+                                                  const double* __restrict__ part, const double* __restrict__ strip,
+                                                  WaitFn wait_dep, unsigned long long* tl = nullptr)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == 0) ps::spine(Km, ld, k0, part, strip, wait_dep, tl);
+    else if (wave == 1) ps::worker<1>(Km, ld, k0, Wm, Rv, part, strip, wait_dep);
+    else if (wave == 2) ps::worker<2>(Km, ld, k0, Wm, Rv, part, strip, wait_dep);
+    else ps::worker<3>(Km, ld, k0, Wm, Rv, part, strip, wait_dep);
+    __syncthreads();   // all outputs issued, the reductions are in LDS
+    if (threadIdx.x == 0) {
+        const double l = psoap_smem[pb::OFF_RED + 0];
+        const double qd = (psoap_smem[pb::OFF_RED + 1] + psoap_smem[pb::OFF_RED + 2]) + psoap_smem[pb::OFF_RED + 3];
+        // MatAcc is handed from block row to block row across workgroups: agent-scope accesses only
+        const double l0 = __hip_atomic_load(&acc->logdet_half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double q0 = __hip_atomic_load(&acc->quad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&acc->logdet_half, l0 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&acc->quad, q0 + qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (psoap_smem[pb::OFF_RED + 4] != 0.0) __hip_atomic_store(&acc->info, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (the LDS scratch goes back to the tile engine behind the caller's next barrier: dag_drain)
+    if (tl && threadIdx.x == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
+}
+
+}  // namespace psoap
