@@ -77,8 +77,11 @@ __device__ __forceinline__ void tile_mma_chunk(Tile& t, int buf, int wr, int wc,
     // being hoisted out of the K-loop: as loop invariants they are the values hipcc spills first when the
     // kernel around the loop grows (a scratch reload in front of the fragment reads also waits for the
     // LDS-DMA of the next stage -- vmcnt counts both -- and serialises it with the MFMAs)
-    int l = lane;
-    asm volatile("" : "+v"(l));
+    // (the lane id itself comes from the exec mask -- all 64 lanes are active here -- so not even it has to
+    // stay in a register across the loop)
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    (void)lane;
     const int fr = l & 15, fk = l >> 4;
     const int baseA = buf * LDS_BUFFER + fk * LDS_LD + wr * 64 + fr;
     const int baseB = buf * LDS_BUFFER + LDS_OPERAND + fk * LDS_LD + wc * 64 + fr;
