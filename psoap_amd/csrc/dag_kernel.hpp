@@ -28,6 +28,8 @@
 // factored), cnt (finished tasks of the current block row).  The update of block row q reads
 // rows < q; it is split so that rows < q-1 are consumed before waiting for row q-1 (look-ahead).
 #pragma once
+#include <stdlib.h>
+
 #include <algorithm>
 #include <utility>
 #include <vector>
@@ -579,12 +581,21 @@ struct DagPlan {
     int scheme = 0;            // 0 throughput, 1 latency: selects the kernel instantiation (k_chol_dag<.., LAT>)
 };
 
-inline int dag_split_factor(int tasks_in_row, int q, int workers)
+inline int dag_split_factor(int tasks_in_row, int q, int workers, int scheme)
 {
-    // cut tiles of sparse block rows until the row offers about `workers` tasks (at most 8 parts,
-    // each at least two panels long)
+    // cut tiles of sparse block rows until the row offers about `workers` tasks (at most 8 parts).
+    // Throughput scheme: full occupancy, parts at least two panels long.  Latency scheme: half the workers,
+    // parts at least four panels long -- every part costs a round trip of its 128 KB partial tile through the
+    // workspace and a dependency hand-off, and the workers that are not on a matrix's critical path have
+    // slack (measured, tools/split_sweep.sh: N = 2000, B = 32: 3.0 -> 2.5 ms; N = 6000, B = 4: 7.7 -> 7.1 ms;
+    // single evaluations unchanged; a quarter of the workers is too few from N = 6000, B = 8 on).
+    // PSOAP_DAG_SPLIT_PCT / PSOAP_DAG_SPLIT_MIN override both numbers (experiments).
+    static const int env_pct = getenv("PSOAP_DAG_SPLIT_PCT") ? atoi(getenv("PSOAP_DAG_SPLIT_PCT")) : 0;
+    static const int env_min = getenv("PSOAP_DAG_SPLIT_MIN") ? atoi(getenv("PSOAP_DAG_SPLIT_MIN")) : 0;
+    const int pct = env_pct > 0 ? env_pct : (scheme == 1 ? 50 : 100);
+    const int minp = env_min > 0 ? env_min : (scheme == 1 ? 4 : 2);
     int S = 1;
-    while (S < 8 && tasks_in_row * S < workers && 2 * S <= q) S *= 2;
+    while (S < 8 && tasks_in_row * S * 100 < workers * pct && minp * S <= q) S *= 2;
     return S;
 }
 
@@ -672,7 +683,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
             live = Bq_nominal;
         }
         const int Bq = live;
-        const int S_off = dag_split_factor((int)row_tiles, q, workers);
+        const int S_off = dag_split_factor((int)row_tiles, q, workers, scheme);
         // latency scheme: DIAG(q) also solves the tile right of the diagonal (DAG_FUSED) whenever a next
         // diagonal tile exists, and DIAG(q >= 1) waits only for that tile of the row above (DAG_WAITNEXT)
         auto fused = [&](int b) { return scheme == 1 && q + 1 < Ps[b]; };
@@ -689,7 +700,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
         // Latency scheme: the PART that needs the block row just above (panel q-1, available only when ALL
         // of row q-1 is finished) is one panel long; the long ones cover [0, q-1) and run a row earlier.
         if (q + 1 < P && q >= 1) {
-            const int S_pre = dag_split_factor(Bq, q, workers / 4 > 0 ? workers / 4 : 1);
+            const int S_pre = dag_split_factor(Bq, q, workers / 4 > 0 ? workers / 4 : 1, scheme);
             for (int b : mats) {
                 if (q + 1 >= Ps[b]) continue;
                 const unsigned int ctr = plan.n_ctrs++;
