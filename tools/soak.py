@@ -8,7 +8,7 @@ from psoap_amd.chunk import ChunkGroup, ChunkHandle
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 t_end = time.time() + budget
-cases = [(1, 32), (1, 5), (2, 32), (3, 32), (3, 3), (5, 8)]
+cases = [(1, 32), (1, 5), (2, 32), (3, 32), (3, 3), (3, 12), (5, 8), (5, 1)]
 n_launch = 0
 while time.time() < t_end:
     for cfg, B in cases:
