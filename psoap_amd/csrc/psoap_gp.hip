@@ -870,6 +870,8 @@ struct psoap_group {
     int scheme = 0;
 };
 
+extern "C" int psoap_group_destroy(psoap_group* g);
+
 extern "C" int psoap_group_create(psoap_group** out, psoap_chunk* const* handles, int n)
 {
     if (!out || !handles || n < 1) FAIL("psoap_group_create: bad arguments");
@@ -878,12 +880,18 @@ extern "C" int psoap_group_create(psoap_group** out, psoap_chunk* const* handles
         if (handles[k]->device != handles[0]->device) FAIL("psoap_group_create: all chunks must live on one device");
         if (handles[k]->P > 255) FAIL("psoap_group_create: N too large for the persistent kernel (N <= 32640)");
     }
+    *out = nullptr;
     HIP_TRY(hipSetDevice(handles[0]->device));
     psoap_group* g = new psoap_group();
     g->device = handles[0]->device;
     g->hs.assign(handles, handles + n);
-    HIP_TRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&g->evDone, hipEventDisableTiming));
+    hipError_t e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->evDone, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)psoap_group_destroy(g);
+        g_err = std::string("psoap_group_create: ") + hipGetErrorString(e);
+        return 1;
+    }
     *out = g;
     return 0;
 }
