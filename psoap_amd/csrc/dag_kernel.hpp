@@ -305,13 +305,16 @@ __device__ __forceinline__ void dag_sub_partials(Tile& t, const double* __restri
 }
 
 // strip solve + right-hand-side update for tile (k0, j0); the updated tile is already in memory
+// BAL: the row blocks are dealt to the waves by work (tile_gemm_tn_lower_balanced and its accumulator map)
+template <bool BAL = false>
 __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, int j0, const double* Wm, double* Rv,
                                          int Npad, double* zk, double* colsum)
 {
     const int tid = threadIdx.x;
     if (tid < NB) zk[tid] = Rv[k0 + tid];
     t.zero();
-    tile_gemm_tn_lower(t, Wm, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld);
+    if (BAL) tile_gemm_tn_lower_balanced(t, Wm, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld);
+    else tile_gemm_tn_lower(t, Wm, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld);
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     double part[4] = {0.0, 0.0, 0.0, 0.0};
@@ -319,7 +322,7 @@ __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, in
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = tile_row(wr, m, lane, r);
+            const int row = BAL ? 16 * lower_rowblock(wr, m) + (lane >> 4) + 4 * r : tile_row(wr, m, lane, r);
             const double z = zk[row];
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -377,7 +380,7 @@ __device__ __attribute__((noinline)) void dag_diag_fast(double* Km, int ld, int 
     if (fused) {
         Tile t;
         dag_wait_ge(&f->off1_ready, q + 1, ctl, 5u);
-        dag_trsm(t, Km, ld, k0, k0 + NB, Wm, Rv, Npad, zk, colsum);
+        dag_trsm<true>(t, Km, ld, k0, k0 + NB, Wm, Rv, Npad, zk, colsum);
         dag_drain();
         if (threadIdx.x == 0) {
             dag_release_fence();

@@ -209,6 +209,56 @@ __device__ __forceinline__ void tile_gemm_tn_lower(Tile& t, const double* __rest
     }
 }
 
+// The same product with the row blocks dealt to the two wave rows by WORK instead of by position.  Row block
+// rb (16 rows) takes part in chunks c <= rb, i.e. rb + 1 of the 8 chunks: in the natural order the waves of
+// the lower half (row blocks 4..7) issue 26 (row block, chunk) pairs and those of the upper half 10, and the
+// product takes as long as the busy half needs.  Here wave row 0 owns row blocks {0, 1, 6, 7} and wave row 1
+// {2, 3, 4, 5}: 18 pairs each (288 MFMAs per wave instead of 416 / 160).  Accumulator (m, n, reg) of wave
+// (wr, wc) is element (16 lower_rowblock(wr, m) + (lane >> 4) + 4 reg, 64 wc + 16 n + (lane & 15)).
+// Used by the strip solve on the row-to-row critical path only (dag_diag_fast): inside the kernel body the
+// different loop shape upset hipcc's register allocation of the c = 2 kernels (measured +3 %).
+__device__ __forceinline__ constexpr int lower_rowblock(int wr, int m) { return wr == 0 ? (m < 2 ? m : m + 4) : m + 2; }
+
+__device__ __forceinline__ void tile_gemm_tn_lower_balanced(Tile& t, const double* __restrict__ A, size_t lda,
+                                                            const double* __restrict__ B, size_t ldb)
+{
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    stage_glds(A, lda, B, ldb, 0, 0, tid);
+    __syncthreads();
+    constexpr int nchunk = NB / KB;
+    for (int c = 0; c < nchunk; ++c) {
+        const int cur = c & 1;
+        if (c + 1 < nchunk) stage_glds(A, lda, B, ldb, (c + 1) * KB, cur ^ 1, tid);
+        const int fr = tid & 15, fk = (tid & 63) >> 4;
+        const int baseA = cur * LDS_BUFFER + fk * LDS_LD + fr;
+        const int baseB = cur * LDS_BUFFER + LDS_OPERAND + fk * LDS_LD + wc * 64 + fr;
+        // wave-uniform: which of this wave's four row blocks still reach below the diagonal of the factor
+        bool live[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) live[m] = c <= lower_rowblock(wr, m);
+        if (live[0] || live[1] || live[2] || live[3]) {
+#pragma unroll
+            for (int ks = 0; ks < KB / 4; ++ks) {
+                double a[4], b[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) a[m] = psoap_smem[baseA + ks * 4 * LDS_LD + 16 * lower_rowblock(wr, m)];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) b[n] = psoap_smem[baseB + ks * 4 * LDS_LD + n * 16];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if (!live[m]) continue;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        t.acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], t.acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // element coordinates of accumulator (m, n, reg) inside the 128 x 128 tile
 __device__ __forceinline__ int tile_row(int wr, int m, int lane, int r) { return wr * 64 + m * 16 + (lane >> 4) + 4 * r; }
 __device__ __forceinline__ int tile_col(int wc, int n, int lane) { return wc * 64 + n * 16 + (lane & 15); }
