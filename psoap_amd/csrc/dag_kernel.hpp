@@ -829,6 +829,33 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
     return plan;
 }
 
+// How many persistent workgroups a batch gets: all the device admits (two per compute unit), or ONE per compute
+// unit when the batch is bound by the row-to-row chains of its matrices and not by MFMA throughput.  The
+// in-block factorisation on a chain is VALU / LDS work in dependent steps; an MFMA-streaming workgroup on the
+// same compute unit owns the double-precision pipe for 64 cycles per instruction and slows it up to 2x
+// (priorities only decide who issues next).  With one workgroup per compute unit the chain runs undisturbed:
+// N = 6000: 4.1 -> 3.5 ms for one evaluation, N = 2000, B = 8: 1.40 -> 1.27 ms -- but the device then
+// delivers roughly half the throughput, so the switch is by work: measured over N = 2000 .. 8192, B = 1 .. 32
+// (tools/latency_quick.py under PSOAP_DAG_WORKERS), one per compute unit wins while
+//     algorithmic flops of the batch  <=  3.3e9 x block rows of its largest matrix
+// (chain time ~ 75 us per block row against ~35 TFLOP/s of the half-populated device), i.e. B N^2 <~ 7.7e7.
+inline int dag_pick_workers(double flops, int Pmax, int compute_units, int max_workers)
+{
+    if (const char* e = getenv("PSOAP_DAG_WORKERS"))      // experiments
+        if (atoi(e) > 0) return atoi(e);
+    if (max_workers <= compute_units) return max_workers;
+    return flops <= 3.3e9 * (double)Pmax ? compute_units : max_workers;
+}
+inline double dag_batch_flops(const std::vector<int>& Ps, int Mt = 0)
+{
+    double f = 0.0;
+    for (int P : Ps) {
+        const double n = 128.0 * P, r = 128.0 * Mt;
+        f += n * n * n / 3.0 + n * n * r;
+    }
+    return f;
+}
+
 // uniform batch: B matrices of P block rows each
 inline DagPlan dag_build_tasks(int B, int P, int workers, int scheme = -1, int Mt = 0)
 {

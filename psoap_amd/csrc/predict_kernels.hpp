@@ -226,7 +226,7 @@ struct PredictWs {
     // task list cache
     int plan_P = -1, plan_Mt = -1, plan_workers = -1, plan_scheme = -2;
     DagPlan plan;
-    int workers = 0;
+    int workers = 0, n_cus = 0;   // persistent workgroups the device admits; compute units
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {};
     PredictTimes times;
@@ -370,8 +370,10 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         }
         const char* env_scheme = getenv("PSOAP_DAG_SCHEME");
         const int scheme = env_scheme ? atoi(env_scheme) : -1;
-        if (ws.plan_P != P || ws.plan_Mt != Mt || ws.plan_workers != ws.workers || ws.plan_scheme != scheme) {
-            ws.plan = dag_build_tasks(1, P, ws.workers, scheme, Mt);
+        const int workers = dag_pick_workers(dag_batch_flops(std::vector<int>(1, P), Mt), P, ws.n_cus > 0 ? ws.n_cus : ws.workers,
+                                             ws.workers);
+        if (ws.plan_P != P || ws.plan_Mt != Mt || ws.plan_workers != workers || ws.plan_scheme != scheme) {
+            ws.plan = dag_build_tasks(1, P, workers, scheme, Mt);
             PR_TRY(hipStreamSynchronize(st));
             PR_TRY(ws.Tasks.need(ws.plan.tasks.size()));
             PR_TRY(hipMemcpy(ws.Tasks, ws.plan.tasks.data(), sizeof(DagTask) * ws.plan.tasks.size(),
@@ -379,7 +381,7 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
             PR_TRY(ws.Ws.need((size_t)NB * NB * ((size_t)ws.plan.n_slots + 1)));
             ws.plan_P = P;
             ws.plan_Mt = Mt;
-            ws.plan_workers = ws.workers;
+            ws.plan_workers = workers;
             ws.plan_scheme = scheme;
         }
         const DagPlan& plan = ws.plan;
@@ -392,7 +394,7 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         PR_TRY(hipMemsetAsync(ws.Dag, 0, dag_bytes, st));
         PR_TRY(hipMemsetAsync(dW, 0, sizeof(double) * 2 * NB * NB, st));  // the strictly upper part of W stays zero
         hipLaunchKernelGGL(k_init_rhs, dim3((Npad + 255) / 256, 1), dim3(256), 0, st, dR, Npad, N, dFl, offset, dAcc);
-        const int grid = (int)(plan.tasks.size() < (size_t)ws.workers ? plan.tasks.size() : (size_t)ws.workers);
+        const int grid = (int)(plan.tasks.size() < (size_t)workers ? plan.tasks.size() : (size_t)workers);
         const DagAug aug{P + Mt, Rq, Rq_pad, ws.Colx};
         MatFlags* fl_ = reinterpret_cast<MatFlags*>(ws.Dag.p + sizeof(DagCtl));
         DagCtl* ctl_ = reinterpret_cast<DagCtl*>(ws.Dag.p);

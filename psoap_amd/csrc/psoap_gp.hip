@@ -99,7 +99,8 @@ struct psoap_chunk {
     char* dDag = nullptr;    // DagCtl followed by max_batch MatFlags (zeroed before every DAG launch)
     unsigned int* hDagErr = nullptr;
     int mode = 1;            // 1 = persistent DAG kernel, 0 = staged panels
-    int dag_grid = 0;
+    int dag_grid = 0, n_cus = 0;   // persistent workgroups the device admits; compute units
+    int plan_workers = 0;          // workgroups of the current task list (dag_pick_workers)
     // task list of the persistent kernel for the current batch size (dag_build_tasks)
     int plan_B = 0, plan_scheme = 0;
     unsigned int plan_tasks = 0, plan_ctrs = 0, plan_slots = 0;
@@ -189,7 +190,7 @@ static int enter_device(int device)
 }
 
 // persistent workgroups of the dependency-graph kernel on this device (2 per CU when they fit)
-static int dag_workers(int device, int* out)
+static int dag_workers(int device, int* out, int* cus = nullptr)
 {
     int blocks_per_cu = 0;
     hipDeviceProp_t prop;
@@ -199,6 +200,7 @@ static int dag_workers(int device, int* out)
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     if (blocks_per_cu > 2) blocks_per_cu = 2;
     *out = blocks_per_cu * prop.multiProcessorCount;
+    if (cus) *cus = prop.multiProcessorCount;
     return 0;
 }
 
@@ -233,7 +235,7 @@ static int chunk_alloc(psoap_chunk* h, const double* fl, const double* sigma)
     HIP_TRY(hipMalloc(&h->dDag, h->arrive_off + sizeof(int) * h->arrive_cap));
     HIP_TRY(hipHostMalloc(&h->hDagErr, 64));
     h->hDagErr[0] = 0;
-    if (int rc = dag_workers(h->device, &h->dag_grid)) return rc;
+    if (int rc = dag_workers(h->device, &h->dag_grid, &h->n_cus)) return rc;
     // one compute stream per handle; the extra streams of the staged mode's groups are created on first
     // use, so that the streams of several handles spread over the runtime's hardware queues (handles that
     // evaluate concurrently must not share one).  Uploads run on a stream of their own.
@@ -666,7 +668,9 @@ static int dag_prepare(psoap_chunk* h)
     HIP_TRY(hipStreamSynchronize(h->streams[0]));
     // PSOAP_DAG_SCHEME=0|1 pins the split scheme (experiments); default: automatic
     const char* env_scheme = getenv("PSOAP_DAG_SCHEME");
-    DagPlan plan = dag_build_tasks(sl.B, h->P, h->dag_grid, env_scheme ? atoi(env_scheme) : -1);
+    const std::vector<int> Ps((size_t)sl.B, h->P);
+    const int workers = dag_pick_workers(dag_batch_flops(Ps), h->P, h->n_cus, h->dag_grid);
+    DagPlan plan = dag_build_tasks(Ps, workers, env_scheme ? atoi(env_scheme) : -1);
     if (plan.n_ctrs > h->arrive_cap) FAIL("internal: arrival counter capacity exceeded");
     if (plan.tasks.size() > h->tasks_cap) {
         if (h->dTasks) HIP_TRY(hipFree(h->dTasks));
@@ -684,6 +688,7 @@ static int dag_prepare(psoap_chunk* h)
     }
     HIP_TRY(hipMemcpy(h->dTasks, plan.tasks.data(), sizeof(DagTask) * plan.tasks.size(), hipMemcpyHostToDevice));
     h->plan_B = sl.B;
+    h->plan_workers = workers;
     h->plan_scheme = plan.scheme;
     h->plan_tasks = (unsigned int)plan.tasks.size();
     h->plan_ctrs = plan.n_ctrs;
@@ -709,7 +714,7 @@ static int eval_dag(psoap_chunk* h)
     HIP_TRY(hipMemsetAsync(h->dDag, 0, h->arrive_off + sizeof(int) * ((size_t)h->plan_ctrs + 4), s));
     if (prof_end(h, s)) return 1;
     const long long tasks = h->plan_tasks;
-    const int grid = (int)(tasks < h->dag_grid ? tasks : h->dag_grid);
+    const int grid = (int)(tasks < h->plan_workers ? tasks : h->plan_workers);
     // executed MFMA flops: left-looking updates + strip solves, full 128^3 tiles
     double fl = 0.0;
     for (int q = 0; q < P; ++q) fl += 2.0 * NB * NB * ((double)q * NB * (P - q) + (double)NB * (P - q - 1));
@@ -868,6 +873,7 @@ struct psoap_group {
     long long n_tasks = 0;
     int total_B = 0;
     int scheme = 0;
+    int workers = 0;
 };
 
 extern "C" int psoap_group_destroy(psoap_group* g);
@@ -940,7 +946,10 @@ extern "C" int psoap_group_eval(psoap_group* g)
             b0 += sl.B;
         }
         const char* env_scheme = getenv("PSOAP_DAG_SCHEME");
-        DagPlan plan = dag_build_tasks(Ps, g->hs[0]->dag_grid, env_scheme ? atoi(env_scheme) : -1);
+        int Pmax = 0;
+        for (int P : Ps) Pmax = P > Pmax ? P : Pmax;
+        g->workers = dag_pick_workers(dag_batch_flops(Ps), Pmax, g->hs[0]->n_cus, g->hs[0]->dag_grid);
+        DagPlan plan = dag_build_tasks(Ps, g->workers, env_scheme ? atoi(env_scheme) : -1);
         if (mats.size() > g->mats_cap) {
             if (g->dMats) HIP_TRY(hipFree(g->dMats));
             g->dMats = nullptr;
@@ -986,7 +995,7 @@ extern "C" int psoap_group_eval(psoap_group* g)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(g->dDag, 0, g->dag_bytes, s));
     {
-        const int workers = g->hs[0]->dag_grid;
+        const int workers = g->workers;
         const int grid = (int)(g->n_tasks < workers ? g->n_tasks : workers);
         MatFlags* fl_ = reinterpret_cast<MatFlags*>(g->dDag + sizeof(DagCtl));
         DagCtl* ctl_ = reinterpret_cast<DagCtl*>(g->dDag);
@@ -1144,7 +1153,7 @@ extern "C" int psoap_predict(int device, int mode, int c, int N, int M, const do
     if (int rc = predict_check(mode, c, N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
     if (int rc = enter_device(device)) return rc;
     PredictWs ws;
-    if (int rc = dag_workers(device, &ws.workers)) return rc;
+    if (int rc = dag_workers(device, &ws.workers, &ws.n_cus)) return rc;
     int status = 0;
     const int rc = predict_run(ws, mode, c, N, M, lwl, fl, sigma, nullptr, nullptr, lwl_pred, mu_c, gp, mu_out,
                                Sigma_out, &status, g_err);
@@ -1177,7 +1186,7 @@ extern "C" int psoap_predictor_create(psoap_predictor** out, int device)
     if (int rc = enter_device(device)) return rc;
     psoap_predictor* p = new psoap_predictor();
     p->device = device;
-    if (int rc = dag_workers(device, &p->ws.workers)) {
+    if (int rc = dag_workers(device, &p->ws.workers, &p->ws.n_cus)) {
         delete p;
         return rc;
     }
@@ -1227,6 +1236,7 @@ extern "C" int psoap_chunk_predict(psoap_chunk* h, int mode, int c, int M, const
     if (!h->pws) {
         h->pws = new PredictWs();
         h->pws->workers = h->dag_grid;
+        h->pws->n_cus = h->n_cus;
     }
     int status = 0;
     const int rc = predict_run(*h->pws, mode, c, h->N, M, lwl, nullptr, nullptr, h->dFl, h->dSigma, lwl_pred, mu_c, gp,
