@@ -240,6 +240,12 @@ int psoap_dag_plan_multi(int B, const int *Ps, int workers, void *out, long long
                          long long *n_tasks, long long *n_slots, long long *n_ctrs,
                          unsigned int *queue_first);
 
+/* Pure host function: the number of persistent workgroups a batch gets -- all the device admits (two per
+ * compute unit), or one per compute unit when the batch is bound by the row-to-row chains of its matrices
+ * (algorithmic flops <= 3.3e9 x block rows of the largest matrix).  Ps[b]: block rows of
+ * matrix b, Mt: appended column tiles (predict). */
+int psoap_dag_pick_workers(int B, const int *Ps, int Mt, int compute_units, int max_workers, int *workers);
+
 /* fp64 MFMA / HBM micro-benchmarks used to state the measured peaks beside the
  * spec peaks in bench.py (results in TFLOP/s and GB/s). */
 int psoap_microbench_mfma_f64(int device, double *tflops);

@@ -92,6 +92,7 @@ SIGNATURES = {
     "psoap_dag_plan_multi": (ctypes.c_int, [ctypes.c_int, _ip, ctypes.c_int, _vp, ctypes.c_longlong,
                                       ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong),
                                       ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_uint32)]),
+    "psoap_dag_pick_workers": (ctypes.c_int, [ctypes.c_int, _ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip]),
     "psoap_microbench_mfma_f64": (ctypes.c_int, [ctypes.c_int, _dp]),
     "psoap_microbench_tile_engine": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp]),
     "psoap_microbench_potrf": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp]),

@@ -398,6 +398,18 @@ extern "C" int psoap_dag_plan_multi(int B, const int* Ps, int workers, void* out
     return 0;
 }
 
+// Pure host function: how many persistent workgroups a batch of B matrices (Ps[b] block rows each, Mt appended
+// column tiles) gets on a device with `compute_units` CUs that admits `max_workers` of them (dag_pick_workers).
+extern "C" int psoap_dag_pick_workers(int B, const int* Ps, int Mt, int compute_units, int max_workers, int* workers)
+{
+    if (B < 1 || !Ps || Mt < 0 || compute_units < 1 || max_workers < 1 || !workers) FAIL("psoap_dag_pick_workers: bad arguments");
+    const std::vector<int> v(Ps, Ps + B);
+    int Pmax = 0;
+    for (int P : v) Pmax = P > Pmax ? P : Pmax;
+    *workers = dag_pick_workers(dag_batch_flops(v, Mt), Pmax, compute_units, max_workers);
+    return 0;
+}
+
 // Debug: copy the current task list (16-byte DagTask records, ticket order) to the host.
 extern "C" int psoap_chunk_dag_tasks(psoap_chunk* h, void* out, long long max_tasks, long long* n_tasks)
 {
