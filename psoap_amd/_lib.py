@@ -97,6 +97,7 @@ SIGNATURES = {
     "psoap_microbench_tile_engine": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp]),
     "psoap_microbench_potrf": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp]),
     "psoap_microbench_hbm": (ctypes.c_int, [ctypes.c_int, _dp, _dp]),
+    "psoap_microbench_mix": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp]),
 }
 
 _lib = None

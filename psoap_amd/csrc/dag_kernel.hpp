@@ -463,7 +463,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
 
         if (tlog && threadIdx.x == 0) {
             tlog[ticket * 8 + 0] = __builtin_amdgcn_s_memrealtime();
-            tlog[ticket * 8 + 7] = __builtin_amdgcn_s_memtime();     // shader clock = d(memtime) / d(realtime) x 100 MHz
+            // where it ran: the XCD and HW_REG_HW_ID (wave slot, SIMD, CU, SH, SE) -- tools/dag_cu_overlap.py
+            tlog[ticket * 8 + 7] = ((unsigned long long)(unsigned int)home << 32) |
+                                   (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));
         }
         const int ttype = task.type & DAG_TYPE_MASK;
         const bool chain = (task.type & DAG_CHAIN) != 0;

@@ -191,7 +191,9 @@ inline int microbench_tile_engine(int shared_operands, double* tflops, std::stri
     int dev = 0;
     MB_TRY(hipGetDevice(&dev));
     MB_TRY(hipGetDeviceProperties(&prop, dev));
-    const int blocks = prop.multiProcessorCount * 2;
+    // + 64: ONE workgroup per compute unit (what a workgroup achieves while its neighbour is outside its K-loop)
+    const int blocks = prop.multiProcessorCount * ((shared_operands & 64) ? 1 : 2);
+    shared_operands &= ~64;
     const int K = 4096;
     const size_t ld = (size_t)blocks * NB;          // one 128-column strip per workgroup
     double* M = nullptr;
@@ -268,6 +270,120 @@ __global__ void k_exp_check(const double* __restrict__ x, long long n, unsigned 
         bad += (__double_as_longlong(want) != __double_as_longlong(z[e])) ? 1ull : 0ull;
     }
     if (bad) atomicAdd(mismatches, bad);
+}
+
+// How fp64 MFMAs and fp64 vector arithmetic of two waves on one SIMD share the machine: one 512-thread
+// workgroup per compute unit, waves 0-3 issue independent MFMAs (bit 0 of mode), waves 4-7 evaluate the
+// epilogue's batched exp (bit 1).  Every wave stamps its own start / end (100 MHz counter) and its SIMD id.
+__global__ __launch_bounds__(512) void k_mfma_valu_mix(int mode, int iters_m, int iters_e, unsigned long long* stamps,
+                                                       double* sink)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    double keep = 0.0;
+    if ((mode & 32) && wave >= 4) __builtin_amdgcn_s_setprio(3);    // vector waves at raised priority
+    if (wave < 4) {
+        if (mode & 1) {
+            const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+            d4 acc0 = {0, 0, 0, 0}, acc1 = {1, 1, 1, 1}, acc2 = {2, 2, 2, 2}, acc3 = {3, 3, 3, 3};
+            for (int i = 0; i < iters_m; ++i) {
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc3, 0, 0, 0);
+            }
+            d4 s4 = acc0 + acc1 + acc2 + acc3;
+            keep = s4[0] + s4[1] + s4[2] + s4[3];
+        }
+    } else if (mode & 8) {       // fp32 FMA chains: 4 chains x 23 + 8, the instruction count of one exp batch
+        float x[4] = {1e-3f * threadIdx.x, 0.5f, 3.0f, 40.0f}, z[4];
+        for (int i = 0; i < iters_e; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = __builtin_fmaf(x[e], 0.999f, -1e-4f);
+#pragma unroll
+            for (int k = 0; k < 22; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = __builtin_fmaf(z[e], 0.999f, -1e-4f);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = x[e] * 0.9999f - 1e-6f * z[e];
+        }
+        keep = x[0] + x[1] + x[2] + x[3];
+    } else if (mode & 16) {      // 32-bit integer multiply-add chains, same count
+        unsigned int x[4] = {threadIdx.x, 5u, 3u, 40u}, z[4];
+        for (int i = 0; i < iters_e; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = x[e] * 2654435761u + 12345u;
+#pragma unroll
+            for (int k = 0; k < 22; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = (z[e] ^ (z[e] >> 7)) + 0x9e3779b9u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = x[e] + z[e];
+        }
+        keep = (double)(x[0] + x[1] + x[2] + x[3]);
+    } else if (mode & 2) {
+        double x[4] = {-1e-3 * threadIdx.x, -0.5 - 1e-3 * threadIdx.x, -3.0 - 1e-3 * threadIdx.x, -40.0 - 1e-3 * threadIdx.x};
+        double z[4];
+        for (int i = 0; i < iters_e; ++i) {
+            if (mode & 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = __builtin_fma(x[e], 0.999, -1e-4);   // plain fp64 FMAs instead
+#pragma unroll
+                for (int k = 0; k < 22; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z[e] = __builtin_fma(z[e], 0.999, -1e-4);
+            } else {
+                exp_nonpos_batch<4>(x, z);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = x[e] * 0.9999 - 1e-6 * z[e];
+        }
+        keep = x[0] + x[1] + x[2] + x[3];
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    if (keep == 12345.678) sink[0] = keep;
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned int simd = __builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));   // HW_ID.SIMD_ID
+        stamps[((size_t)blockIdx.x * 8 + wave) * 2 + 0] = t1 - t0;
+        stamps[((size_t)blockIdx.x * 8 + wave) * 2 + 1] = simd;
+    }
+}
+
+// out[0] = mean MFMA-wave time (us), out[1] = mean exp-wave time (us), out[2] = fraction of workgroups whose
+// waves w and w + 4 report the same SIMD
+inline int microbench_mix(int mode, int iters_m, int iters_e, double* out, std::string& err)
+{
+    hipDeviceProp_t prop;
+    int dev = 0;
+    MB_TRY(hipGetDevice(&dev));
+    MB_TRY(hipGetDeviceProperties(&prop, dev));
+    const int blocks = prop.multiProcessorCount;
+    unsigned long long* d = nullptr;
+    double* sink = nullptr;
+    MB_TRY(hipMalloc(&d, sizeof(unsigned long long) * blocks * 16));
+    MB_TRY(hipMalloc(&sink, sizeof(double)));
+    std::vector<unsigned long long> h((size_t)blocks * 16);
+    for (int rep = 0; rep < 2; ++rep) {
+        hipLaunchKernelGGL(k_mfma_valu_mix, dim3(blocks), dim3(512), 0, 0, mode, iters_m, iters_e, d, sink);
+        MB_TRY(hipGetLastError());
+        MB_TRY(hipMemcpy(h.data(), d, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+    }
+    double tm = 0, te = 0, same = 0;
+    for (int b = 0; b < blocks; ++b) {
+        bool s = true;
+        for (int w = 0; w < 4; ++w) {
+            tm += (double)h[((size_t)b * 8 + w) * 2] / 100.0;
+            te += (double)h[((size_t)b * 8 + w + 4) * 2] / 100.0;
+            s = s && h[((size_t)b * 8 + w) * 2 + 1] == h[((size_t)b * 8 + w + 4) * 2 + 1];
+        }
+        same += s ? 1.0 : 0.0;
+    }
+    out[0] = tm / (4.0 * blocks);
+    out[1] = te / (4.0 * blocks);
+    out[2] = same / blocks;
+    (void)hipFree(d);
+    (void)hipFree(sink);
+    return 0;
 }
 
 inline int microbench_exp_check(long long n, const double* x, long long* mismatches, std::string& err)

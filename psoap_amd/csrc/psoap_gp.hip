@@ -1347,6 +1347,13 @@ extern "C" int psoap_microbench_exp_check(int device, long long n, const double*
     return microbench_exp_check(n, x, mismatches, g_err);
 }
 
+extern "C" int psoap_microbench_mix(int device, int mode, int iters_mfma, int iters_valu, double* out3)
+{
+    if (!out3 || iters_mfma < 0 || iters_valu < 0) FAIL("psoap_microbench_mix: bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    return microbench_mix(mode, iters_mfma, iters_valu, out3, g_err);
+}
+
 extern "C" int psoap_microbench_hbm(int device, double* write_gbs, double* copy_gbs)
 {
     HIP_TRY(hipSetDevice(device));

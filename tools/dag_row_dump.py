@@ -27,8 +27,6 @@ log[:, 7] = 0.0
 log -= log[:, 0].min()
 dd = np.where((tasks["type"] & 0x0F) == 1)[0]
 dd = dd[np.argsort(raw[dd, 0])]
-clk = np.diff(raw[dd, 7]) / np.diff(raw[dd, 0]) * 100.0     # MHz, between consecutive DIAG task starts (any CU: rough)
-print("shader clock between consecutive DIAG starts [MHz]: median %.0f  min %.0f  max %.0f" % (np.median(clk), clk.min(), clk.max()))
 names = {0: "PART", 1: "DIAG", 2: "OFF "}
 print(f"span {log[:,3].max()/1e3:.2f} ms, tasks {nt}")
 for q in range(q0, q1 + 1):

@@ -47,3 +47,18 @@ for q in (1, 5, 10, 20, 30, 40, 46):
 edges = np.linspace(0, span, 41)
 occ = [(np.minimum(log[:, 3], e1) - np.maximum(log[:, 0], e0)).clip(0).sum() / (e1 - e0) for e0, e1 in zip(edges[:-1], edges[1:])]
 print("tasks in flight per 2.5% time slice:", " ".join(f"{o:.0f}" for o in occ))
+# MFMA work delivered per time slice (a task's update flops spread evenly over its K-loop interval [0]..[5],
+# its strip solve over [2]..[3]): where in the launch the rate falls below the steady state
+upd = 2.0 * 128 * 128 * 128 * (tasks["pb"].astype(float) - tasks["pa"].astype(float))
+have5 = log[:, 5] > 0
+k_end = np.where(have5, log[:, 5], log[:, 1])
+rate = []
+for e0, e1 in zip(edges[:-1], edges[1:]):
+    ov = (np.minimum(k_end, e1) - np.maximum(log[:, 0], e0)).clip(0)
+    dur = (k_end - log[:, 0]).clip(1e-3)
+    f = (upd * ov / dur).sum()
+    ov2 = (np.minimum(log[:, 3], e1) - np.maximum(log[:, 2], e0)).clip(0)
+    dur2 = (log[:, 3] - log[:, 2]).clip(1e-3)
+    f += (np.where(off, 128.0 ** 3 * 1.125, 0.0) * ov2 / dur2).sum()
+    rate.append(f / ((e1 - e0) * 1e-6) / 1e12)
+print("TFLOP/s delivered per 2.5% time slice:", " ".join(f"{r:.0f}" for r in rate))
