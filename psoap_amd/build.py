@@ -8,8 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libpsoap_gp.so")
 SOURCES = ["psoap_gp.hip"]
-HEADERS = ["common.hpp", "gemm_core.hpp", "fill_kernels.hpp", "chol_kernels.hpp", "dag_kernel.hpp", "potrf_blocked.hpp",
-           "predict_kernels.hpp", "calibrate_kernels.hpp", "microbench_kernels.hpp", "orbit_kernels.hpp", os.path.join("..", "..", "include", "psoap_gp.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "psoap_gp.h")]
 
 
 def _stale() -> bool:
