@@ -11,15 +11,28 @@ SOURCES = ["psoap_gp.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "psoap_gp.h")]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
+HASH_PATH = LIB_PATH + ".srchash"
+
+
+def source_hash() -> str:
+    """SHA-256 over the kernel sources the library is built from (names and contents)."""
+    import hashlib
+    h = hashlib.sha256()
     for f in SOURCES + HEADERS:
         p = os.path.join(CSRC, f)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
-            return True
-    return False
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _stale() -> bool:
+    """The library is missing or was not built from the sources as they are now (content hash kept beside it:
+    modification times say nothing after a `git checkout` of a kernel header over an experimental build)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
+        return True
+    with open(HASH_PATH) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -31,7 +44,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
+    digest = source_hash()
     subprocess.check_call(cmd)
+    with open(HASH_PATH, "w") as fh:
+        fh.write(digest + "\n")
     return LIB_PATH
 
 

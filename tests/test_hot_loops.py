@@ -20,3 +20,15 @@ def test_no_spill_reloads_inside_mfma_loop_stages():
     assert len(lines) == 12, res.stdout + res.stderr          # C = 1, 2, 3  x  AUG  x  LAT
     assert all(" 3 K-loop stage blocks, 0 scratch accesses" in ln for ln in lines), res.stdout
     assert res.returncode == 0
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
+def test_library_is_built_from_the_sources_as_they_are():
+    """The in-tree library travels to the GPU box as built here: it must come from the kernel sources in the tree
+    (content hash kept beside it), not from an experiment built over them earlier."""
+    sys.path.insert(0, ROOT)
+    from psoap_amd import build
+    build.build()                      # rebuilds only when the hash differs
+    assert not build._stale()
+    with open(build.HASH_PATH) as fh:
+        assert fh.read().strip() == build.source_hash()
