@@ -361,4 +361,9 @@ def test_non_finite_data_conventions(cov):
     sg = ch.sigma.copy()
     sg[5] = np.nan
     assert cov.lnlike_f_g(None, ch.lwls[0], ch.lwls[1], ch.fl, sg, *syn.GP_BASE[2]) == -np.inf
+    # NaN in a wavelength vector poisons a row and column of the covariance (off the diagonal, whose elements do
+    # not depend on the wavelengths): the factorisation meets a NaN pivot further down -> -inf, never a number
+    wl = ch.lwls[0].copy()
+    wl[11] = np.nan
+    assert cov.lnlike_f_g(None, wl, ch.lwls[1], ch.fl, ch.sigma, *syn.GP_BASE[2]) == -np.inf
     cov.release_handles()
