@@ -356,7 +356,14 @@ __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, in
 // DAG_FUSED, the strip solve of the tile right of the diagonal follows in the same workgroup.
 // A function of its own (not inlined): inside the kernel body a second instance of the factorisation makes
 // hipcc spill in the MFMA loops of every other task (32-walker batch: 39.5 -> 44.2 ms).
-__device__ __attribute__((noinline)) void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double* Rv, MatAcc* acc,
+// (-DPSOAP_DIAG_INLINE compiles it into the LAT kernels instead: 2-5 % slower in the latency regime, and the way
+// out if a build of the out-of-line version ever misbehaves -- see "A known hazard" in DESIGN.md 3.4)
+#ifdef PSOAP_DIAG_INLINE
+#define PSOAP_DIAG_FN __device__ __forceinline__
+#else
+#define PSOAP_DIAG_FN __device__ __attribute__((noinline))
+#endif
+PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double* Rv, MatAcc* acc,
                                                         const double* prev, int Npad, MatFlags* f, DagCtl* ctl, int q,
                                                         int ntasks_row, bool fused, double* zk, double* colsum,
                                                         unsigned long long* tl)
