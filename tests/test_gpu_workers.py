@@ -153,3 +153,19 @@ def test_bench_launches_its_own_ranks_gloo_dry_run():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["parity_checked"] is True and rec["backend"] == "gloo"
     assert rec["value"] > 0 and rec["scaling"] == "weak" and rec["parity"]["golden_cfg4_table"] == [2, 4]
+
+
+# ---------------------------------------------------------------------------------------------- forced split schemes
+@pytest.mark.parametrize("scheme", ["0", "1"])
+def test_parity_under_forced_split_scheme(scheme):
+    """PSOAP_DAG_SCHEME pins the throughput (0) or latency (1) task lists -- and with them the kernel instantiation
+    (k_chol_dag<.., LAT>) -- for every launch, also where the automatic rule would pick the other one (predict under
+    the throughput scheme, 32-walker batches under the latency scheme).  The golden / oracle parity tests must hold
+    for both.  (A child process: the variable is read when the library builds its first plan.)"""
+    env = dict(os.environ, PSOAP_DAG_SCHEME=scheme)
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x",
+                          "-k", "lnlike_golden or edge_sizes or batch_matches or predict_golden or predict_edge or walker_batch",
+                          "-p", "no:cacheprovider"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert " passed" in res.stdout
