@@ -116,13 +116,21 @@ dist.destroy_process_group()
 '''
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (asked from the kernel, as bench.py does for its own ranks)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 @pytest.mark.parametrize("n_chunks", [2, 5])     # one chunk per rank / several per rank (ChunkGroup branch)
 def test_two_ranks_one_gpu_gloo_bit_identical_to_single_process(tmp_path, n_chunks):
     prog = tmp_path / "rank_prog.py"
     prog.write_text(_RANK_CODE % (ROOT, n_chunks))
     outs = {}
     for world in (1, 2):
-        port = 29500 + (os.getpid() + 7 * world + n_chunks) % 2000
+        port = _free_port()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), str(prog)]
         env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
