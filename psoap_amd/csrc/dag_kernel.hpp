@@ -162,22 +162,23 @@ __device__ __forceinline__ void dag_task_done(MatFlags* f, int q, int ntasks_row
 
 // left-looking update over finished block rows [pa, pb) with look-ahead: all but the last panel
 // need rows_done >= pb-1, the last one rows_done >= pb
+template <bool SW = false>
 __device__ __forceinline__ void dag_update(Tile& t, double* Km, int ld, int k0, int j0, int pa, int pb, MatFlags* f,
-                                           DagCtl* ctl, bool wait_next, unsigned long long* tl)
+                                           DagCtl* ctl, bool wait_next, unsigned long long* tl, int wave_s = -1)
 {
     if (pb <= pa) return;
     const bool diag = (k0 == j0);
     if (pb - pa > 1) {
         dag_wait_ge(&f->rows_done, pb - 1, ctl, 1u);
         const size_t r0 = (size_t)pa * NB;
-        tile_gemm_tn(t, Km + r0 * ld + k0, (size_t)ld, Km + r0 * ld + j0, (size_t)ld, (pb - 1 - pa) * NB, diag);
+        tile_gemm_tn<SW>(t, Km + r0 * ld + k0, (size_t)ld, Km + r0 * ld + j0, (size_t)ld, (pb - 1 - pa) * NB, diag, 0x7fffffff, wave_s);
     }
     // the last panel: the whole block row above, or (diagonal tile of the latency scheme) only its tile
     // right of the diagonal -- U(pb-1, pb), all this tile reads of that row
     dag_wait_ge(wait_next ? &f->next_done : &f->rows_done, pb, ctl, 2u);
     if (tl && threadIdx.x == 0) tl[4] = __builtin_amdgcn_s_memrealtime();
     const size_t r1 = (size_t)(pb - 1) * NB;
-    tile_gemm_tn(t, Km + r1 * ld + k0, (size_t)ld, Km + r1 * ld + j0, (size_t)ld, NB, diag);
+    tile_gemm_tn<SW>(t, Km + r1 * ld + k0, (size_t)ld, Km + r1 * ld + j0, (size_t)ld, NB, diag, 0x7fffffff, wave_s);
 }
 
 // The ONE consumer of the accumulators.  Every task ends its update here:
@@ -435,6 +436,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
                 --sel;
             }
     }
+    // throughput kernels (LAT = false): the wave index as a scalar for the staging of every K-loop, and the strip
+    // solve with its row blocks dealt to the waves by work -- together 38.9 -> 38.7 ms per 32-walker step; the
+    // balanced solve alone brings a thread-id reload into the K-loop stages.  The LAT kernels keep the plain forms:
+    // their code is left exactly as it was ("A known hazard").
+    [[maybe_unused]] int wave_s = -1;
+    if constexpr (!LAT) wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     unsigned int dry = 0;                       // bit g: queue g is exhausted (wave-uniform)
     int probe = 0;
     for (;;) {
@@ -498,8 +505,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
             dag_sub_partials(t, prev, 1);
             n_prev = 0;
         }
-        dag_update(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl, (task.type & DAG_WAITNEXT) != 0,
-                   tlog ? tlog + ticket * 8 : nullptr);
+        if constexpr (LAT)
+            dag_update(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl, (task.type & DAG_WAITNEXT) != 0,
+                       tlog ? tlog + ticket * 8 : nullptr);
+        else
+            dag_update<true>(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl, (task.type & DAG_WAITNEXT) != 0,
+                             tlog ? tlog + ticket * 8 : nullptr, wave_s);
         if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 5] = __builtin_amdgcn_s_memrealtime();
         if (!preload && n_wait > 0) dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);
         if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 6] = __builtin_amdgcn_s_memrealtime();
@@ -566,7 +577,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         } else {
             dag_wait_ge(&f->potrf_done, q + 1, ctl, 3u + 16u * (unsigned int)q + 4096u * (unsigned int)b);
             if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 2] = __builtin_amdgcn_s_memrealtime();
-            dag_trsm(t, Km, ld, k0, j0, Wm, Rv, Npad, vec1, vec2);
+            if constexpr (LAT) dag_trsm(t, Km, ld, k0, j0, Wm, Rv, Npad, vec1, vec2);
+            else dag_trsm<true>(t, Km, ld, k0, j0, Wm, Rv, Npad, vec1, vec2);
             dag_drain();
             if (threadIdx.x == 0) {
                 dag_release_fence();

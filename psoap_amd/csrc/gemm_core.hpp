@@ -133,6 +133,15 @@ __device__ __forceinline__ void tile_gemm_tn_reg(Tile& t, const double* __restri
     }
 }
 
+// lane id from the exec mask (all 64 lanes are active wherever this is used): nothing to keep in a register
+// across a K-loop, nothing for the register allocator to spill and reload inside it
+__device__ __forceinline__ int hw_lane()
+{
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+
 // LDS-DMA staging: one global_load_lds_dwordx4 per wave moves one 1 KiB operand row (128 doubles)
 // straight into its padded LDS row -- no staging VGPRs, no ds_write pass.  Wave w fills rows
 // w, w+4, w+8, w+12 of both operand chunks.
@@ -142,6 +151,24 @@ __device__ __forceinline__ void stage_glds(const double* __restrict__ A, size_t 
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = wave + 4 * it;
+        const int off = buf * LDS_BUFFER + row * LDS_LD;
+        __builtin_amdgcn_global_load_lds((glb_ptr)(A + (size_t)(k + row) * lda + 2 * lane), (lds_ptr)(psoap_smem + off), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(B + (size_t)(k + row) * ldb + 2 * lane),
+                                         (lds_ptr)(psoap_smem + off + LDS_OPERAND), 16, 0, 0);
+    }
+}
+
+// the same with the wave index given as a scalar and the lane taken from the exec mask: no thread-id register
+// lives across the K-loop (tile_gemm_tn with wave_s >= 0)
+__device__ __forceinline__ void stage_glds_w(const double* __restrict__ A, size_t lda, const double* __restrict__ B,
+                                             size_t ldb, int k, int buf, int wave)
+{
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int lane = hw_lane();
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int row = wave + 4 * it;
@@ -167,10 +194,30 @@ __device__ __forceinline__ void stage_glds_one(const double* __restrict__ A, siz
     }
 }
 
+// SW (scalar wave): the caller passes the wave index as a scalar it keeps (wave_s) and the staging takes the lane from
+// the exec mask (stage_glds_w) -- no thread-id register lives across the K-loop.  SW = false is the plain form.
+template <bool SW = false>
 __device__ __forceinline__ void tile_gemm_tn(Tile& t, const double* __restrict__ A, size_t lda,
                                                   const double* __restrict__ B, size_t ldb, int K,
-                                                  bool skip_lower_left = false, int k_limit_upper = 0x7fffffff)
+                                                  bool skip_lower_left = false, int k_limit_upper = 0x7fffffff,
+                                                  int wave_s = -1)
 {
+    if constexpr (SW) {
+        const int wave = wave_s;
+        const int wr = wave >> 1, wc = wave & 1;
+        if (K <= 0) return;
+        stage_glds_w(A, lda, B, ldb, 0, 0, wave);
+        __syncthreads();
+        const int nchunk = K / KB;
+        for (int c = 0; c < nchunk; ++c) {
+            const int cur = c & 1;
+            if (c + 1 < nchunk) stage_glds_w(A, lda, B, ldb, (c + 1) * KB, cur ^ 1, wave);
+            const bool idle = (skip_lower_left && wr == 1 && wc == 0) || (wr == 0 && c * KB >= k_limit_upper);
+            if (!idle) tile_mma_chunk(t, cur, wr, wc, 0);
+            __syncthreads();
+        }
+        return;
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar offsets
     const int wr = wave >> 1, wc = wave & 1;
