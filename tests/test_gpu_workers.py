@@ -116,6 +116,19 @@ dist.destroy_process_group()
 '''
 
 
+def _run_twice_if_needed(cmd, **kw):
+    """Run a multi-process launcher; ONE retry when it exits non-zero (a rendezvous on a loopback port can fail for
+    reasons that have nothing to do with the code under test: a port taken between probe and bind, a slow first import
+    on a cold box).  The first failure's output is kept for the assertion message of a second one."""
+    import time
+    res = subprocess.run(cmd, **kw)
+    if res.returncode == 0:
+        return res, ""
+    first = f"[first attempt rc={res.returncode}]\n{res.stdout[-1500:]}\n{res.stderr[-2500:]}\n[second attempt]\n"
+    time.sleep(5.0)
+    return subprocess.run(cmd, **kw), first
+
+
 def _free_port():
     """A TCP port nobody listens on right now (asked from the kernel, as bench.py does for its own ranks)."""
     import socket
@@ -134,8 +147,8 @@ def test_two_ranks_one_gpu_gloo_bit_identical_to_single_process(tmp_path, n_chun
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), str(prog)]
         env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
-        assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+        res, first = _run_twice_if_needed(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert res.returncode == 0, (first, res.stdout[-1500:], res.stderr[-3000:])
         line = [ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1]
         outs[world] = json.loads(line[len("RESULT "):])
     assert outs[1]["tot"] == outs[2]["tot"], (outs[1], outs[2])            # hex strings: bit for bit
@@ -152,10 +165,10 @@ def test_bench_launches_its_own_ranks_gloo_dry_run():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(key, None)
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
-                          "--steps", "2", "--warmup", "1", "--walkers", "8"],
-                         capture_output=True, text=True, timeout=1500, env=env)
-    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    res, first = _run_twice_if_needed([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                                       "--steps", "2", "--warmup", "1", "--walkers", "8"],
+                                      capture_output=True, text=True, timeout=1500, env=env)
+    assert res.returncode == 0, (first, res.stdout[-1500:], res.stderr[-3000:])
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     rec = json.loads(lines[0])
