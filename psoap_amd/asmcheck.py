@@ -1,0 +1,149 @@
+"""Checks on the device assembly hipcc produced for the library -- run by ``psoap_amd.build`` on every build (a library
+that fails them is not installed) and by the CPU tests.
+
+1. ``scan_exec_restore``: vector-register writes under a stale exec mask.  hipcc (ROCm 7.2, AMD clang 22.0.0git) lowers
+   ``if (threadIdx.x == 0) { ... }`` to
+
+        s_and_saveexec_b64 s[A:B], vcc        ; exec := the lanes that take the branch, old exec -> s[A:B]
+        s_cbranch_execz    .LBB_join
+        ...                                   ; then-block, exec partial
+    .LBB_join:
+        s_or_b64 exec, exec, s[A:B]           ; all lanes back
+
+   and everything between the label and the ``s_or_b64`` still runs under the PARTIAL mask (exec == 0 in the waves that
+   skipped).  When its register allocator needs copies or reloads at the top of the join block -- e.g. to park values that
+   live across a function call in callee-saved VGPRs -- it sometimes puts them AHEAD of the ``s_or_b64``: the copy happens
+   only in the lanes of the ``if``, and the copy back after the call hands every other lane garbage.  This was the
+   "build-dependent GPU fault of the latency-scheme kernels" of round 2: in ``k_chol_dag<3, true, true>`` the value was
+   threadIdx.x, parked around the call of ``dag_diag_fast`` behind the one-lane poll of ``dag_wait_ge``; the next LDS-DMA
+   staging took its row index from the garbage (``profiles/r3_lat_fault_rocgdb.txt``; prediction against
+   outcome for 30 builds in ``profiles/r3_lat_variant_matrix.md``).  Whether it happens depends on the allocator's split
+   decisions, i.e. on unrelated code.
+
+2. ``scan_hot_loops``: scratch (spill) accesses inside the 64-MFMA K-loop stages of the ``k_chol_dag`` kernels -- a
+   reload there also waits for the LDS-DMA of the next stage (``s_waitcnt vmcnt(0)`` counts both) and serialises it with
+   the MFMAs.  A performance defect, not a correctness one: reported, not fatal for a build.
+"""
+from __future__ import annotations
+
+import re
+
+_VWRITE = re.compile(r"^(v_|scratch_load|global_load|flat_load|ds_read|ds_bpermute|ds_permute|buffer_load|"
+                     r"global_atomic|flat_atomic|image_)")
+# no vector destination, or (v_writelane: an SGPR spill into ONE lane) a write that ignores the exec mask
+_NO_VDST = re.compile(r"^(v_cmp|v_cmpx|v_readlane|v_readfirstlane|v_writelane|global_load_lds|v_nop)")
+_EXEC_RESTORE = re.compile(r"^s_or_b64\s+exec,\s*(exec,\s*s\[\d+:\d+\]|s\[\d+:\d+\],\s*exec)")
+_BRANCH_Z = re.compile(r"^s_cbranch_execz\s+(\S+)")
+_LABEL = re.compile(r"^([A-Za-z_.$][\w.$]*):")
+
+
+def short(mangled: str | None) -> str:
+    """k_chol_dag<3,true,true> for _ZN5psoap10k_chol_dagILi3ELb1ELb1EEE...; other names are returned as they are"""
+    m = re.match(r"_ZN5psoap10k_chol_dagILi(\d)ELb([01])ELb([01])EEE", mangled or "")
+    if m:
+        return "k_chol_dag<%s,%s,%s>" % (m.group(1), "true" if m.group(2) == "1" else "false",
+                                         "true" if m.group(3) == "1" else "false")
+    return mangled or "?"
+
+
+def scan_exec_restore(text: str):
+    """-> [(function, join block, line of its label, [(line, instruction), ...]), ...]: the join blocks -- targets of an
+    ``s_cbranch_execz``, or the fall-through exit of a loop closed by ``s_cbranch_execnz`` -- in which an instruction that
+    writes a vector register sits ahead of the ``s_or_b64 exec, exec, s[..]`` that re-enables the lanes."""
+    code = [ln.split(";")[0].strip() for ln in text.split("\n")]
+    fn_of = []
+    cur = None
+    for s in code:
+        m = _LABEL.match(s)
+        if m and not m.group(1).startswith(".L"):
+            cur = m.group(1)
+        fn_of.append(cur)
+    skip_targets = set()
+    for n, s in enumerate(code):
+        b = _BRANCH_Z.match(s)
+        if b:
+            skip_targets.add((fn_of[n], b.group(1)))
+    hits = []
+    for n, s in enumerate(code):
+        m = _LABEL.match(s)
+        if m and (fn_of[n], m.group(1)) in skip_targets:
+            name = m.group(1)
+        elif s.startswith("s_cbranch_execnz") and not (n + 1 < len(code) and _LABEL.match(code[n + 1])):
+            name = "(exit of the loop that ends at line %d)" % (n + 1)   # falls through with the lanes that left
+        else:
+            continue
+        pend = []
+        for k in range(n + 1, min(n + 400, len(code))):
+            s2 = code[k]
+            if not s2 or s2.startswith("."):
+                continue
+            if _LABEL.match(s2):
+                break
+            op = s2.split()[0]
+            if _EXEC_RESTORE.match(s2):
+                if pend:
+                    hits.append((fn_of[n], name, n + 1, pend))
+                break
+            if op.startswith(("s_cbranch", "s_branch", "s_setpc", "s_swappc", "s_endpgm", "s_barrier")):
+                break
+            dst = s2.split(None, 1)[1].split(",")[0] if " " in s2 else ""
+            if re.search(r"\bexec", dst) or "saveexec" in op:
+                break           # exec rewritten some other way (else-mask, loop mask): not this pattern
+            if _VWRITE.match(op) and not _NO_VDST.match(op):
+                pend.append((k + 1, s2))
+    return hits
+
+
+def scan_hot_loops(text: str):
+    """-> {kernel: (number of 64-MFMA K-loop stage blocks, scratch accesses inside them)} for every k_chol_dag"""
+    lines = text.split("\n")
+    out = {}
+    i = 0
+    while i < len(lines):
+        m = re.match(r"^(_ZN5psoap10k_chol_dag\w+):", lines[i])
+        if not m:
+            i += 1
+            continue
+        name = m.group(1)
+        j = i
+        while j < len(lines) and not lines[j].strip().startswith(".Lfunc_end"):
+            j += 1
+        cur, blocks = "entry", {}
+        for ln in lines[i:j]:
+            mm = re.match(r"^(\.LBB\d+_\d+):", ln)
+            if mm:
+                cur = mm.group(1)
+            b = blocks.setdefault(cur, [0, 0])
+            if "v_mfma" in ln:
+                b[0] += 1
+            if "scratch_load" in ln or "scratch_store" in ln:
+                b[1] += 1
+        hot = [v for v in blocks.values() if v[0] == 64]     # one K-loop stage = 64 MFMAs per wave
+        out[short(name)] = (len(hot), sum(v[1] for v in hot))
+        i = j
+    return out
+
+
+def kernel_resources(text: str):
+    """-> {kernel: {"vgpr_spill_count": n, "private_segment_fixed_size": n, ...}} from the code-object metadata"""
+    out = {}
+    cur = {}
+    for ln in text.split("\n"):
+        m = re.match(r"\s+-?\s*\.(\w+):\s+(.*)$", ln)
+        if not m:
+            continue
+        key, val = m.group(1), m.group(2).strip()
+        if key in ("vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size", "vgpr_count", "agpr_count",
+                   "group_segment_fixed_size"):
+            cur[key] = int(val)
+        elif key == "symbol":
+            sym = val.strip("'\"")[:-3] if val.strip("'\"").endswith(".kd") else val.strip("'\"")
+            cur["symbol"] = sym
+        elif key == "name" and "symbol" not in cur:
+            cur["name"] = val.strip("'\"")
+        if key == "wavefront_size":      # last field of a kernel record in hipcc's emission order
+            name = cur.get("symbol") or cur.get("name")
+            if name:
+                out[short(name)] = {k: v for k, v in cur.items() if k not in ("symbol", "name")}
+            cur = {}
+    return out

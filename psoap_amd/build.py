@@ -1,22 +1,46 @@
-"""Build the gfx950 shared library in-tree with hipcc (cross-compiles without a GPU)."""
+"""Build the gfx950 shared library in-tree with hipcc (cross-compiles without a GPU), and refuse to install a binary
+whose device assembly shows the compiler defect described in ``psoap_amd/asmcheck.py`` (vector-register writes ahead
+of an exec restore: the GPU fault of round 2's latency-scheme kernels).
+
+    python -m psoap_amd.build            # rebuild if the sources / compiler / flags changed
+    python -m psoap_amd.build --force
+"""
 from __future__ import annotations
 
+import hashlib
+import json
 import os
+import shutil
 import subprocess
+import tempfile
+
+from . import asmcheck
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libpsoap_gp.so")
 SOURCES = ["psoap_gp.hip"]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "psoap_gp.h")]
+HASH_PATH = LIB_PATH + ".srchash"                      # JSON: what the library beside it was built from
+ASM_PATH = os.path.join(CSRC, "libpsoap_gp.device.s")   # device assembly of that build (kept for the CPU tests)
+
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+# Flag sets tried in order until the device assembly is clean.  The second compiles the diagonal routine of the
+# latency-scheme kernels into the kernels (no function call, so no values parked around one): 2-5 % slower single
+# evaluations, and the form that never showed the defect.
+FLAG_LADDER = [[], ["-DPSOAP_DIAG_INLINE"]]
 
 
-HASH_PATH = LIB_PATH + ".srchash"
+class BuildError(RuntimeError):
+    pass
+
+
+def hipcc() -> str:
+    return os.environ.get("HIPCC", "hipcc")
 
 
 def source_hash() -> str:
     """SHA-256 over the kernel sources the library is built from (names and contents)."""
-    import hashlib
     h = hashlib.sha256()
     for f in SOURCES + HEADERS:
         p = os.path.join(CSRC, f)
@@ -26,30 +50,107 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
+def compiler_id() -> str:
+    """First line of `hipcc --version` that names the compiler build (the defect is a property of the compiler)."""
+    try:
+        out = subprocess.run([hipcc(), "--version"], capture_output=True, text=True).stdout
+    except OSError:
+        return "unknown"
+    for ln in out.splitlines():
+        if "clang version" in ln:
+            return ln.strip()
+    return out.strip().splitlines()[0] if out.strip() else "unknown"
+
+
+def extra_flags() -> list[str]:
+    """PSOAP_BUILD_FLAGS: extra hipcc flags (experiments, tools/lat_variants.py)"""
+    return os.environ.get("PSOAP_BUILD_FLAGS", "").split()
+
+
+def build_record() -> dict | None:
+    if not os.path.exists(HASH_PATH):
+        return None
+    try:
+        with open(HASH_PATH) as fh:
+            return json.load(fh)
+    except ValueError:
+        return None            # a hash file of the round-2 format
+
+
 def _stale() -> bool:
-    """The library is missing or was not built from the sources as they are now (content hash kept beside it:
-    modification times say nothing after a `git checkout` of a kernel header over an experimental build)."""
-    if not os.path.exists(LIB_PATH) or not os.path.exists(HASH_PATH):
+    """The library is missing or was not built from the sources as they are now, by this compiler, with these extra
+    flags (content hash kept beside it: modification times say nothing after a `git checkout` of a kernel header over
+    an experimental build)."""
+    rec = build_record()
+    if not os.path.exists(LIB_PATH) or rec is None:
         return True
-    with open(HASH_PATH) as fh:
-        return fh.read().strip() != source_hash()
+    return (rec.get("sources") != source_hash() or rec.get("compiler") != compiler_id() or
+            rec.get("extra_flags") != extra_flags())
+
+
+def compile_once(flags: list[str], out_dir: str) -> tuple[str, str]:
+    """hipcc -> (shared library, device assembly) in out_dir"""
+    so = os.path.join(out_dir, "libpsoap_gp.so")
+    cmd = [hipcc(), *BASE_FLAGS, "-save-temps=obj", *flags, *[os.path.join(CSRC, s) for s in SOURCES], "-o", so]
+    subprocess.check_call(cmd, cwd=out_dir)
+    asm = [f for f in os.listdir(out_dir) if f.endswith(".s") and "amdgcn" in f]
+    if len(asm) != 1:
+        raise BuildError(f"expected one device assembly file from -save-temps, found {asm}")
+    return so, os.path.join(out_dir, asm[0])
+
+
+def compile_checked(extra: list[str], out_dir: str, verbose: bool = False) -> tuple[str, str, dict]:
+    """Walk FLAG_LADDER until the device assembly is clean -> (library, assembly, build record), all inside out_dir."""
+    tried = []
+    for k, rung in enumerate(FLAG_LADDER):
+        flags = extra + rung
+        sub = os.path.join(out_dir, f"rung{k}")
+        os.makedirs(sub, exist_ok=True)
+        if verbose:
+            print(f"{hipcc()} {' '.join(BASE_FLAGS + flags)} psoap_gp.hip")
+        so, asm_path = compile_once(flags, sub)
+        with open(asm_path) as fh:
+            hits = asmcheck.scan_exec_restore(fh.read())
+        tried.append((flags, hits))
+        if hits:
+            if verbose:
+                for fn, label, line, pend in hits:
+                    print(f"  exec-restore defect in {asmcheck.short(fn)}, block {label}: {len(pend)} vector writes")
+            continue
+        rec = {"sources": source_hash(), "compiler": compiler_id(), "extra_flags": extra, "flags": BASE_FLAGS + flags,
+               "fallback_rung": k,
+               "rejected": [{"flags": f, "kernels": sorted({asmcheck.short(h[0]) for h in hs})} for f, hs in tried[:-1]]}
+        return so, asm_path, rec
+    raise BuildError("every flag set produced device code with vector-register writes ahead of an exec restore "
+                     "(psoap_amd/asmcheck.py): " +
+                     "; ".join(f"{' '.join(f) or '(default)'} -> {sorted({asmcheck.short(h[0]) for h in hs})}"
+                               for f, hs in tried))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> psoap_amd/csrc/libpsoap_gp.so"""
+    """hipcc --offload-arch=gfx950 -> psoap_amd/csrc/libpsoap_gp.so, after the assembly checks"""
     if not force and not _stale():
         return LIB_PATH
-    hipcc = os.environ.get("HIPCC", "hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    digest = source_hash()
-    subprocess.check_call(cmd)
-    with open(HASH_PATH, "w") as fh:
-        fh.write(digest + "\n")
+    with tempfile.TemporaryDirectory(prefix="psoap_build_") as tmp:
+        so, asm_path, rec = compile_checked(extra_flags(), tmp, verbose)
+        shutil.copy(so, LIB_PATH)
+        shutil.copy(asm_path, ASM_PATH)
+        with open(HASH_PATH, "w") as fh:
+            json.dump(rec, fh, indent=1)
+            fh.write("\n")
     return LIB_PATH
 
 
+def device_asm() -> str:
+    """Device assembly of the installed library (rebuilding first if it is stale)."""
+    build()
+    if not os.path.exists(ASM_PATH):
+        build(force=True)
+    with open(ASM_PATH) as fh:
+        return fh.read()
+
+
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))
+    print(json.dumps(build_record(), indent=1))

@@ -307,14 +307,16 @@ __device__ __forceinline__ void dag_sub_partials(Tile& t, const double* __restri
 
 // strip solve + right-hand-side update for tile (k0, j0); the updated tile is already in memory
 // BAL: the row blocks are dealt to the waves by work (tile_gemm_tn_lower_balanced and its accumulator map)
-template <bool BAL = false>
+// VP: how the two 128-entry LDS vectors are addressed (double* inside a kernel, lds_double* inside dag_diag_fast);
+// SM: how the tile engine's LDS array is reached (gemm_core.hpp)
+template <bool BAL = false, class VP = double*, class SM = SmemKernel>
 __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, int j0, const double* Wm, double* Rv,
-                                         int Npad, double* zk, double* colsum)
+                                         int Npad, VP zk, VP colsum, SM sm = SM())
 {
     const int tid = threadIdx.x;
     if (tid < NB) zk[tid] = Rv[k0 + tid];
     t.zero();
-    if (BAL) tile_gemm_tn_lower_balanced(t, Wm, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld);
+    if (BAL) tile_gemm_tn_lower_balanced(t, Wm, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld, sm);
     else tile_gemm_tn_lower(t, Wm, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld);
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -352,23 +354,52 @@ __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, in
 }
 
 // Diagonal tile of the latency scheme, the row-to-row critical path: the running sum of its PART chain,
-// the last K = 128 symmetric update and the in-block Cholesky all happen in the registers of potrf_blocked
-// (FUSED) -- no tile engine, no store / drain / reload of the tile in between -- and, when the task is
+// the last K = 128 symmetric update and the in-block Cholesky all happen in registers (potrf_spine_fused)
+// -- no tile engine, no store / drain / reload of the tile in between -- and, when the task is
 // DAG_FUSED, the strip solve of the tile right of the diagonal follows in the same workgroup.
 // A function of its own (not inlined): inside the kernel body a second instance of the factorisation makes
 // hipcc spill in the MFMA loops of every other task (32-walker batch: 39.5 -> 44.2 ms).
-// (-DPSOAP_DIAG_INLINE compiles it into the LAT kernels instead: 2-5 % slower in the latency regime, and the way
-// out if a build of the out-of-line version ever misbehaves -- see "A known hazard" in DESIGN.md 3.4)
+// Being a non-kernel function it names NO __shared__ variable: the kernel hands it the base of the dynamic LDS
+// array (`smem`) and its two LDS vectors as address_space(3) pointers, and the spine's progress flag lives in
+// that array (pb::OFF_FLAG) -- see gemm_core.hpp (SmemArg) and DESIGN.md 3.4 for why.
+//   -DPSOAP_DIAG_INLINE     compiles the routine into the LAT kernels instead (2-5 % slower in the latency regime);
+//   -DPSOAP_DIAG_LDS_TABLE  the round-2 form: the routine names psoap_smem itself, i.e. reaches LDS through the
+//                           compiler's per-kernel table (tools/lat_variants.py builds both for comparison).
+// The LDS address of a __shared__ object as a value the optimiser cannot see through: with the address visible at
+// the (only) call sites, interprocedural constant propagation puts the object's name right back into the callee.
+__device__ __forceinline__ lds_double* dag_opaque_lds(double* shared_obj)
+{
+    unsigned int a = (unsigned int)(uintptr_t)(lds_double*)shared_obj;
+    asm volatile("" : "+s"(a));
+    return (lds_double*)(uintptr_t)a;
+}
 #ifdef PSOAP_DIAG_INLINE
 #define PSOAP_DIAG_FN __device__ __forceinline__
 #else
 #define PSOAP_DIAG_FN __device__ __attribute__((noinline))
 #endif
+#if defined(PSOAP_DIAG_INLINE) || defined(PSOAP_DIAG_LDS_TABLE)
+#define PSOAP_DIAG_SMEM(smem) SmemKernel()
+#else
+#define PSOAP_DIAG_SMEM(smem) SmemArg{smem}
+#endif
 PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double* Rv, MatAcc* acc,
                                                         const double* prev, int Npad, MatFlags* f, DagCtl* ctl, int q,
-                                                        int ntasks_row, bool fused, double* zk, double* colsum,
+                                                        int ntasks_row, bool fused, int* chain_ctr, int chain_len,
+                                                        lds_double* smem, lds_double* zk, lds_double* colsum,
                                                         unsigned long long* tl)
 {
+#ifdef PSOAP_PAD_CALLEE
+    // variant matrix (tools/lat_variants.py): code placement only
+    asm volatile(".rept %0\n\ts_nop 0\n\t.endr" ::"n"(PSOAP_PAD_CALLEE));
+#endif
+    const auto sm = PSOAP_DIAG_SMEM(smem);
+    // the wait for the tile's PART chain (it ran ahead: normally no wait at all) happens in here, not in front of the
+    // call: a one-lane poll right before a call is where hipcc's register allocator parked the values that live
+    // across the call UNDER THE POLL'S EXEC MASK (tools/check_exec_restore.py)
+#ifndef PSOAP_WAIT_BEFORE_CALL
+    dag_wait_ge(chain_ctr, chain_len, ctl, 4u);
+#endif
     __builtin_amdgcn_s_setprio(3);
     auto wait_dep = [f, ctl, q, tl]() {
         dag_wait_ge(&f->next_done, q, ctl, 2u);
@@ -377,7 +408,7 @@ PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double*
 #ifdef PSOAP_NO_SPINE
     potrf_blocked<0, true>(Km, ld, k0, Wm, Rv, acc, prev, Km + (size_t)(k0 - NB) * ld + k0, wait_dep, tl);
 #else
-    potrf_spine_fused(Km, ld, k0, Wm, Rv, acc, prev, Km + (size_t)(k0 - NB) * ld + k0, wait_dep, tl);
+    potrf_spine_fused(Km, ld, k0, Wm, Rv, acc, prev, Km + (size_t)(k0 - NB) * ld + k0, wait_dep, tl, sm);
 #endif
     dag_drain();
     if (tl && threadIdx.x == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
@@ -388,7 +419,7 @@ PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double*
     if (fused) {
         Tile t;
         dag_wait_ge(&f->off1_ready, q + 1, ctl, 5u);
-        dag_trsm<true>(t, Km, ld, k0, k0 + NB, Wm, Rv, Npad, zk, colsum);
+        dag_trsm<true>(t, Km, ld, k0, k0 + NB, Wm, Rv, Npad, zk, colsum, sm);
         dag_drain();
         if (threadIdx.x == 0) {
             dag_release_fence();
@@ -436,12 +467,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
                 --sel;
             }
     }
-    // throughput kernels (LAT = false): the wave index as a scalar for the staging of every K-loop, and the strip
-    // solve with its row blocks dealt to the waves by work -- together 38.9 -> 38.7 ms per 32-walker step; the
-    // balanced solve alone brings a thread-id reload into the K-loop stages.  The LAT kernels keep the plain forms:
-    // their code is left exactly as it was ("A known hazard").
-    [[maybe_unused]] int wave_s = -1;
-    if constexpr (!LAT) wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // the wave index as a scalar for the staging of every K-loop (the lane id comes from the exec mask: no thread-id
+    // register lives across a K-loop), and the strip solve with its row blocks dealt to the waves by work -- together
+    // 38.9 -> 38.7 ms per 32-walker step; the balanced solve alone brings a thread-id reload into the K-loop stages.
+    // Both kinds of kernel use these forms (round 2 kept the LAT kernels on the plain ones only because any change to
+    // them could bring the fault of DESIGN.md 3.4 back; measured in round 3: within 1 % either way, profiles/r3_ab_forms.txt)
+#ifdef PSOAP_PAD_KERNEL
+    asm volatile(".rept %0\n\ts_nop 0\n\t.endr" ::"n"(PSOAP_PAD_KERNEL));
+#endif
+    const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     unsigned int dry = 0;                       // bit g: queue g is exhausted (wave-uniform)
     int probe = 0;
     for (;;) {
@@ -493,9 +527,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         const double* prev = wspace + (size_t)(is_part ? task.slot ^ 1u : task.slot) * SLOT;
         const bool preload = !is_part && chain && n_wait > 0;
         if (LAT && preload && ttype == DAG_DIAG && (task.type & DAG_WAITNEXT) && task.pb - task.pa == 1) {
-            dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);         // the chain ran ahead: normally no wait
+#ifdef PSOAP_WAIT_BEFORE_CALL
+            dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);   // round-2 placement, kept for tools/lat_variants.py only
+#endif
             dag_diag_fast(Km, ld, k0, Wm, Rv, mat.acc, prev, Npad, f, ctl, q, ntasks_row, (task.type & DAG_FUSED) != 0,
-                          vec1, vec2, tlog ? tlog + ticket * 8 : nullptr);
+                          &arrive[task.ctr], n_wait, dag_opaque_lds(psoap_smem), dag_opaque_lds(vec1), dag_opaque_lds(vec2),
+                          tlog ? tlog + ticket * 8 : nullptr);
             continue;
         }
         t.zero();
@@ -505,12 +542,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
             dag_sub_partials(t, prev, 1);
             n_prev = 0;
         }
+#ifdef PSOAP_LAT_PLAIN
+        // round-2 forms of the LAT kernels (thread-id staging, plain strip solve): tools/lat_variants.py only -- with
+        // -DPSOAP_WAIT_BEFORE_CALL this is the code shape on which hipcc produces the defect of DESIGN.md 3.4
         if constexpr (LAT)
             dag_update(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl, (task.type & DAG_WAITNEXT) != 0,
                        tlog ? tlog + ticket * 8 : nullptr);
         else
-            dag_update<true>(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl, (task.type & DAG_WAITNEXT) != 0,
-                             tlog ? tlog + ticket * 8 : nullptr, wave_s);
+#endif
+        dag_update<true>(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl, (task.type & DAG_WAITNEXT) != 0,
+                         tlog ? tlog + ticket * 8 : nullptr, wave_s);
         if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 5] = __builtin_amdgcn_s_memrealtime();
         if (!preload && n_wait > 0) dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);
         if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 6] = __builtin_amdgcn_s_memrealtime();
@@ -577,8 +618,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         } else {
             dag_wait_ge(&f->potrf_done, q + 1, ctl, 3u + 16u * (unsigned int)q + 4096u * (unsigned int)b);
             if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+#ifdef PSOAP_LAT_PLAIN
             if constexpr (LAT) dag_trsm(t, Km, ld, k0, j0, Wm, Rv, Npad, vec1, vec2);
-            else dag_trsm<true>(t, Km, ld, k0, j0, Wm, Rv, Npad, vec1, vec2);
+            else
+#endif
+            dag_trsm<true>(t, Km, ld, k0, j0, Wm, Rv, Npad, vec1, vec2);
             dag_drain();
             if (threadIdx.x == 0) {
                 dag_release_fence();

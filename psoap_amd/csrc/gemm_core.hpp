@@ -54,6 +54,25 @@ __device__ __forceinline__ void stage_load(Staging& s, const double* __restrict_
 // time degrades to flat_* accesses whose waits also drain the global prefetch).
 extern __shared__ __attribute__((aligned(16))) double psoap_smem[];
 
+// How a routine reaches that array.  Kernels (and everything inlined into them) name it directly (SmemKernel): its
+// offset inside the workgroup's LDS is a link-time constant that folds into the DS instructions.  A routine that is
+// compiled as a real function (dag_diag_fast, dag_kernel.hpp) must NOT name it -- nor any other __shared__ variable:
+// a non-kernel function has no LDS layout of its own, and hipcc then lowers every such reference to a run-time
+// lookup in a per-kernel table (llvm.amdgcn.dynlds.offset.table, indexed by a hidden kernel-id SGPR).  Such a
+// routine is handed the base as an explicit address_space(3) pointer by the kernel that calls it (SmemArg) and
+// reaches LDS through nothing else.
+typedef __attribute__((address_space(3))) double lds_double;
+typedef __attribute__((address_space(3))) int lds_int;
+struct SmemKernel {
+    __device__ __forceinline__ double& operator[](int i) const { return psoap_smem[i]; }
+    __device__ __forceinline__ lds_double* ptr(int i) const { return (lds_double*)(psoap_smem + i); }
+};
+struct SmemArg {
+    lds_double* base;
+    __device__ __forceinline__ lds_double& operator[](int i) const { return base[i]; }
+    __device__ __forceinline__ lds_double* ptr(int i) const { return base + i; }
+};
+
 constexpr int LDS_OPERAND = KB * LDS_LD;     // doubles per staged operand chunk
 constexpr int LDS_BUFFER = 2 * LDS_OPERAND;  // A chunk followed by B chunk
 
@@ -145,8 +164,9 @@ __device__ __forceinline__ int hw_lane()
 // LDS-DMA staging: one global_load_lds_dwordx4 per wave moves one 1 KiB operand row (128 doubles)
 // straight into its padded LDS row -- no staging VGPRs, no ds_write pass.  Wave w fills rows
 // w, w+4, w+8, w+12 of both operand chunks.
+template <class SM = SmemKernel>
 __device__ __forceinline__ void stage_glds(const double* __restrict__ A, size_t lda, const double* __restrict__ B,
-                                           size_t ldb, int k, int buf, int tid)
+                                           size_t ldb, int k, int buf, int tid, SM sm = SM())
 {
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -155,9 +175,9 @@ __device__ __forceinline__ void stage_glds(const double* __restrict__ A, size_t 
     for (int it = 0; it < 4; ++it) {
         const int row = wave + 4 * it;
         const int off = buf * LDS_BUFFER + row * LDS_LD;
-        __builtin_amdgcn_global_load_lds((glb_ptr)(A + (size_t)(k + row) * lda + 2 * lane), (lds_ptr)(psoap_smem + off), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(A + (size_t)(k + row) * lda + 2 * lane), (lds_ptr)sm.ptr(off), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_ptr)(B + (size_t)(k + row) * ldb + 2 * lane),
-                                         (lds_ptr)(psoap_smem + off + LDS_OPERAND), 16, 0, 0);
+                                         (lds_ptr)sm.ptr(off + LDS_OPERAND), 16, 0, 0);
     }
 }
 
@@ -181,7 +201,9 @@ __device__ __forceinline__ void stage_glds_w(const double* __restrict__ A, size_
 
 // one operand only (the symmetric update of a diagonal tile multiplies a strip with itself): the A half
 // of LDS buffer `buf`
-__device__ __forceinline__ void stage_glds_one(const double* __restrict__ A, size_t lda, int k, int buf, int tid)
+template <class SM = SmemKernel>
+__device__ __forceinline__ void stage_glds_one(const double* __restrict__ A, size_t lda, int k, int buf, int tid,
+                                               SM sm = SM())
 {
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -190,7 +212,7 @@ __device__ __forceinline__ void stage_glds_one(const double* __restrict__ A, siz
     for (int it = 0; it < 4; ++it) {
         const int row = wave + 4 * it;
         __builtin_amdgcn_global_load_lds((glb_ptr)(A + (size_t)(k + row) * lda + 2 * lane),
-                                         (lds_ptr)(psoap_smem + buf * LDS_BUFFER + row * LDS_LD), 16, 0, 0);
+                                         (lds_ptr)sm.ptr(buf * LDS_BUFFER + row * LDS_LD), 16, 0, 0);
     }
 }
 
@@ -266,18 +288,19 @@ __device__ __forceinline__ void tile_gemm_tn_lower(Tile& t, const double* __rest
 // different loop shape upset hipcc's register allocation of the c = 2 kernels (measured +3 %).
 __device__ __forceinline__ constexpr int lower_rowblock(int wr, int m) { return wr == 0 ? (m < 2 ? m : m + 4) : m + 2; }
 
+template <class SM = SmemKernel>
 __device__ __forceinline__ void tile_gemm_tn_lower_balanced(Tile& t, const double* __restrict__ A, size_t lda,
-                                                            const double* __restrict__ B, size_t ldb)
+                                                            const double* __restrict__ B, size_t ldb, SM sm = SM())
 {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    stage_glds(A, lda, B, ldb, 0, 0, tid);
+    stage_glds(A, lda, B, ldb, 0, 0, tid, sm);
     __syncthreads();
     constexpr int nchunk = NB / KB;
     for (int c = 0; c < nchunk; ++c) {
         const int cur = c & 1;
-        if (c + 1 < nchunk) stage_glds(A, lda, B, ldb, (c + 1) * KB, cur ^ 1, tid);
+        if (c + 1 < nchunk) stage_glds(A, lda, B, ldb, (c + 1) * KB, cur ^ 1, tid, sm);
         const int fr = tid & 15, fk = (tid & 63) >> 4;
         const int baseA = cur * LDS_BUFFER + fk * LDS_LD + fr;
         const int baseB = cur * LDS_BUFFER + LDS_OPERAND + fk * LDS_LD + wc * 64 + fr;
@@ -290,9 +313,9 @@ __device__ __forceinline__ void tile_gemm_tn_lower_balanced(Tile& t, const doubl
             for (int ks = 0; ks < KB / 4; ++ks) {
                 double a[4], b[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) a[m] = psoap_smem[baseA + ks * 4 * LDS_LD + 16 * lower_rowblock(wr, m)];
+                for (int m = 0; m < 4; ++m) a[m] = sm[baseA + ks * 4 * LDS_LD + 16 * lower_rowblock(wr, m)];
 #pragma unroll
-                for (int n = 0; n < 4; ++n) b[n] = psoap_smem[baseB + ks * 4 * LDS_LD + n * 16];
+                for (int n = 0; n < 4; ++n) b[n] = sm[baseB + ks * 4 * LDS_LD + n * 16];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     if (!live[m]) continue;

@@ -40,20 +40,23 @@ constexpr int OFF_DUMMY = 18 * BLK;          // target of predicated-off publica
 constexpr int OFF_TR = 19 * BLK;             // 4 x (16 x 17) transpose scratch, one per wave
 constexpr int OFF_LINE = OFF_TR + 4 * 272;   // 32: broadcast line of the in-wave factorisation
 constexpr int OFF_RED = OFF_LINE + 32;       // 8: reductions
+constexpr int OFF_FLAG = OFF_RED + 6;         // one int: progress flag of potrf_spine (diagonal blocks announced)
 constexpr int LDS_DOUBLES = OFF_RED + 8;
 static_assert((size_t)LDS_DOUBLES * sizeof(double) <= GEMM_LDS_BYTES, "blocked potrf scratch must fit the GEMM LDS");
 
-__device__ __forceinline__ d4 load_blk(int off, int lane)
+template <class SM = SmemKernel>
+__device__ __forceinline__ d4 load_blk(int off, int lane, SM sm = SM())
 {
     d4 v;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = psoap_smem[off + r * 64 + lane];
+    for (int r = 0; r < 4; ++r) v[r] = sm[off + r * 64 + lane];
     return v;
 }
-__device__ __forceinline__ void store_blk(int off, int lane, const d4& v)
+template <class SM = SmemKernel>
+__device__ __forceinline__ void store_blk(int off, int lane, const d4& v, SM sm = SM())
 {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) psoap_smem[off + r * 64 + lane] = v[r];
+    for (int r = 0; r < 4; ++r) sm[off + r * 64 + lane] = v[r];
 }
 // c += x^T y, all three blocks in the accumulator layout
 __device__ __forceinline__ d4 mma16(const d4& x, const d4& y, d4 c)
@@ -87,10 +90,11 @@ __device__ __forceinline__ double rsqrt_chain(double d)
 // In-wave Cholesky of a 16 x 16 block t (accumulator layout) with the row eliminations mirrored on an
 // identity block: on return t = U (strictly lower entries zeroed) and w = U^-T.  Branch-free per
 // pivot: all six LDS reads are issued right behind the line write and overlap the rsqrt chain.
-__device__ __forceinline__ void chol16(d4& t, d4& w, int lane, int& bad)
+template <class SM = SmemKernel>
+__device__ __forceinline__ void chol16(d4& t, d4& w, int lane, int& bad, SM sm = SM())
 {
     const int q = lane >> 4, c = lane & 15;
-    double* line = psoap_smem + OFF_LINE;
+    auto* line = sm.ptr(OFF_LINE);
     d4 e;
 #pragma unroll
     for (int r = 0; r < 4; ++r) e[r] = (q + 4 * r == c) ? 1.0 : 0.0;
@@ -137,10 +141,11 @@ __device__ __forceinline__ void chol16(d4& t, d4& w, int lane, int& bad)
 
 // one finished block of W into the k-major operand Wt[e][i] = W[i][e] of the strip solve, transposed
 // through a per-wave LDS scratch so the global stores are 128-byte row segments
-__device__ __forceinline__ void emit_w(const d4& w, int I, int J, int lane, int wave, double* Wm)
+template <class SM = SmemKernel>
+__device__ __forceinline__ void emit_w(const d4& w, int I, int J, int lane, int wave, double* Wm, SM sm = SM())
 {
     const int q = lane >> 4, c = lane & 15;
-    double* tr = psoap_smem + OFF_TR + wave * 272;
+    auto* tr = sm.ptr(OFF_TR + wave * 272);
 #pragma unroll
     for (int r = 0; r < 4; ++r) tr[(q + 4 * r) * 17 + c] = w[r];
     __builtin_amdgcn_wave_barrier();

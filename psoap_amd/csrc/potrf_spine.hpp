@@ -22,6 +22,15 @@
 #pragma once
 #include "potrf_blocked.hpp"
 
+// variant matrix (tools/lat_variants.py): the routine's global accesses as global_* instead of flat_* instructions
+#ifdef PSOAP_SPINE_GLOBAL
+#define PSOAP_SG(p) ((__attribute__((address_space(1))) double*)(p))
+#define PSOAP_SGC(p) ((const __attribute__((address_space(1))) double*)(p))
+#else
+#define PSOAP_SG(p) (p)
+#define PSOAP_SGC(p) (p)
+#endif
+
 namespace psoap {
 namespace ps {
 
@@ -29,7 +38,10 @@ using pb::BLK;
 constexpr int OFF_ROW = 0;              // 2 x 9 blocks: row bb of U (J > bb) / W (J <= bb) / z (slot 8), buffer bb & 1
 constexpr int OFF_V = 18 * BLK;         // W_bb^T
 static_assert(OFF_V + BLK <= pb::OFF_TR, "spine layout must stay below the transpose scratch it shares with potrf_blocked");
-__shared__ int s_flag;                  // diagonal blocks factored and announced so far
+// progress flag (diagonal blocks factored and announced so far): one int in the routine's LDS scratch, pb::OFF_FLAG --
+// not a __shared__ variable of its own, so that the routine can run inside a non-kernel function (gemm_core.hpp, SmemArg)
+template <class SM>
+__device__ __forceinline__ lds_int* flag_ptr(SM sm) { return (lds_int*)sm.ptr(pb::OFF_FLAG); }
 
 __device__ __forceinline__ int row_off(int bb) { return OFF_ROW + (bb & 1) * 9 * BLK; }
 // Wave W (1..3) owns block (I, J), J != I, when (I + J) mod 3 == W - 1; column 8 is the right-hand side
@@ -39,10 +51,11 @@ __device__ __forceinline__ int row_off(int bb) { return OFF_ROW + (bb & 1) * 9 *
 constexpr int col0(int W, int I) { return ((W - 1 - I) % 3 + 3) % 3; }
 constexpr bool owned(int W, int I, int s) { return col0(W, I) + 3 * s <= 8 && col0(W, I) + 3 * s != I; }
 
-__device__ __forceinline__ void wait_flag(int target, int lane)
+template <class SM>
+__device__ __forceinline__ void wait_flag(int target, int lane, SM sm)
 {
     if (lane == 0)
-        while (__hip_atomic_load(&s_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
+        while (__hip_atomic_load(flag_ptr(sm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
 }
@@ -55,10 +68,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ d4 neg(const d4& v) { return d4{-v[0], -v[1], -v[2], -v[3]}; }
 
 // ---- the three worker waves ------------------------------------------------------------------------------
-template <int W, class WaitFn>
+template <int W, class WaitFn, class SM>
 __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, double* Rv,
                                        const double* __restrict__ part, const double* __restrict__ strip,
-                                       WaitFn& wait_dep)
+                                       WaitFn& wait_dep, SM sm)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = lane >> 4, c = lane & 15;
@@ -72,7 +85,7 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
                 d4 v = {0.0, 0.0, 0.0, 0.0};
                 if (J > I && J < 8) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = part[(size_t)(16 * I + q + 4 * r) * NB + 16 * J + c];
+                    for (int r = 0; r < 4; ++r) v[r] = PSOAP_SGC(part)[(size_t)(16 * I + q + 4 * r) * NB + 16 * J + c];
                 }
                 blk[3 * I + s] = v;
             }
@@ -84,30 +97,30 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
         for (int s = 0; s < 3; ++s)
             if (owned(W, I, s) && col0(W, I) + 3 * s == 8) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) blk[3 * I + s][r] = (c == 0) ? Rv[k0 + 16 * I + q + 4 * r] : 0.0;
+                for (int r = 0; r < 4; ++r) blk[3 * I + s][r] = (c == 0) ? PSOAP_SG(Rv)[k0 + 16 * I + q + 4 * r] : 0.0;
             }
     // ---- T -= strip^T strip on the upper blocks this wave owns (K = 128 in eight LDS stages)
-    stage_glds_one(strip, (size_t)ld, 0, 0, tid);
+    stage_glds_one(strip, (size_t)ld, 0, 0, tid, sm);
     __syncthreads();
     {
         const int fr = lane & 15, fk = lane >> 4;
 #pragma unroll 1
         for (int ch = 0; ch < NB / KB; ++ch) {
             const int cur = ch & 1;
-            if (ch + 1 < NB / KB) stage_glds_one(strip, (size_t)ld, (ch + 1) * KB, cur ^ 1, tid);
+            if (ch + 1 < NB / KB) stage_glds_one(strip, (size_t)ld, (ch + 1) * KB, cur ^ 1, tid, sm);
             const int base = cur * LDS_BUFFER + fk * LDS_LD + fr;
 #pragma unroll
             for (int I = 0; I < 7; ++I) {
                 double x[4];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) x[ks] = -psoap_smem[base + ks * 4 * LDS_LD + 16 * I];
+                for (int ks = 0; ks < 4; ++ks) x[ks] = -sm[base + ks * 4 * LDS_LD + 16 * I];
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
                     if (owned(W, I, s) && col0(W, I) + 3 * s > I && col0(W, I) + 3 * s < 8) {
                         const int J = col0(W, I) + 3 * s;
                         double y[4];
 #pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) y[ks] = psoap_smem[base + ks * 4 * LDS_LD + 16 * J];
+                        for (int ks = 0; ks < 4; ++ks) y[ks] = sm[base + ks * 4 * LDS_LD + 16 * J];
 #pragma unroll
                         for (int ks = 0; ks < 4; ++ks)
                             blk[3 * I + s] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ks], y[ks], blk[3 * I + s], 0, 0, 0);
@@ -122,10 +135,10 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
     for (int bb = 0; bb < 8; ++bb) {
         // ---- B: block row bb (behind the flag of diagonal block bb).  The (up to three) products of the row
         // are issued k-step by k-step so that consecutive MFMAs are independent.
-        wait_flag(bb + 1, lane);
+        wait_flag(bb + 1, lane, sm);
         {
             const int base = row_off(bb);
-            const d4 x = pb::load_blk(OFF_V, lane);
+            const d4 x = pb::load_blk(OFF_V, lane, sm);
 #pragma unroll
             for (int I = 0; I < 8; ++I) {
                 if (I != bb) continue;
@@ -142,7 +155,7 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
                 for (int s = 0; s < 3; ++s)
                     if (owned(W, I, s)) {
                         const int J = col0(W, I) + 3 * s;
-                        pb::store_blk(base + J * BLK, lane, res[s]);
+                        pb::store_blk(base + J * BLK, lane, res[s], sm);
                         blk[3 * I + s] = res[s];
                     }
             }
@@ -154,12 +167,12 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
 #pragma unroll
             for (int I = 1; I < 8; ++I) {
                 if (I <= bb) continue;
-                const d4 xs = neg(pb::load_blk(base + I * BLK, lane));           // -U_bI
+                const d4 xs = neg(pb::load_blk(base + I * BLK, lane, sm));           // -U_bI
                 // upper blocks, A_IJ -= U_bI^T U_bJ: always active here (J > I > bb), interleaved like phase B
                 d4 y[3];
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
-                    if (owned(W, I, s) && col0(W, I) + 3 * s > I) y[s] = pb::load_blk(base + (col0(W, I) + 3 * s) * BLK, lane);
+                    if (owned(W, I, s) && col0(W, I) + 3 * s > I) y[s] = pb::load_blk(base + (col0(W, I) + 3 * s) * BLK, lane, sm);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -171,7 +184,7 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
                 for (int s = 0; s < 3; ++s)
                     if (owned(W, I, s) && col0(W, I) + 3 * s < I) {
                         const int J = col0(W, I) + 3 * s;
-                        if (J <= bb) blk[3 * I + s] = pb::mma16(xs, pb::load_blk(base + J * BLK, lane), blk[3 * I + s]);
+                        if (J <= bb) blk[3 * I + s] = pb::mma16(xs, pb::load_blk(base + J * BLK, lane, sm), blk[3 * I + s]);
                     }
             }
         }
@@ -186,17 +199,17 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
                 if (owned(W, I, s)) {
                     const int J = col0(W, I) + 3 * s;
                     if (J < I) {
-                        pb::emit_w(blk[3 * I + s], I, J, lane, W, Wm);
+                        pb::emit_w(blk[3 * I + s], I, J, lane, W, Wm, sm);
                     } else if (J < 8) {
                         const d4& v = blk[3 * I + s];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) Km[(size_t)(k0 + 16 * I + q + 4 * r) * ld + k0 + 16 * J + c] = v[r];
+                        for (int r = 0; r < 4; ++r) PSOAP_SG(Km)[(size_t)(k0 + 16 * I + q + 4 * r) * ld + k0 + 16 * J + c] = v[r];
                     }
                 }
         }
 #endif
         // W_bb itself (parked by the spine in the row buffer) goes out to memory from here, off the spine's chain
-        if (W == 1) pb::emit_w(pb::load_blk(row_off(bb) + bb * BLK, lane), bb, bb, lane, 1, Wm);
+        if (W == 1) pb::emit_w(pb::load_blk(row_off(bb) + bb * BLK, lane, sm), bb, bb, lane, 1, Wm, sm);
     }
     double zz = 0.0;
 #ifndef PSOAP_SPINE_INLOOP_OUT
@@ -208,18 +221,18 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
             if (owned(W, I, s)) {
                 const int J = col0(W, I) + 3 * s;
                 if (J < I) {
-                    pb::emit_w(blk[3 * I + s], I, J, lane, W, Wm);
+                    pb::emit_w(blk[3 * I + s], I, J, lane, W, Wm, sm);
                 } else if (J < 8) {
                     const d4& v = blk[3 * I + s];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Km[(size_t)(k0 + 16 * I + q + 4 * r) * ld + k0 + 16 * J + c] = v[r];
+                    for (int r = 0; r < 4; ++r) PSOAP_SG(Km)[(size_t)(k0 + 16 * I + q + 4 * r) * ld + k0 + 16 * J + c] = v[r];
                 } else {
                     // z (column 0 of the rhs block) back into r, and its share of z^T z
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (c == 0) {
                             const double z = blk[3 * I + s][r];
-                            Rv[k0 + 16 * I + q + 4 * r] = z;
+                            PSOAP_SG(Rv)[k0 + 16 * I + q + 4 * r] = z;
                             zz = fma(z, z, zz);
                         }
                 }
@@ -227,36 +240,37 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
 #endif
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) zz += __shfl_xor(zz, off, 64);
-    if (lane == 0) psoap_smem[pb::OFF_RED + W] = zz;
+    if (lane == 0) sm[pb::OFF_RED + W] = zz;
 }
 
 // ---- wave 0 --------------------------------------------------------------------------------------------
 // factor diagonal block bb (d), park W_bb and W_bb^T (the X operand of W_bb Y) in LDS, announce
-__device__ __forceinline__ void spine_factor(d4& d, int bb, int lane, int& bad, double& logsum)
+template <class SM>
+__device__ __forceinline__ void spine_factor(d4& d, int bb, int lane, int& bad, double& logsum, SM sm)
 {
     const int q = lane >> 4, c = lane & 15;
     d4 wdiag;
-    pb::chol16(d, wdiag, lane, bad);
-    pb::store_blk(row_off(bb) + bb * BLK, lane, wdiag);
+    pb::chol16(d, wdiag, lane, bad, sm);
+    pb::store_blk(row_off(bb) + bb * BLK, lane, wdiag, sm);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) psoap_smem[pb::OFF_TR + (q + 4 * r) * 17 + c] = wdiag[r];
+    for (int r = 0; r < 4; ++r) sm[pb::OFF_TR + (q + 4 * r) * 17 + c] = wdiag[r];
     __builtin_amdgcn_wave_barrier();
     d4 v;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = psoap_smem[pb::OFF_TR + c * 17 + q + 4 * r];
+    for (int r = 0; r < 4; ++r) v[r] = sm[pb::OFF_TR + c * 17 + q + 4 * r];
     __builtin_amdgcn_wave_barrier();
-    pb::store_blk(OFF_V, lane, v);
+    pb::store_blk(OFF_V, lane, v, sm);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(&s_flag, bb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_store(flag_ptr(sm), bb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     double dg = 1.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) dg = (c == q + 4 * r) ? d[r] : dg;
     logsum += log(dg);
 }
 
-template <class WaitFn>
+template <class WaitFn, class SM>
 __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* __restrict__ part,
-                                      const double* __restrict__ strip, WaitFn& wait_dep, unsigned long long* tl)
+                                      const double* __restrict__ strip, WaitFn& wait_dep, unsigned long long* tl, SM sm)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = lane >> 4, c = lane & 15;
@@ -264,22 +278,22 @@ __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* 
 #pragma unroll
     for (int I = 0; I < 8; ++I)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d[I][r] = part[(size_t)(16 * I + q + 4 * r) * NB + 16 * I + c];
+        for (int r = 0; r < 4; ++r) d[I][r] = PSOAP_SGC(part)[(size_t)(16 * I + q + 4 * r) * NB + 16 * I + c];
     wait_dep();
-    stage_glds_one(strip, (size_t)ld, 0, 0, tid);
+    stage_glds_one(strip, (size_t)ld, 0, 0, tid, sm);
     __syncthreads();
     {
         const int fr = lane & 15, fk = lane >> 4;
 #pragma unroll 1
         for (int ch = 0; ch < NB / KB; ++ch) {
             const int cur = ch & 1;
-            if (ch + 1 < NB / KB) stage_glds_one(strip, (size_t)ld, (ch + 1) * KB, cur ^ 1, tid);
+            if (ch + 1 < NB / KB) stage_glds_one(strip, (size_t)ld, (ch + 1) * KB, cur ^ 1, tid, sm);
             const int base = cur * LDS_BUFFER + fk * LDS_LD + fr;
 #pragma unroll
             for (int I = 0; I < 8; ++I) {
                 double x[4];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) x[ks] = psoap_smem[base + ks * 4 * LDS_LD + 16 * I];
+                for (int ks = 0; ks < 4; ++ks) x[ks] = sm[base + ks * 4 * LDS_LD + 16 * I];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) d[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[ks], x[ks], d[I], 0, 0, 0);
             }
@@ -287,11 +301,11 @@ __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* 
         }
     }
     if (tl && lane == 0) tl[5] = __builtin_amdgcn_s_memrealtime();
-    if (lane == 0) __hip_atomic_store(&s_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_store(flag_ptr(sm), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();   // [S0]
     int bad = 0;
     double logsum = 0.0;
-    spine_factor(d[0], 0, lane, bad, logsum);
+    spine_factor(d[0], 0, lane, bad, logsum, sm);
 #pragma unroll 1
     for (int bb = 0; bb < 7; ++bb) {
         lds_barrier();     // [S1 + bb] block row bb is published
@@ -300,15 +314,15 @@ __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* 
 #pragma unroll
         for (int I = 1; I < 8; ++I)
             if (I == bb + 1) {
-                const d4 xi = pb::load_blk(base + I * BLK, lane);
+                const d4 xi = pb::load_blk(base + I * BLK, lane, sm);
                 d[I] = pb::mma16(neg(xi), xi, d[I]);
-                spine_factor(d[I], I, lane, bad, logsum);
+                spine_factor(d[I], I, lane, bad, logsum, sm);
             }
         // ---- deferred: the other diagonal blocks, while the workers finish row bb+1
 #pragma unroll
         for (int I = 2; I < 8; ++I)
             if (I > bb + 1) {
-                const d4 xi = pb::load_blk(base + I * BLK, lane);
+                const d4 xi = pb::load_blk(base + I * BLK, lane, sm);
                 d[I] = pb::mma16(neg(xi), xi, d[I]);
             }
     }
@@ -319,12 +333,12 @@ __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* 
 #pragma unroll
     for (int I = 0; I < 8; ++I)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Km[(size_t)(k0 + 16 * I + q + 4 * r) * ld + k0 + 16 * I + c] = d[I][r];
+        for (int r = 0; r < 4; ++r) PSOAP_SG(Km)[(size_t)(k0 + 16 * I + q + 4 * r) * ld + k0 + 16 * I + c] = d[I][r];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) logsum += __shfl_xor(logsum, off, 64);
     if (lane == 0) {
-        psoap_smem[pb::OFF_RED + 0] = logsum;
-        psoap_smem[pb::OFF_RED + 4] = bad ? 1.0 : 0.0;
+        sm[pb::OFF_RED + 0] = logsum;
+        sm[pb::OFF_RED + 4] = bad ? 1.0 : 0.0;
     }
 }
 
@@ -333,26 +347,26 @@ __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* 
 // All 256 threads call this.  part: the tile's running sum (row-major 128 x 128, read before wait_dep());
 // strip: the tile above the diagonal (k-major, leading dimension ld), final once wait_dep() returns.
 // wait_dep() is called by every thread exactly once (it may contain a workgroup barrier).
-template <class WaitFn>
+template <class WaitFn, class SM = SmemKernel>
 __device__ __forceinline__ void potrf_spine_fused(double* Km, int ld, int k0, double* Wm, double* Rv, MatAcc* acc,
                                                   const double* __restrict__ part, const double* __restrict__ strip,
-                                                  WaitFn wait_dep, unsigned long long* tl = nullptr)
+                                                  WaitFn wait_dep, unsigned long long* tl = nullptr, SM sm = SM())
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) ps::spine(Km, ld, k0, part, strip, wait_dep, tl);
-    else if (wave == 1) ps::worker<1>(Km, ld, k0, Wm, Rv, part, strip, wait_dep);
-    else if (wave == 2) ps::worker<2>(Km, ld, k0, Wm, Rv, part, strip, wait_dep);
-    else ps::worker<3>(Km, ld, k0, Wm, Rv, part, strip, wait_dep);
+    if (wave == 0) ps::spine(Km, ld, k0, part, strip, wait_dep, tl, sm);
+    else if (wave == 1) ps::worker<1>(Km, ld, k0, Wm, Rv, part, strip, wait_dep, sm);
+    else if (wave == 2) ps::worker<2>(Km, ld, k0, Wm, Rv, part, strip, wait_dep, sm);
+    else ps::worker<3>(Km, ld, k0, Wm, Rv, part, strip, wait_dep, sm);
     __syncthreads();   // all outputs issued, the reductions are in LDS
     if (threadIdx.x == 0) {
-        const double l = psoap_smem[pb::OFF_RED + 0];
-        const double qd = (psoap_smem[pb::OFF_RED + 1] + psoap_smem[pb::OFF_RED + 2]) + psoap_smem[pb::OFF_RED + 3];
+        const double l = sm[pb::OFF_RED + 0];
+        const double qd = (sm[pb::OFF_RED + 1] + sm[pb::OFF_RED + 2]) + sm[pb::OFF_RED + 3];
         // MatAcc is handed from block row to block row across workgroups: agent-scope accesses only
         const double l0 = __hip_atomic_load(&acc->logdet_half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const double q0 = __hip_atomic_load(&acc->quad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&acc->logdet_half, l0 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&acc->quad, q0 + qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (psoap_smem[pb::OFF_RED + 4] != 0.0) __hip_atomic_store(&acc->info, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sm[pb::OFF_RED + 4] != 0.0) __hip_atomic_store(&acc->info, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // (the LDS scratch goes back to the tile engine behind the caller's next barrier: dag_drain)
     if (tl && threadIdx.x == 0) tl[1] = __builtin_amdgcn_s_memrealtime();

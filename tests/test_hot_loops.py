@@ -1,34 +1,96 @@
-"""CPU (needs hipcc, no GPU): the 64-MFMA K-loop stages of every k_chol_dag instantiation must not touch scratch.
-A spill reload inside a stage costs more than its latency -- the s_waitcnt vmcnt(0) behind it also waits for the
-LDS-DMA of the next stage and serialises it with the MFMAs (measured: 39.5 -> 44.2 ms per 32-walker step) -- and
-hipcc introduces one whenever the kernel around the loops grows in the wrong place."""
+"""CPU (needs hipcc, no GPU): checks on the device assembly of the library as built from the sources in the tree
+(psoap_amd/asmcheck.py).
+
+* The 64-MFMA K-loop stages of every k_chol_dag instantiation must not touch scratch.  A spill reload inside a stage
+  costs more than its latency -- the s_waitcnt vmcnt(0) behind it also waits for the LDS-DMA of the next stage and
+  serialises it with the MFMAs (measured: 39.5 -> 44.2 ms per 32-walker step) -- and hipcc introduces one whenever the
+  kernel around the loops grows in the wrong place.
+* No vector-register write ahead of an exec restore: the hipcc defect that made round 2's latency-scheme kernels fault
+  on the GPU in about half of all builds.  psoap_amd.build refuses to install such a binary; here the
+  scanner itself is pinned on the join block of the faulting build (profiles/r3_lat_fault_joinblock.s)."""
+import json
 import os
 import shutil
-import subprocess
 import sys
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+needs_hipcc = pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
 
 
-@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
-def test_no_spill_reloads_inside_mfma_loop_stages():
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_hot_loops.py")], capture_output=True, text=True,
-                         timeout=900)
-    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("k_chol_dag<")]
-    assert len(lines) == 12, res.stdout + res.stderr          # C = 1, 2, 3  x  AUG  x  LAT
-    assert all(" 3 K-loop stage blocks, 0 scratch accesses" in ln for ln in lines), res.stdout
-    assert res.returncode == 0
-
-
-@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
+@needs_hipcc
 def test_library_is_built_from_the_sources_as_they_are():
-    """The in-tree library travels to the GPU box as built here: it must come from the kernel sources in the tree
-    (content hash kept beside it), not from an experiment built over them earlier."""
-    sys.path.insert(0, ROOT)
+    """The in-tree library travels to the GPU box as built here: it must come from the kernel sources in the tree, the
+    compiler on this machine and no experimental flags (record kept beside it), not from an experiment built earlier."""
     from psoap_amd import build
-    build.build()                      # rebuilds only when the hash differs
+    build.build()                      # rebuilds only when the record differs
     assert not build._stale()
-    with open(build.HASH_PATH) as fh:
-        assert fh.read().strip() == build.source_hash()
+    rec = build.build_record()
+    assert rec["sources"] == build.source_hash() and rec["compiler"] == build.compiler_id()
+    assert rec["extra_flags"] == []
+    # the shipped sources must not need the inline fallback with the compiler of this image
+    assert rec["fallback_rung"] == 0 and rec["rejected"] == [], rec
+
+
+@needs_hipcc
+def test_no_spill_reloads_inside_mfma_loop_stages():
+    from psoap_amd import asmcheck, build
+    res = asmcheck.scan_hot_loops(build.device_asm())
+    assert len(res) == 12, res                              # C = 1, 2, 3  x  AUG  x  LAT
+    assert all(v == (3, 0) for v in res.values()), res      # 3 K-loop stage blocks each, no scratch access in them
+
+
+@needs_hipcc
+def test_no_vector_write_ahead_of_an_exec_restore():
+    from psoap_amd import asmcheck, build
+    hits = asmcheck.scan_exec_restore(build.device_asm())
+    assert hits == [], [(asmcheck.short(h[0]), h[1], h[3][:3]) for h in hits]
+
+
+@needs_hipcc
+def test_build_falls_back_when_the_default_flags_show_the_defect(tmp_path):
+    """With the round-2 code shape (the PART-chain wait as a one-lane poll right in front of the call of dag_diag_fast,
+    round-2 staging forms in the LAT kernels) this compiler produces the defect in k_chol_dag<3, true, true>: the build
+    must reject that binary and take the next rung of the ladder (diagonal routine inlined), which is clean."""
+    from psoap_amd import build
+    shape = ["-DPSOAP_WAIT_BEFORE_CALL", "-DPSOAP_LAT_PLAIN"]
+    so, asm, rec = build.compile_checked(shape, str(tmp_path))
+    assert rec["fallback_rung"] == 1
+    assert rec["rejected"] == [{"flags": shape, "kernels": ["k_chol_dag<3,true,true>"]}]
+    assert os.path.exists(so) and "-DPSOAP_DIAG_INLINE" in rec["flags"]
+
+
+def test_exec_restore_scanner_flags_the_faulting_join_block():
+    """The join block of k_chol_dag<3, true, true> from the build that faulted on the GPU (rocgdb session in
+    profiles/r3_lat_fault_rocgdb.txt): ten vector writes -- `v_mov_b32 v172, v244` among them -- ahead of the
+    `s_or_b64 exec, exec, s[0:1]`."""
+    from psoap_amd import asmcheck
+    with open(os.path.join(ROOT, "profiles", "r3_lat_fault_joinblock.s")) as fh:
+        block = fh.read()
+    text = "_ZN5psoap10k_chol_dagILi3ELb1ELb1EEEv:\n\ts_cbranch_execz .LBB46_1318\n" + block
+    hits = asmcheck.scan_exec_restore(text)
+    assert len(hits) == 1 and hits[0][1] == ".LBB46_1318"
+    assert any("v_mov_b32_e32 v172, v244" in ins for _, ins in hits[0][3])
+    assert asmcheck.short(hits[0][0]) == "k_chol_dag<3,true,true>"
+    # the same block with the restore in front is clean; v_writelane (an SGPR spill into one lane) ignores exec
+    lines = block.split("\n")
+    k = next(i for i, ln in enumerate(lines) if "s_or_b64 exec, exec" in ln)
+    first = next(i for i, ln in enumerate(lines) if ln.startswith(".LBB46_1318:"))
+    fixed = lines[:first + 1] + [lines[k], "\tv_writelane_b32 v254, s72, 57"] + lines[first + 1:k] + lines[k + 1:]
+    assert asmcheck.scan_exec_restore("f:\n\ts_cbranch_execz .LBB46_1318\n" + "\n".join(fixed)) == []
+    bad = lines[:first + 1] + ["\tv_writelane_b32 v254, s72, 57", lines[k]]
+    assert asmcheck.scan_exec_restore("f:\n\ts_cbranch_execz .LBB46_1318\n" + "\n".join(bad)) == []
+
+
+def test_variant_matrix_predictions_match_the_gpu_outcomes():
+    """profiles/r3_lat_variant_matrix.jsonl: 30 builds, detector verdict (CPU) against what the GPU did."""
+    rows = [json.loads(ln) for ln in open(os.path.join(ROOT, "profiles", "r3_lat_variant_matrix.jsonl"))]
+    assert len(rows) >= 30
+    for d in rows:
+        predicted_fault = bool(d["detector_hits"])
+        faulted = d["check_rc"] != 0 or d["repro_rc"] != 0
+        assert predicted_fault == faulted, d["name"]
+    assert sum(bool(d["detector_hits"]) for d in rows) >= 7

@@ -1,40 +1,23 @@
-"""Compile the HIP library to assembly and report, for every k_chol_dag instantiation, the scratch (spill)
-loads / stores inside the basic blocks that hold the 64-MFMA K-loop stages.  A reload there costs more than
-its latency: the s_waitcnt vmcnt(0) behind it also waits for the LDS-DMA of the next stage.
+"""For every k_chol_dag instantiation of the installed library: the scratch (spill) accesses inside the basic blocks
+that hold the 64-MFMA K-loop stages.  A reload there costs more than its latency: the s_waitcnt vmcnt(0) behind it
+also waits for the LDS-DMA of the next stage.  (psoap_amd/asmcheck.py: scan_hot_loops)
 
     python tools/check_hot_loops.py        # exit code 1 if any K-loop stage block touches scratch
 """
-import os, re, subprocess, sys, tempfile
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out = os.path.join(tempfile.mkdtemp(prefix="psoap_asm_"), "psoap.s")
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                       os.path.join(ROOT, "psoap_amd", "csrc", "psoap_gp.hip"), "-o", out], stderr=subprocess.DEVNULL)
-lines = open(out).read().split("\n")
+sys.path.insert(0, ROOT)
+from psoap_amd import asmcheck, build  # noqa: E402
+
+text = build.device_asm()
+res = asmcheck.scan_hot_loops(text)
+meta = asmcheck.kernel_resources(text)
 bad = 0
-i = 0
-while i < len(lines):
-    m = re.match(r"^(_ZN5psoap10k_chol_dag\w+):", lines[i])
-    if not m:
-        i += 1
-        continue
-    name = m.group(1)
-    j = i
-    while not lines[j].strip().startswith(".Lfunc_end"):
-        j += 1
-    cur, blocks = "entry", {}
-    for l in lines[i:j]:
-        mm = re.match(r"^(\.LBB\d+_\d+):", l)
-        if mm:
-            cur = mm.group(1)
-        b = blocks.setdefault(cur, [0, 0, 0])
-        if "v_mfma" in l: b[0] += 1
-        if "scratch_load" in l: b[1] += 1
-        if "scratch_store" in l: b[2] += 1
-    hot = {k: v for k, v in blocks.items() if v[0] == 64}     # one K-loop stage = 64 MFMAs per wave
-    spills = sum(v[1] + v[2] for v in hot.values())
-    tmpl = re.search(r"k_chol_dagILi(\d)ELb(\d)ELb(\d)E", name)
-    print(f"k_chol_dag<C={tmpl.group(1)}, AUG={tmpl.group(2)}, LAT={tmpl.group(3)}>: {len(hot)} K-loop stage blocks, "
-          f"{spills} scratch accesses inside them")
+for name, (n_hot, spills) in sorted(res.items()):
+    r = meta.get(name, {})
+    print(f"{name}: {n_hot} K-loop stage blocks, {spills} scratch accesses inside them; "
+          f"vgpr_spill_count {r.get('vgpr_spill_count')}, private segment {r.get('private_segment_fixed_size')} B")
     bad += spills
-    i = j
 sys.exit(1 if bad else 0)
