@@ -191,6 +191,9 @@ typedef struct psoap_group psoap_group;
 int psoap_group_create(psoap_group **out, psoap_chunk *const *handles, int n);
 int psoap_group_eval(psoap_group *g);
 int psoap_group_destroy(psoap_group *g);
+/* How often the group rebuilt its task list (batch sizes changed) and refreshed its matrix
+ * records (a member moved to its other proposal slot: device-to-device, no host sync). */
+int psoap_group_stats(psoap_group *g, long long *plan_builds, long long *record_refreshes);
 
 /* ---- measurement ----------------------------------------------------------------
  * With profiling on, every kernel launch of psoap_batch_eval is bracketed by

@@ -80,6 +80,7 @@ SIGNATURES = {
     "psoap_group_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int]),
     "psoap_group_eval": (ctypes.c_int, [_vp]),
     "psoap_group_destroy": (ctypes.c_int, [_vp]),
+    "psoap_group_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
     "psoap_chunk_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "psoap_chunk_get_timings": (ctypes.c_int, [_vp, ctypes.POINTER(Timings)]),
     "psoap_chunk_set_stream_groups": (ctypes.c_int, [_vp, ctypes.c_int]),

@@ -181,6 +181,12 @@ class ChunkGroup:
     def eval(self):
         check(self._L.psoap_group_eval(self._g), "psoap_group_eval")
 
+    def stats(self) -> dict:
+        """task-list builds (batch sizes changed) and record refreshes (a member changed its proposal slot) so far"""
+        a, b = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        check(self._L.psoap_group_stats(self._g, ctypes.byref(a), ctypes.byref(b)), "psoap_group_stats")
+        return {"plan_builds": a.value, "record_refreshes": b.value}
+
     def close(self):
         if getattr(self, "_g", None) is not None and self._g:
             self._L.psoap_group_destroy(self._g)

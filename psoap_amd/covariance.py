@@ -81,12 +81,55 @@ def last_predict_timings() -> dict:
     return t.as_dict()
 
 
+_NONFINITE = "array must not contain infs or NaNs"      # the message of scipy's check_finite
+
+
+def _matrix_is_finite(lw: np.ndarray, sigma, gp) -> bool:
+    """Would the reference's filled matrix (fill_V11_* + sigma**2 on the diagonal) be free of NaN / inf?  Entries are
+    ``amp**2 * exp(-0.5 c**2 r**2 / l**2)`` with ``r`` a wavelength difference: a NaN wavelength, amplitude or length scale,
+    an infinite amplitude, two infinite wavelengths of one sign in one component (inf - inf), or a non-finite
+    uncertainty poison it; ONE infinite wavelength (exp(-inf) = 0) or an infinite length scale (exp(-0) = 1) do not."""
+    if not np.all(np.isfinite(np.asarray(sigma, dtype=np.float64))):
+        return False
+    amps, ls = gp[0::2], gp[1::2]
+    if not all(np.isfinite(a) for a in amps) or any(np.isnan(l) for l in ls):
+        return False
+    if np.any(np.isnan(lw)):
+        return False
+    if lw.shape[1] > 1 and (np.any(np.sum(np.isposinf(lw), axis=1) > 1) or np.any(np.sum(np.isneginf(lw), axis=1) > 1)):
+        return False
+    return True
+
+
 def _lnlike(lwls, fl, sigma, gp, mu_GP):
+    """Error behaviour of the reference on degenerate input, pinned by running the reference itself
+    (tests/golden/make_golden_conventions.py -> golden_conventions_v1.json):
+
+    * a negative hyper-parameter -> ``-inf`` before anything else (covariance.py:317,339,362);
+    * a length scale of exactly 0 -> ``ZeroDivisionError`` (``-0.5 * c_kms2 / (l*l)`` in the Cython fills,
+      matrix_functions.pyx:29,111-112,165-167: Cython checks float division);
+    * anything non-finite in the covariance matrix -> ``ValueError``: ``lnlike_f`` / ``lnlike_f_g_h`` factor with
+      scipy's ``check_finite`` (:325,370); ``lnlike_f_g`` factors unchecked (:348), but OpenBLAS's ``dpotrf`` does not
+      stop at a NaN pivot, the factor comes back non-finite and the ``cho_solve`` that follows refuses it (:354);
+    * a finite matrix that is not positive definite -> ``-inf`` (``LinAlgError`` caught, :327,350,372);
+    * non-finite ``fl`` / ``mu_GP`` (the right-hand side of ``cho_solve``, :331,354,376) -> ``ValueError``.
+
+    Behind the C ABI the device keeps its own convention (NaN in, NaN or -inf out, never an exception): include/psoap_gp.h."""
     gp = [float(g) for g in gp]
-    if any(g < 0.0 for g in gp):          # covariance.py:317-318,339-340,362-363
+    if any(g < 0.0 for g in gp):
         return -np.inf
+    if any(l == 0.0 for l in gp[1::2]):
+        raise ZeroDivisionError("float division")
+    lw = np.stack([as_f64(w) for w in lwls])
+    if not _matrix_is_finite(lw, sigma, gp):
+        raise ValueError(_NONFINITE)
     h = _chunk_for(fl, sigma)
-    return np.float64(h.lnlike(np.stack([as_f64(w) for w in lwls]), gp, mu_GP))
+    out = np.float64(h.lnlike(lw, gp, mu_GP))
+    if np.isneginf(out):
+        return out
+    if not (np.all(np.isfinite(np.asarray(fl, dtype=np.float64))) and np.isfinite(mu_GP)):
+        raise ValueError(_NONFINITE)
+    return out
 
 
 def lnlike_f(V11, wl_f, fl, sigma, amp_f, l_f, mu_GP=1.):

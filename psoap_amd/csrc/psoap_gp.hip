@@ -124,6 +124,8 @@ struct psoap_chunk {
     int pend = -1;           // uploaded, not yet evaluated
     hipStream_t copy = nullptr;
     hipEvent_t evStaging = nullptr;   // copy stream: the pinned staging buffers have been consumed
+    hipEvent_t evLast = nullptr;      // the most recent evaluation of this handle, whichever slot and stream it used:
+    bool last_recorded = false;       // the shared workspaces (K, r, Wt, acc, out) are free once it has completed
     // execution
     int groups = 2;
     hipStream_t streams[MAX_GROUPS] = {};
@@ -243,6 +245,7 @@ static int chunk_alloc(psoap_chunk* h, const double* fl, const double* sigma)
     HIP_TRY(hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking));
     for (int g = 0; g < MAX_GROUPS; ++g) HIP_TRY(hipEventCreateWithFlags(&h->evDone[g], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->evStaging, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->evLast, hipEventDisableTiming));
     HIP_TRY(hipMemcpy(h->dFl, fl, sizeof(double) * N, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->dSigma, sigma, sizeof(double) * N, hipMemcpyHostToDevice));
     return 0;
@@ -298,6 +301,7 @@ extern "C" int psoap_chunk_destroy(psoap_chunk* h)
     }
     if (h->copy) (void)hipStreamDestroy(h->copy);
     if (h->evStaging) (void)hipEventDestroy(h->evStaging);
+    if (h->evLast) (void)hipEventDestroy(h->evLast);
     for (auto e : h->evPool) (void)hipEventDestroy(e);
     delete h->pws;
     delete h;
@@ -663,18 +667,24 @@ static int promote_slot(psoap_chunk* h, const char* who)
     return 0;
 }
 
+// the slot's per-matrix records on the device: written once per (slot, B, C)
+static int ensure_slot_mats(psoap_chunk* h, BatchSlot& sl)
+{
+    if (sl.mats_B == sl.B && sl.mats_C == sl.C) return 0;
+    std::vector<DagMat> mats(sl.B);
+    fill_mats(h, sl, mats.data());
+    HIP_TRY(hipStreamSynchronize(h->streams[0]));   // an earlier launch may still read the records
+    HIP_TRY(hipMemcpy(sl.dMats, mats.data(), sizeof(DagMat) * sl.B, hipMemcpyHostToDevice));
+    sl.mats_B = sl.B;
+    sl.mats_C = sl.C;
+    return 0;
+}
+
 // (re)build the task list of the persistent kernel when the batch size changes
 static int dag_prepare(psoap_chunk* h)
 {
     BatchSlot& sl = h->slot[h->act];
-    if (sl.mats_B != sl.B || sl.mats_C != sl.C) {
-        std::vector<DagMat> mats(sl.B);
-        fill_mats(h, sl, mats.data());
-        HIP_TRY(hipStreamSynchronize(h->streams[0]));   // an earlier launch may still read the records
-        HIP_TRY(hipMemcpy(sl.dMats, mats.data(), sizeof(DagMat) * sl.B, hipMemcpyHostToDevice));
-        sl.mats_B = sl.B;
-        sl.mats_C = sl.C;
-    }
+    if (int rc = ensure_slot_mats(h, sl)) return rc;
     if (h->plan_B == sl.B) return 0;
     if (h->P > 255) FAIL("N too large for the persistent kernel's 8-bit block-row indices (N <= 32640)");
     HIP_TRY(hipStreamSynchronize(h->streams[0]));
@@ -751,6 +761,8 @@ static int eval_dag(psoap_chunk* h)
     HIP_TRY(hipGetLastError());
     if (prof_end(h, s)) return 1;
     HIP_TRY(hipEventRecord(sl.evEval, s));
+    HIP_TRY(hipEventRecord(h->evLast, s));
+    h->last_recorded = true;
     HIP_TRY(hipMemcpyAsync(h->hOut, h->dOut, sizeof(double) * B, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(h->hDagErr, h->dDag + offsetof(DagCtl, error), 4 * sizeof(unsigned int),
                            hipMemcpyDeviceToHost, s));
@@ -778,7 +790,9 @@ extern "C" int psoap_batch_eval(psoap_chunk* h)
         hipStream_t s = h->streams[g];
         const int b0 = gb0[g], nb = gb0[g + 1] - gb0[g];
         HIP_TRY(hipStreamWaitEvent(s, sl.evUpload, 0));
-        if (g != 0) HIP_TRY(hipStreamWaitEvent(s, sl.evEval, 0));   // the workspaces: after the previous evaluation
+        // the shared workspaces: after the previous evaluation of this HANDLE (it normally ran on the other slot, and
+        // the stream-group boundaries move with B, so the slot's own evEval says nothing about them)
+        if (g != 0 && h->last_recorded) HIP_TRY(hipStreamWaitEvent(s, h->evLast, 0));
         const double fbytes = (double)nb * (4.0 * N * (N + 1.0) + 8.0 * (C + 1.0) * N);
         if (prof_begin(h, s, PSOAP_K_FILL, 0.0, fbytes)) return 1;
         if (C == 1) launch_fill<1>(h, sl, s, b0, nb, 1);
@@ -837,6 +851,8 @@ extern "C" int psoap_batch_eval(psoap_chunk* h)
         }
     }
     HIP_TRY(hipEventRecord(sl.evEval, h->streams[0]));
+    HIP_TRY(hipEventRecord(h->evLast, h->streams[0]));
+    h->last_recorded = true;
     HIP_TRY(hipMemcpyAsync(h->hOut, h->dOut, sizeof(double) * B, hipMemcpyDeviceToHost, h->streams[0]));
     return 0;
 }
@@ -881,6 +897,8 @@ struct psoap_group {
     double* dWs = nullptr;
     size_t ws_cap = 0;
     std::vector<int> key;      // B of every handle, then C: the plan is rebuilt when it changes
+    std::vector<int> acts;     // proposal slot of every handle the records in dMats point into
+    long long plan_builds = 0, record_refreshes = 0;   // psoap_group_stats
     DagQueues queues{};
     long long n_tasks = 0;
     int total_B = 0;
@@ -932,7 +950,7 @@ extern "C" int psoap_group_eval(psoap_group* g)
 {
     if (!g) FAIL("psoap_group_eval: null group");
     HIP_TRY(hipSetDevice(g->device));
-    std::vector<int> key;
+    std::vector<int> key, acts;
     int total = 0;
     for (psoap_chunk* h : g->hs)
         if (int rc = promote_slot(h, "psoap_group_eval (every member needs an uploaded batch)")) return rc;
@@ -941,32 +959,29 @@ extern "C" int psoap_group_eval(psoap_group* g)
         const BatchSlot& sl = h->slot[h->act];
         if (sl.C != C) FAIL("psoap_group_eval: all members must use the same number of components");
         key.push_back(sl.B);
-        key.push_back(h->act);      // the records point into the slot's arrays
+        acts.push_back(h->act);
         total += sl.B;
     }
     key.push_back(C);
     if (total > 65535) FAIL("psoap_group_eval: more than 65535 matrices in one launch");
+    // The task list depends on the batch sizes only.  (Round 2 had the proposal slots in this key as well: in an
+    // upload / eval loop they flip every step, so every step rebuilt the plan behind a hipDeviceSynchronize -- which
+    // also waited for the copy stream and undid the two-slot upload pipeline.)
     if (key != g->key) {
         HIP_TRY(hipDeviceSynchronize());
-        std::vector<DagMat> mats((size_t)total);
         std::vector<int> Ps;
-        int b0 = 0;
-        for (psoap_chunk* h : g->hs) {
-            const BatchSlot& sl = h->slot[h->act];
-            fill_mats(h, sl, mats.data() + b0);
-            for (int b = 0; b < sl.B; ++b) Ps.push_back(h->P);
-            b0 += sl.B;
-        }
+        for (psoap_chunk* h : g->hs)
+            for (int b = 0; b < h->slot[h->act].B; ++b) Ps.push_back(h->P);
         const char* env_scheme = getenv("PSOAP_DAG_SCHEME");
         int Pmax = 0;
         for (int P : Ps) Pmax = P > Pmax ? P : Pmax;
         g->workers = dag_pick_workers(dag_batch_flops(Ps), Pmax, g->hs[0]->n_cus, g->hs[0]->dag_grid);
         DagPlan plan = dag_build_tasks(Ps, g->workers, env_scheme ? atoi(env_scheme) : -1);
-        if (mats.size() > g->mats_cap) {
+        if ((size_t)total > g->mats_cap) {
             if (g->dMats) HIP_TRY(hipFree(g->dMats));
             g->dMats = nullptr;
-            HIP_TRY(hipMalloc(&g->dMats, sizeof(DagMat) * mats.size()));
-            g->mats_cap = mats.size();
+            HIP_TRY(hipMalloc(&g->dMats, sizeof(DagMat) * (size_t)total));
+            g->mats_cap = (size_t)total;
         }
         if (plan.tasks.size() > g->tasks_cap) {
             if (g->dTasks) HIP_TRY(hipFree(g->dTasks));
@@ -988,15 +1003,30 @@ extern "C" int psoap_group_eval(psoap_group* g)
             HIP_TRY(hipMalloc(&g->dDag, g->dag_bytes));
             g->dag_cap = g->dag_bytes;
         }
-        HIP_TRY(hipMemcpy(g->dMats, mats.data(), sizeof(DagMat) * mats.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(g->dTasks, plan.tasks.data(), sizeof(DagTask) * plan.tasks.size(), hipMemcpyHostToDevice));
         g->queues = plan.queues;
         g->scheme = plan.scheme;
         g->n_tasks = (long long)plan.tasks.size();
         g->total_B = total;
         g->key = key;
+        g->acts.clear();
+        ++g->plan_builds;
     }
     hipStream_t s = g->stream;
+    // Only the matrix records (storage, size, proposal arrays) depend on the slots: every slot keeps its own on the
+    // device (ensure_slot_mats: written once per slot and batch size), and the group's array is refreshed from them by
+    // device-to-device copies queued on the group's stream -- behind the previous launch, no host synchronisation.
+    if (acts != g->acts) {
+        size_t b0 = 0;
+        for (psoap_chunk* h : g->hs) {
+            BatchSlot& sl = h->slot[h->act];
+            if (int rc = ensure_slot_mats(h, sl)) return rc;
+            HIP_TRY(hipMemcpyAsync(g->dMats + b0, sl.dMats, sizeof(DagMat) * (size_t)sl.B, hipMemcpyDeviceToDevice, s));
+            b0 += (size_t)sl.B;
+        }
+        g->acts = acts;
+        ++g->record_refreshes;
+    }
     for (psoap_chunk* h : g->hs) {
         const BatchSlot& sl = h->slot[h->act];
         HIP_TRY(hipStreamWaitEvent(s, sl.evUpload, 0));
@@ -1026,6 +1056,8 @@ extern "C" int psoap_group_eval(psoap_group* g)
         const BatchSlot& sl = h->slot[h->act];
         hipLaunchKernelGGL(k_finalize, dim3((sl.B + 63) / 64), dim3(64), 0, s, h->dAcc, h->dOut, sl.B, sl.dTooFast);
         HIP_TRY(hipEventRecord(sl.evEval, s));
+        HIP_TRY(hipEventRecord(h->evLast, s));
+        h->last_recorded = true;
         HIP_TRY(hipMemcpyAsync(h->hOut, h->dOut, sizeof(double) * sl.B, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(h->hDagErr, g->dDag + offsetof(DagCtl, error), 4 * sizeof(unsigned int),
                                hipMemcpyDeviceToHost, s));
@@ -1033,6 +1065,14 @@ extern "C" int psoap_group_eval(psoap_group* g)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g->evDone, s));
     for (psoap_chunk* h : g->hs) HIP_TRY(hipStreamWaitEvent(h->streams[0], g->evDone, 0));
+    return 0;
+}
+
+extern "C" int psoap_group_stats(psoap_group* g, long long* plan_builds, long long* record_refreshes)
+{
+    if (!g) FAIL("psoap_group_stats: null group");
+    if (plan_builds) *plan_builds = g->plan_builds;
+    if (record_refreshes) *record_refreshes = g->record_refreshes;
     return 0;
 }
 

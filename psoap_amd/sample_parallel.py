@@ -157,7 +157,16 @@ def run(config, chunks, run_index=0, n_chains=1, seed=None, world=1, rank=0, dev
     if world > 1 and seed is None:
         raise ValueError("multi-rank sampling needs an explicit seed so that all ranks draw the same proposals")
     routdirs = [os.path.join(config["outdir"], "run{:0>2}".format(run_index + b)) + "/" for b in range(n_chains)]
-    taken = [d for d in routdirs if os.path.exists(d)]
+    # Only rank 0 writes, so only rank 0 looks -- and every rank raises or none does: a rank that raised alone
+    # (output directory on a non-shared file system, or created between the ranks' checks) would leave the others
+    # hanging in the first gather.
+    taken = [d for d in routdirs if os.path.exists(d)] if rank == 0 else []
+    if world > 1:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            box = [taken]
+            dist.broadcast_object_list(box, src=0)
+            taken = box[0]
     if taken and not overwrite:
         raise FileExistsError("output directories exist (pass overwrite=True / --overwrite to replace them): "
                               + ", ".join(taken))

@@ -11,23 +11,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """Kept as the third argument of the rank functions; the rendezvous itself goes through a file store in the test's
+    temporary directory (no port to probe and lose between probe and bind)."""
+    return 0
 
 
 def _worker(rank, world, port, n_chunks, outdir):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GLOO_SOCKET_IFNAME"] = "lo"
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch.distributed as dist
     import oracle
     from psoap_amd import synthetic as syn
     from psoap_amd.ensemble import EnsembleEvaluator
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(outdir, "rendezvous"), rank=rank, world_size=world)
     chunks = [syn.make_chunk(2, 3, 30, seed=50 + k) for k in range(n_chunks)]
     gps = syn.make_walkers(2, 5, seed=9)
 

@@ -89,3 +89,68 @@ def test_ensemble_evaluator_uses_one_launch_for_its_chunks(oracle):
         ev.close()
     want = sum(oracle.lnlike(props[k][0][1], chunks[k].fl, chunks[k].sigma, gps[1]) for k in range(3))
     assert close(got[1], want)
+
+
+def test_group_plan_is_built_once_across_an_upload_eval_loop():
+    """upload / eval / fetch steps alternate every member's proposal slot: the task list must be built once (it depends
+    on the batch sizes only), the matrix records are refreshed on the device, and every step's values stay those of
+    single launches -- with the uploads of step k+1 queued while step k is being evaluated."""
+    from psoap_amd.chunk import ChunkGroup, ChunkHandle
+    chunks = [syn.make_chunk(2, 3 + k, 100 + 9 * k, seed=9700 + k) for k in range(3)]
+    B = 4
+    steps = 6
+    props = [[(syn.walker_lwls(ch, syn.make_walker_velocities(ch, B, seed=9800 + 10 * st + k)),
+               syn.make_walkers(2, B, seed=9900 + st)) for k, ch in enumerate(chunks)] for st in range(steps)]
+    handles = [ChunkHandle(ch.fl, ch.sigma, max_batch=B) for ch in chunks]
+    try:
+        want = [[h.lnlike_batch(*props[st][k]) for k, h in enumerate(handles)] for st in range(steps)]
+        with ChunkGroup(handles) as g:
+            for k, h in enumerate(handles):
+                h.upload(*props[0][k])
+            for st in range(steps):
+                g.eval()
+                if st + 1 < steps:
+                    for k, h in enumerate(handles):          # next step's proposals go to the other slot meanwhile
+                        h.upload(*props[st + 1][k])
+                for k, h in enumerate(handles):
+                    got = h.fetch()
+                    assert np.allclose(got, want[st][k], rtol=LNP_RTOL, atol=0.0), (st, k)
+            stats = g.stats()
+            assert stats["plan_builds"] == 1, stats
+            assert stats["record_refreshes"] == steps, stats      # one device-side refresh per slot flip
+            # a different batch size: one more build
+            for k, h in enumerate(handles):
+                h.upload(props[0][k][0][:2], props[0][k][1][:2])
+            g.eval()
+            assert np.allclose(handles[1].fetch(), want[0][1][:2], rtol=LNP_RTOL, atol=0.0)
+            assert g.stats()["plan_builds"] == 2
+    finally:
+        for h in handles:
+            h.close()
+
+
+def test_staged_mode_back_to_back_evals_with_changing_batch_size():
+    """eval, upload, eval with no fetch in between and a different B: the stream-group boundaries of the staged mode
+    move, so every group stream has to wait for the handle's previous evaluation before it touches the shared
+    workspaces (round 2 waited on the slot's own event, i.e. on the evaluation two steps back)."""
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_chunk(2, 6, 200, seed=9950)               # N = 1200
+    big, small = 6, 2
+    gps = syn.make_walkers(2, big, seed=9951)
+    lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, big, seed=9952))
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=big) as h:
+        want_big = h.lnlike_batch(lw, gps)
+        want_small = h.lnlike_batch(lw[3:5], gps[3:5])
+        h.set_mode("staged")
+        h.set_stream_groups(3)
+        for _ in range(5):
+            h.upload(lw, gps)
+            h.eval()
+            h.upload(lw[3:5], gps[3:5])
+            h.eval()                                        # B = 2 right behind B = 6, nothing fetched in between
+            got_small = h.fetch()
+            h.upload(lw, gps)
+            h.eval()
+            got_big = h.fetch()
+            assert np.allclose(got_small, want_small, rtol=LNP_RTOL, atol=0.0)
+            assert np.allclose(got_big, want_big, rtol=LNP_RTOL, atol=0.0)

@@ -351,19 +351,38 @@ def test_predict_edge_shapes_vs_oracle(oracle, cov, c, ne, npx, M, seed):
 
 
 def test_non_finite_data_conventions(cov):
-    """NaN in the flux vector: the reference raises ValueError from cho_solve's check_finite
-    (covariance.py:331,354,376); the device path returns NaN, which every sampler rejects.  NaN in the
-    uncertainties poisons the diagonal -> not positive definite -> -inf."""
+    """Degenerate inputs (NaN / inf in flux, uncertainties, wavelengths, hyper-parameters, mean; l == 0; a negative
+    hyper-parameter beside them): the shim must do what the REFERENCE does with the same call -- ValueError,
+    ZeroDivisionError, -inf or a number -- as recorded from the reference itself in golden_conventions_v1.json
+    (tests/golden/make_golden_conventions.py).  Behind the C ABI the device keeps its own convention."""
+    import json
+    import os
+    from psoap_amd import _convention_cases as cc
+    from psoap_amd.chunk import ChunkHandle
+    with open(os.path.join(os.path.dirname(__file__), "golden", "golden_conventions_v1.json")) as fh:
+        want = json.load(fh)
+    cases = cc.cases()
+    assert sorted(want) == sorted(name for name, *_ in cases) and len(cases) >= 30
+    kinds = set()
+    for name, fname, args, kwargs in cases:
+        got = cc.outcome(getattr(cov, fname), args, kwargs, None)
+        assert got["kind"] == want[name]["kind"], (name, got, want[name])
+        if got["kind"] == "finite":
+            assert abs(got["value"] - want[name]["value"]) <= LNP_RTOL * max(1.0, abs(want[name]["value"])), (name, got, want[name])
+        kinds.add(got["kind"])
+    assert kinds == {"ValueError", "ZeroDivisionError", "-inf", "finite"}
+    # the same dict entry the reference's Worker calls (sample_parallel.py:193)
+    name, fname, args, kwargs = next(c for c in cases if c[0] == "fg_fl_nan")
+    with pytest.raises(ValueError, match="infs or NaNs"):
+        cov.lnlike["SB2"](None, *args)
+    cov.release_handles()
+    # ---- the C ABI itself: no exceptions, NaN / -inf
     ch = syn.make_chunk(2, 3, 50, seed=77)
     fl = ch.fl.copy()
     fl[17] = np.nan
-    assert np.isnan(cov.lnlike_f_g(None, ch.lwls[0], ch.lwls[1], fl, ch.sigma, *syn.GP_BASE[2]))
     sg = ch.sigma.copy()
     sg[5] = np.nan
-    assert cov.lnlike_f_g(None, ch.lwls[0], ch.lwls[1], ch.fl, sg, *syn.GP_BASE[2]) == -np.inf
-    # NaN in a wavelength vector poisons a row and column of the covariance (off the diagonal, whose elements do
-    # not depend on the wavelengths): the factorisation meets a NaN pivot further down -> -inf, never a number
-    wl = ch.lwls[0].copy()
-    wl[11] = np.nan
-    assert cov.lnlike_f_g(None, wl, ch.lwls[1], ch.fl, ch.sigma, *syn.GP_BASE[2]) == -np.inf
-    cov.release_handles()
+    with ChunkHandle(fl, ch.sigma, max_batch=1) as h:
+        assert np.isnan(h.lnlike(ch.lwls, syn.GP_BASE[2]))
+    with ChunkHandle(ch.fl, sg, max_batch=1) as h:
+        assert h.lnlike(ch.lwls, syn.GP_BASE[2]) == -np.inf

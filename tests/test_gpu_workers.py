@@ -116,25 +116,27 @@ dist.destroy_process_group()
 '''
 
 
-def _run_twice_if_needed(cmd, **kw):
-    """Run a multi-process launcher; ONE retry when it exits non-zero (a rendezvous on a loopback port can fail for
-    reasons that have nothing to do with the code under test: a port taken between probe and bind, a slow first import
-    on a cold box).  The first failure's output is kept for the assertion message of a second one."""
+_RENDEZVOUS_ERRORS = ("Address already in use", "RendezvousConnectionError", "RendezvousTimeoutError", "EADDRINUSE",
+                      "failed to bind", "The server socket has failed to listen", "Connection refused",
+                      "DistNetworkError", "TCPStore")
+
+
+def _run_retry_rendezvous_only(cmd, **kw):
+    """Run a multi-process launcher.  ONE retry, and only when the failure is a rendezvous / bind error of the launcher
+    itself (stderr names one): a GPU fault or a dependency-wait timeout in a rank -- exactly what these tests exist to
+    catch -- fails at once.  A retry that was needed is reported as a warning with the first attempt's output."""
     import time
+    import warnings
     res = subprocess.run(cmd, **kw)
     if res.returncode == 0:
         return res, ""
+    err = (res.stderr or "") + (res.stdout or "")
+    if not any(pat in err for pat in _RENDEZVOUS_ERRORS) or "Memory access fault" in err or "timed out (results invalid)" in err:
+        return res, ""
     first = f"[first attempt rc={res.returncode}]\n{res.stdout[-1500:]}\n{res.stderr[-2500:]}\n[second attempt]\n"
+    warnings.warn("launcher rendezvous failed once, retried: " + first[-600:])
     time.sleep(5.0)
     return subprocess.run(cmd, **kw), first
-
-
-def _free_port():
-    """A TCP port nobody listens on right now (asked from the kernel, as bench.py does for its own ranks)."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
 
 
 @pytest.mark.parametrize("n_chunks", [2, 5])     # one chunk per rank / several per rank (ChunkGroup branch)
@@ -143,11 +145,11 @@ def test_two_ranks_one_gpu_gloo_bit_identical_to_single_process(tmp_path, n_chun
     prog.write_text(_RANK_CODE % (ROOT, n_chunks))
     outs = {}
     for world in (1, 2):
-        port = _free_port()
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), str(prog)]
+        # --standalone: the launcher binds its own rendezvous port on the loopback address (no probe-then-bind race)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               f"--nproc-per-node={world}", str(prog)]
         env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        res, first = _run_twice_if_needed(cmd, capture_output=True, text=True, timeout=900, env=env)
+        res, first = _run_retry_rendezvous_only(cmd, capture_output=True, text=True, timeout=900, env=env)
         assert res.returncode == 0, (first, res.stdout[-1500:], res.stderr[-3000:])
         line = [ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1]
         outs[world] = json.loads(line[len("RESULT "):])
@@ -165,7 +167,7 @@ def test_bench_launches_its_own_ranks_gloo_dry_run():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(key, None)
-    res, first = _run_twice_if_needed([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+    res, first = _run_retry_rendezvous_only([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
                                        "--steps", "2", "--warmup", "1", "--walkers", "8"],
                                       capture_output=True, text=True, timeout=1500, env=env)
     assert res.returncode == 0, (first, res.stdout[-1500:], res.stderr[-3000:])
@@ -174,6 +176,11 @@ def test_bench_launches_its_own_ranks_gloo_dry_run():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["parity_checked"] is True and rec["backend"] == "gloo"
     assert rec["value"] > 0 and rec["scaling"] == "weak" and rec["parity"]["golden_cfg4_table"] == [2, 4]
+    # the configs[3] curve comes out of the same run: 8 chunks over the 2 ranks (ChunkGroup of 4 per rank), strong scaling
+    st = rec["cfg4_strong"]
+    assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["chunks_per_rank"] == [4, 4]
+    assert st["evals_per_s"] > 0 and st["parity_checked"] is True and st["parity_table"] == [8, 4]
+    assert st["group_plan_builds"] == 1
 
 
 # ---------------------------------------------------------------------------------------------- forced split schemes

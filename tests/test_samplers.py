@@ -273,23 +273,20 @@ def test_posterior_keeps_batch_size_and_masks_rows_outside_prior():
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """Kept as the third argument of the rank functions; the rendezvous itself goes through a file store in the test's
+    temporary directory (no port to probe and lose between probe and bind)."""
+    return 0
 
 
 def _rank_main(rank, world, port, outdir):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GLOO_SOCKET_IFNAME"] = "lo"
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     import test_samplers as me
     from psoap_amd import sample_parallel as sp
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(outdir, "rendezvous"), rank=rank, world_size=world)
     try:
         config = dict(me.CONFIG, outdir=os.path.join(outdir, "output"))
         built = []
@@ -319,3 +316,37 @@ def test_driver_two_ranks_gloo(tmp_path):
     assert os.path.exists(tmp_path / "output" / "run00" / "flatchain.npy")
     with pytest.raises(ValueError, match="seed"):
         sp.run(config, _chunks(3), n_chains=2, world=2, rank=0, make_worker=lambda ch: None, verbose=False)
+
+
+def _rank_outdir_clash(rank, world, port, outdir):
+    os.environ["GLOO_SOCKET_IFNAME"] = "lo"
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import test_samplers as me
+    from psoap_amd import sample_parallel as sp
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(outdir, "rendezvous"), rank=rank, world_size=world)
+    try:
+        # the run directory exists on rank 0's side only: rank 1 looks at a private, empty output tree
+        config = dict(me.CONFIG, outdir=os.path.join(outdir, "output" if rank == 0 else "elsewhere"))
+        verdict = "ran"
+        try:
+            sp.run(config, me._chunks(3), n_chains=1, seed=3, world=world, rank=rank, iterations=2,
+                   make_worker=lambda ch: me._OracleWorker(ch, config), verbose=False)
+        except FileExistsError:
+            verdict = "FileExistsError"
+        with open(os.path.join(outdir, f"verdict_{rank}.txt"), "w") as fh:
+            fh.write(verdict)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_existing_output_directory_raises_on_every_rank_together(tmp_path):
+    """the check used to run on each rank on its own, before any collective -- a rank that raised alone left
+    the others hanging in the first gather.  Rank 0 decides, the verdict is broadcast."""
+    import torch.multiprocessing as mp
+    os.makedirs(tmp_path / "output" / "run00")
+    mp.spawn(_rank_outdir_clash, args=(2, 0, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "verdict_0.txt").read_text() == "FileExistsError"
+    assert (tmp_path / "verdict_1.txt").read_text() == "FileExistsError"
