@@ -126,11 +126,18 @@ int psoap_predict(int device, int mode, int c, int N, int M, const double *lwl,
 int psoap_chunk_predict(psoap_chunk *h, int mode, int c, int M, const double *lwl,
                         const double *lwl_pred, const double *mu_c, const double *gp,
                         double *mu_out, double *Sigma_out, int *status_out);
+/* Mean and diag(Sigma) only (R doubles instead of R^2, no N R^2 product, no 75 MB download):
+ * what the retrieve scripts use of Sigma -- sigma_f = sqrt(diag(Sigma))[0:M]
+ * (scripts/psoap_retrieve_ST3.py:111-119, psoap_retrieve_SB2.py:107-113). */
+int psoap_chunk_predict_var(psoap_chunk *h, int mode, int c, int M, const double *lwl,
+                            const double *lwl_pred, const double *mu_c, const double *gp,
+                            double *mu_out, double *var_out, int *status_out);
 int psoap_chunk_predict_release(psoap_chunk *h);
 /* Timings of the handle's last predict call, in ms: device_ms = first upload ->
  * mu and Sigma complete on the device (HIP events), factor_ms = the persistent
  * launch over [B | Cx^T], sigma_ms = mean + prior fill + Sigma = A - W^T W,
- * download_ms = Sigma D2H into the caller's array, total_ms = the whole call
+ * download_ms = what the Sigma download adds to the call beyond the device work (it
+ * travels in groups of tile rows while later groups are computed), total_ms = the whole call
  * (host clock); flops = N^3/3 + N^2 R + N R^2 + 2 N R (SURVEY.md 8(d) F_pred,
  * padded sizes, R = prediction columns). */
 typedef struct {

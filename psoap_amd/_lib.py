@@ -63,6 +63,8 @@ SIGNATURES = {
                                      _dp, _dp, _dp, _dp, _dp, _dp, _ip]),
     "psoap_chunk_predict": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp,
                                            _ip]),
+    "psoap_chunk_predict_var": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp, _dp, _dp,
+                                               _ip]),
     "psoap_chunk_predict_release": (ctypes.c_int, [_vp]),
     "psoap_chunk_predict_timings": (ctypes.c_int, [_vp, ctypes.POINTER(PredictTimings)]),
     "psoap_predictor_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int]),

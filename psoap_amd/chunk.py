@@ -126,9 +126,11 @@ class ChunkHandle:
     def sync(self):
         check(self._L.psoap_chunk_sync(self._h), "psoap_chunk_sync")
 
-    def predict(self, mode: int, lwls, lwls_predict, mu_c, gp, want_sigma: bool = True):
+    def predict(self, mode: int, lwls, lwls_predict, mu_c, gp, want_sigma=True):
         """``predict_*`` on this chunk's resident ``fl`` / ``sigma`` (include/psoap_gp.h: psoap_chunk_predict;
-        mode 0 components, 1 sum, 2 predict_f).  The workspace stays with the handle."""
+        mode 0 components, 1 sum, 2 predict_f).  The workspace stays with the handle.
+        ``want_sigma``: True -> (mu, Sigma); "diag" -> (mu, diag(Sigma)) without ever forming Sigma
+        (psoap_chunk_predict_var); False -> mu."""
         lwls = as_f64(np.atleast_2d(lwls))
         pred = as_f64(np.atleast_2d(lwls_predict))
         c = lwls.shape[0]
@@ -139,8 +141,17 @@ class ChunkHandle:
         gp = as_f64(gp, (2 * c,))
         R = c * M if mode == 0 else M
         mu = np.empty(R)
-        Sigma = np.empty((R, R)) if want_sigma else None
         status = ctypes.c_int(0)
+        if isinstance(want_sigma, str):
+            if want_sigma != "diag":
+                raise ValueError('want_sigma must be True, False or "diag"')
+            var = np.empty(R)
+            check(self._L.psoap_chunk_predict_var(self._h, int(mode), c, M, dptr(lwls), dptr(pred), dptr(mu_c), dptr(gp),
+                                                  dptr(mu), dptr(var), ctypes.byref(status)), "psoap_chunk_predict_var")
+            if status.value != 0:
+                raise np.linalg.LinAlgError("data covariance matrix is not positive definite")
+            return mu, var
+        Sigma = np.empty((R, R)) if want_sigma else None
         check(self._L.psoap_chunk_predict(self._h, int(mode), c, M, dptr(lwls), dptr(pred), dptr(mu_c), dptr(gp),
                                           dptr(mu), None if Sigma is None else dptr(Sigma), ctypes.byref(status)),
               "psoap_chunk_predict")

@@ -291,7 +291,11 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* __restr
 // above -- its PARTs ran ahead -- so the running sum is read off the row-to-row path.
 __device__ __forceinline__ void dag_sub_partials(Tile& t, const double* __restrict__ prev, int n_prev)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (opaque copy of the thread id, as in dag_store_updated: otherwise the 64 per-lane element offsets below are
+    // computed once at the top of the kernel, kept for its whole life and spilled)
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int lane = tid_ & 63, wave = tid_ >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     for (int sidx = 0; sidx < n_prev; ++sidx) {
         const double* __restrict__ ps = prev + (size_t)sidx * NB * NB;
@@ -318,7 +322,9 @@ __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, in
     t.zero();
     if (BAL) tile_gemm_tn_lower_balanced(t, Wm, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld, sm);
     else tile_gemm_tn_lower(t, Wm, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld);
-    const int lane = tid & 63, wave = tid >> 6;
+    int tid_ = threadIdx.x;                      // opaque: the store offsets below are not kernel-lifetime values
+    asm volatile("" : "+v"(tid_));
+    const int lane = tid_ & 63, wave = tid_ >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     double part[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll

@@ -210,7 +210,9 @@ __device__ __forceinline__ void potrf_blocked(double* Km, int ld, int k0, double
                                               unsigned long long* tl = nullptr)
 {
     using namespace pb;
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                 // opaque: no per-lane offset of this routine outlives it (spills)
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: block ownership tests become s_cbranch
     const int q = lane >> 4, c = lane & 15;
     const int rhs_row = (3 * wave) & 3;   // this wave owns the rhs blocks of block rows rhs_row and rhs_row + 4

@@ -1278,9 +1278,29 @@ extern "C" int psoap_predictor_timings(psoap_predictor* p, psoap_predict_timings
 
 // handle-resident form: fl / sigma are the handle's, every device buffer lives in a
 // grow-only workspace owned by the handle, so a second call of the same shape allocates nothing.
+static int chunk_predict(psoap_chunk* h, int mode, int c, int M, const double* lwl, const double* lwl_pred,
+                         const double* mu_c, const double* gp, double* mu_out, double* Sigma_out, double* var_out,
+                         int* status_out);
+
 extern "C" int psoap_chunk_predict(psoap_chunk* h, int mode, int c, int M, const double* lwl, const double* lwl_pred,
                                    const double* mu_c, const double* gp, double* mu_out, double* Sigma_out,
                                    int* status_out)
+{
+    return chunk_predict(h, mode, c, M, lwl, lwl_pred, mu_c, gp, mu_out, Sigma_out, nullptr, status_out);
+}
+
+// mean and diag(Sigma) only: what the retrieve scripts plot (sqrt(diag(Sigma)), psoap_retrieve_ST3.py:111)
+extern "C" int psoap_chunk_predict_var(psoap_chunk* h, int mode, int c, int M, const double* lwl, const double* lwl_pred,
+                                       const double* mu_c, const double* gp, double* mu_out, double* var_out,
+                                       int* status_out)
+{
+    if (!var_out) FAIL("psoap_chunk_predict_var: var_out is required");
+    return chunk_predict(h, mode, c, M, lwl, lwl_pred, mu_c, gp, mu_out, nullptr, var_out, status_out);
+}
+
+static int chunk_predict(psoap_chunk* h, int mode, int c, int M, const double* lwl, const double* lwl_pred,
+                         const double* mu_c, const double* gp, double* mu_out, double* Sigma_out, double* var_out,
+                         int* status_out)
 {
     if (!h) FAIL("psoap_chunk_predict: null handle");
     if (int rc = predict_check(mode, c, h->N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
@@ -1292,7 +1312,7 @@ extern "C" int psoap_chunk_predict(psoap_chunk* h, int mode, int c, int M, const
     }
     int status = 0;
     const int rc = predict_run(*h->pws, mode, c, h->N, M, lwl, nullptr, nullptr, h->dFl, h->dSigma, lwl_pred, mu_c, gp,
-                               mu_out, Sigma_out, &status, g_err);
+                               mu_out, Sigma_out, &status, g_err, var_out);
     if (status_out) *status_out = status;
     return rc;
 }

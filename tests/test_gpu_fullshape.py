@@ -103,3 +103,17 @@ def test_cfg4_eight_chunks_32_walkers_one_launch(full):
     finally:
         for h in handles:
             h.close()
+
+
+def test_predict_cfg5_variance_only(full):
+    """psoap_chunk_predict_var: mean and diag(Sigma) without forming Sigma -- what the retrieve scripts use of it
+    (sqrt(diag(Sigma)), psoap_retrieve_ST3.py:111) -- against the reference's diagonal at the retrieve shape."""
+    from psoap_amd.chunk import ChunkHandle
+    ch, M, pred = _cfg5()
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=1) as h:
+        mu, var = h.predict(0, ch.lwls, np.stack([pred] * 3), np.zeros(3), syn.GP_BASE[3], want_sigma="diag")
+        assert mu.shape == (3 * M,) and var.shape == (3 * M,)
+        assert np.max(np.abs(mu - full["cfg5_pred_mu"])) <= MU_ATOL
+        assert np.max(np.abs(var - full["cfg5_pred_diag"])) <= SIGMA_ATOL
+        t = h.predict_timings()
+        assert t["download_ms"] < 1.0          # nothing R^2-sized travels

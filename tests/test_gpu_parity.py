@@ -386,3 +386,20 @@ def test_non_finite_data_conventions(cov):
         assert np.isnan(h.lnlike(ch.lwls, syn.GP_BASE[2]))
     with ChunkHandle(ch.fl, sg, max_batch=1) as h:
         assert h.lnlike(ch.lwls, syn.GP_BASE[2]) == -np.inf
+
+
+@pytest.mark.parametrize("mode,c", [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 1)])
+def test_predict_variance_only_matches_the_diagonal_of_sigma(mode, c):
+    """diag(Sigma) from the variance-only entry (prior variance minus the column norms of W) against the diagonal
+    of the full Sigma = A - W^T W of the same call, every mode (components / sum incl. the 1e-8 nugget / predict_f);
+    ragged sizes (N, M not multiples of 128)."""
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_chunk(c, 5, 117, seed=600 + 10 * mode + c)           # N = 585
+    M = ch.N if (mode == 1 and c == 3) else 150                        # predict_f_g_h_sum needs M == N (covariance.py:294)
+    pred = np.linspace(ch.lwls[0].min(), ch.lwls[0].max(), M)
+    mu_c = np.full(c, 0.25)
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=1) as h:
+        mu, Sigma = h.predict(mode, ch.lwls, np.stack([pred] * c), mu_c, syn.GP_BASE[c])
+        mu2, var = h.predict(mode, ch.lwls, np.stack([pred] * c), mu_c, syn.GP_BASE[c], want_sigma="diag")
+    assert np.array_equal(mu, mu2)
+    assert np.max(np.abs(var - np.diag(Sigma))) <= 1e-12
