@@ -154,6 +154,10 @@ int psoap_predictor_run(psoap_predictor *p, int mode, int c, int N, int M,
                         const double *lwl, const double *fl, const double *sigma,
                         const double *lwl_pred, const double *mu_c, const double *gp,
                         double *mu_out, double *Sigma_out, int *status_out);
+int psoap_predictor_run_var(psoap_predictor *p, int mode, int c, int N, int M,
+                            const double *lwl, const double *fl, const double *sigma,
+                            const double *lwl_pred, const double *mu_c, const double *gp,
+                            double *mu_out, double *var_out, int *status_out);
 int psoap_predictor_timings(psoap_predictor *p, psoap_predict_timings *t);
 int psoap_predictor_destroy(psoap_predictor *p);
 
@@ -249,6 +253,12 @@ int psoap_dag_plan(int B, int P, int workers, void *out, long long max_tasks, lo
 int psoap_dag_plan_multi(int B, const int *Ps, int workers, void *out, long long max_tasks,
                          long long *n_tasks, long long *n_slots, long long *n_ctrs,
                          unsigned int *queue_first);
+/* One matrix of P block rows with Mt appended column tiles (the predict launch) and, when
+ * Ms > 0, the Ms x Ms upper tiles of their Schur complement (Sigma = A - W^T W) as tasks of
+ * the same launch; scheme -1 automatic, 0 throughput, 1 latency. */
+int psoap_dag_plan_aug(int P, int Mt, int Ms, int workers, int scheme, void *tasks_out,
+                       long long max_tasks, long long *n_tasks, long long *n_slots,
+                       long long *n_ctrs, unsigned int *queue_first);
 
 /* Pure host function: the number of persistent workgroups a batch gets -- all the device admits (two per
  * compute unit), or one per compute unit when the batch is bound by the row-to-row chains of its matrices

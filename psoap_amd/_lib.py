@@ -70,6 +70,8 @@ SIGNATURES = {
     "psoap_predictor_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int]),
     "psoap_predictor_run": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp,
                                            _dp, _dp, _dp, _dp, _dp, _ip]),
+    "psoap_predictor_run_var": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp,
+                                               _dp, _dp, _dp, _dp, _dp, _ip]),
     "psoap_predictor_timings": (ctypes.c_int, [_vp, ctypes.POINTER(PredictTimings)]),
     "psoap_predictor_destroy": (ctypes.c_int, [_vp]),
     "psoap_calibrate": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -95,6 +97,10 @@ SIGNATURES = {
     "psoap_dag_plan_multi": (ctypes.c_int, [ctypes.c_int, _ip, ctypes.c_int, _vp, ctypes.c_longlong,
                                       ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong),
                                       ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_uint32)]),
+    "psoap_dag_plan_aug": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp,
+                                          ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong),
+                                          ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong),
+                                          ctypes.POINTER(ctypes.c_uint32)]),
     "psoap_dag_pick_workers": (ctypes.c_int, [ctypes.c_int, _ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip]),
     "psoap_microbench_mfma_f64": (ctypes.c_int, [ctypes.c_int, _dp]),
     "psoap_microbench_tile_engine": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp]),

@@ -159,8 +159,18 @@ def _predict(mode, lwls, fl, sigma, lwls_predict, mu_c, gp, want_sigma=True):
     gp = as_f64(gp, (2 * c,))
     R = c * M if mode == 0 else M
     mu = np.empty(R)
-    Sigma = np.empty((R, R)) if want_sigma else None
     status = ctypes.c_int(0)
+    if isinstance(want_sigma, str):
+        if want_sigma != "diag":
+            raise ValueError('want_sigma must be True, False or "diag"')
+        var = np.empty(R)
+        check(_lib.load().psoap_predictor_run_var(_predictor(), mode, c, N, M, dptr(lwls), dptr(fl), dptr(sigma),
+                                                  dptr(pred), dptr(mu_c), dptr(gp), dptr(mu), dptr(var),
+                                                  ctypes.byref(status)), "psoap_predictor_run_var")
+        if status.value != 0:
+            raise np.linalg.LinAlgError("data covariance matrix is not positive definite")
+        return mu, var
+    Sigma = np.empty((R, R)) if want_sigma else None
     check(_lib.load().psoap_predictor_run(_predictor(), mode, c, N, M, dptr(lwls), dptr(fl), dptr(sigma),
                                           dptr(pred), dptr(mu_c), dptr(gp), dptr(mu),
                                           None if Sigma is None else dptr(Sigma), ctypes.byref(status)),
@@ -169,6 +179,13 @@ def _predict(mode, lwls, fl, sigma, lwls_predict, mu_c, gp, want_sigma=True):
         # cho_factor raises here in the reference (covariance.py:113,182,222,292)
         raise np.linalg.LinAlgError("data covariance matrix is not positive definite")
     return (mu, Sigma) if want_sigma else mu
+
+
+def predict_components_var(lwls, fl, sigma, lwls_predict, mus, gp):
+    """Not in the reference: ``(mu, diag(Sigma))`` of ``predict_f`` / ``predict_f_g`` / ``predict_f_g_h`` (by the number
+    of components) without forming ``Sigma`` -- all the retrieve scripts use of it is ``sqrt(diag(Sigma))``
+    (scripts/psoap_retrieve_ST3.py:111-119).  ``lwls`` (c, N), ``lwls_predict`` (c, M), ``mus`` (c,), ``gp`` (2c,)."""
+    return _predict(2 if len(lwls) == 1 else 0, lwls, fl, sigma, lwls_predict, mus, gp, want_sigma="diag")
 
 
 def predict_f(lwl_known, fl_known, sigma_known, lwl_predict, amp_f, l_f, mu_GP=1.0):

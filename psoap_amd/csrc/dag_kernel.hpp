@@ -85,7 +85,10 @@ struct DagQueues {
 //                        next_done = q + 1;
 //   DAG_WAITNEXT (DIAG)  the final part [q-1, q) waits for next_done >= q instead of the whole block row;
 //   DAG_NOSOLVE  (OFF)   tile (q, q+1): update only, publishes off1_ready = q + 1 (the DIAG task solves it).
-enum : unsigned char { DAG_PART = 0, DAG_DIAG = 1, DAG_OFF = 2, DAG_TYPE_MASK = 0x0F, DAG_CHAIN = 0x10,
+//   DAG_SCHUR    (predict) final of a tile of the Schur complement  A - W^T W  = Sigma: rows AND columns lie in the
+//                        appended range (q, j >= P), update over all P block rows, then the tile -- with the prior
+//                        covariance A evaluated on the fly like K -- is stored into DagAug::S and mirrored; no solve.
+enum : unsigned char { DAG_PART = 0, DAG_DIAG = 1, DAG_OFF = 2, DAG_SCHUR = 3, DAG_TYPE_MASK = 0x0F, DAG_CHAIN = 0x10,
                        DAG_NOSOLVE = 0x20, DAG_WAITNEXT = 0x40, DAG_FUSED = 0x80 };
 struct DagTask {
     unsigned char type, q, j, S;
@@ -202,6 +205,12 @@ struct DagAug {
     int Pt;               // column tiles in total (P + extra); == P when there are none
     int R, Rpad;          // valid / padded extra columns
     const double* colx;   // (C, Rpad)
+    // Schur-complement tiles (DAG_SCHUR; predict's Sigma = A - W^T W computed inside the same launch):
+    const double* rowx;   // (C, Rpad) the same abscissae for tile ROWS, with -1e30 where colx has +1e30 (a component that
+                          // contributes to neither the row's nor the column's block must see r = 2e30, not r = 0)
+    const double* diag;   // (Rpad) prior variances: the diagonal of A (amp^2 sums, + the 1e-8 nugget of predict_f_g_sum)
+    double* S;            // (Rpad x lds) Sigma
+    size_t lds;
 };
 
 // One matrix of the batch.  The batch may be heterogeneous (matrices of several chunks with their own
@@ -222,7 +231,7 @@ template <int C, bool AUG>
 __device__ __forceinline__ void dag_store_updated(const Tile& t, double* __restrict__ dest, size_t ldd, int k0, int j0,
                                                   const double* __restrict__ lw, const GpDev& g, double dsum,
                                                   const double* __restrict__ sigma, int N, double scale,
-                                                  int Npad, const DagAug& aug)
+                                                  int Npad, const DagAug& aug, double* __restrict__ mirror = nullptr)
 {
     // the thread id passes through an opaque statement: everything below (coordinate loads, addresses)
     // depends on it and so cannot be hoisted above the K-loops of the update, where it would sit in
@@ -233,12 +242,13 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* __restr
     const int wr = wave >> 1, wc = wave & 1;
     double xj[4][C];
     int jj[4];
-    const bool cross = AUG && j0 >= Npad;   // wave-uniform: a tile of the appended columns
+    const bool cross = AUG && j0 >= Npad;      // wave-uniform: a tile of the appended columns
+    const bool rowcross = AUG && k0 >= Npad;   // wave-uniform: a tile of the Schur complement (rows appended too)
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         jj[n] = j0 + tile_col(wc, n, lane);
         if (cross) {
-            // map to a column index that passes / fails the `j < N` test below and never equals a row index
+            // map to a column index that passes / fails the `j < N` test below and never equals a data row index
             const int e = jj[n] - Npad;
 #pragma unroll
             for (int c = 0; c < C; ++c) xj[n][c] = (e < aug.R) ? aug.colx[(size_t)c * aug.Rpad + e] : 0.0;
@@ -255,8 +265,15 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             ii[r] = k0 + tile_row(wr, m, lane, r);
+            if (rowcross) {
+                const int e = ii[r] - Npad;        // the same index map as the columns: equal indices = the diagonal of A
 #pragma unroll
-            for (int c = 0; c < C; ++c) xi[r][c] = (ii[r] < N) ? lw[(size_t)c * N + ii[r]] : 0.0;
+                for (int c = 0; c < C; ++c) xi[r][c] = (e < aug.R) ? aug.rowx[(size_t)c * aug.Rpad + e] : 0.0;
+                ii[r] = (e < aug.R) ? -1 - e : 0x7ffffffe;
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) xi[r][c] = (ii[r] < N) ? lw[(size_t)c * N + ii[r]] : 0.0;
+            }
         }
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -269,8 +286,12 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* __restr
                 if (i < N && j < N) {
                     if (i == j) {
 #pragma clang fp contract(off)
-                        const double sg = sigma[i];
-                        v = dsum + sg * sg;
+                        if (rowcross) {
+                            v = aug.diag[-1 - i];
+                        } else {
+                            const double sg = sigma[i];
+                            v = dsum + sg * sg;
+                        }
                     } else {
                         v = kv[r];
                     }
@@ -278,7 +299,19 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* __restr
                     v = (i == j) ? 1.0 : 0.0;
                 }
                 const int jc = tile_col(wc, n, lane);                          // column inside the tile
-                dest[(size_t)(i - k0) * ldd + (size_t)jc] = scale * v - t.acc[m][n][r];
+                const int ic = tile_row(wr, m, lane, r);                       // row inside the tile
+                const double out = scale * v - t.acc[m][n][r];
+                if (AUG && mirror) {
+                    // a tile of Sigma, written twice: as it is and transposed.  A DIAGONAL tile (mirror == dest) comes out of
+                    // the update with its lower-left quadrant missing (the symmetric update skips it): only the elements
+                    // on and above the diagonal are stored, each also at its mirror position.
+                    if (mirror != dest || ic <= jc) {
+                        dest[(size_t)ic * ldd + (size_t)jc] = out;
+                        mirror[(size_t)jc * ldd + (size_t)ic] = out;
+                    }
+                } else {
+                    dest[(size_t)ic * ldd + (size_t)jc] = out;
+                }
             }
         }
     }
@@ -571,12 +604,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
                 for (int c = 1; c < C; ++c) dsum = dsum + g.a2[c];
             }
             double* dest = is_part ? (wspace + (size_t)task.slot * SLOT) : (Km + (size_t)k0 * ld + j0);
+            size_t ldd = is_part ? (size_t)NB : (size_t)ld;
+            double* mirror = nullptr;
+            if (AUG && ttype == DAG_SCHUR) {
+                // a tile of Sigma: rows k0 - Npad .., columns j0 - Npad .. of DagAug::S, and its transpose
+                dest = aug.S + (size_t)(k0 - Npad) * aug.lds + (size_t)(j0 - Npad);
+                ldd = aug.lds;
+                mirror = aug.S + (size_t)(j0 - Npad) * aug.lds + (size_t)(k0 - Npad);     // == dest on the diagonal
+            }
             // who adds K(i, j): the final task -- except in a chain, where the FIRST PART carries it, so
             // that the exp() evaluations are off the critical row-to-row path (the final of a chain runs
             // right after the block row above completes; its PARTs ran ahead)
             const bool carries_k = chain ? (is_part ? task.S == 0 : task.S <= 1) : !is_part;
-            dag_store_updated<C, AUG>(t, dest, is_part ? (size_t)NB : (size_t)ld, k0, j0, mat.lw, g, dsum, mat.sigma, N,
-                                      carries_k ? 1.0 : 0.0, Npad, aug);
+            dag_store_updated<C, AUG>(t, dest, ldd, k0, j0, mat.lw, g, dsum, mat.sigma, N, carries_k ? 1.0 : 0.0, Npad, aug,
+                                      mirror);
         }
         if (is_part) {
             dag_drain();
@@ -587,6 +628,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
             if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
             continue;
         }
+        if (AUG && ttype == DAG_SCHUR) continue;     // nobody inside the launch reads Sigma: no drain, no counter
         dag_drain();  // the tile is re-read below in another layout by other waves of this block
         if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 1] = __builtin_amdgcn_s_memrealtime();
         if (ttype == DAG_DIAG) {
@@ -729,8 +771,56 @@ inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first,
 // task list of ONE queue: the matrices in `mats`, served by about `workers` workgroups
 // `Bq_nominal` (the largest queue's matrix count) decides the split factors, so every matrix of the
 // batch gets the same task structure and identical proposals give identical bits in any batch slot
+// Tasks of the Schur complement of the appended columns (predict: Sigma = A - W^T W), Ms x Ms tiles, upper triangle:
+// tile (P + i, P + j) is a left-looking update over ALL P block rows with nothing to solve afterwards -- work that
+// needs no critical path, cut into chained parts of `len` panels whose boundaries are staggered from tile to tile, so
+// that about the same number of parts becomes ready with every finished block row and the workgroups that wait on the
+// factorisation's row-to-row chain always find one.  The final covers the last panel and stores into DagAug::S.
+inline void dag_emit_schur(DagPlan& plan, int b, int P, int Ms, int len = 8)
+{
+    static const int env_len = getenv("PSOAP_SCHUR_LEN") ? atoi(getenv("PSOAP_SCHUR_LEN")) : 0;   // experiments
+    if (env_len > 0) len = env_len;
+    int tile = 0;
+    for (int i = 0; i < Ms; ++i)
+        for (int j = i; j < Ms; ++j, ++tile) {
+            std::vector<int> cuts;                           // part boundaries in [0, P - 1]
+            cuts.push_back(0);
+            for (int c = 1 + tile % len; c < P - 1; c += len) cuts.push_back(c);
+            if (P - 1 > cuts.back()) cuts.push_back(P - 1);
+            const int nparts = (int)cuts.size() - 1;         // PARTs cover [0, P - 1); may be 0 when P == 1
+            const unsigned int ctr = plan.n_ctrs++;
+            plan.n_slots += plan.n_slots & 1u;
+            const unsigned int slot0 = plan.n_slots;
+            for (int sidx = 0; sidx < nparts; ++sidx) {
+                DagTask t{};
+                t.type = DAG_PART | DAG_CHAIN;
+                t.b = (unsigned short)b;
+                t.q = (unsigned char)(P + i);
+                t.j = (unsigned char)(P + j);
+                t.S = (unsigned char)sidx;
+                t.pa = (unsigned char)cuts[sidx];
+                t.pb = (unsigned char)cuts[sidx + 1];
+                t.slot = slot0 + (unsigned int)(sidx & 1);
+                t.ctr = ctr;
+                plan.tasks.push_back(t);
+            }
+            plan.n_slots = slot0 + (nparts > 1 ? 2 : (nparts > 0 ? 1 : 0));
+            DagTask fin{};
+            fin.type = DAG_SCHUR | DAG_CHAIN;
+            fin.b = (unsigned short)b;
+            fin.q = (unsigned char)(P + i);
+            fin.j = (unsigned char)(P + j);
+            fin.S = (unsigned char)(nparts + 1);
+            fin.pa = (unsigned char)(P - 1);
+            fin.pb = (unsigned char)P;
+            fin.slot = nparts > 0 ? slot0 + (unsigned int)((nparts - 1) & 1) : 0u;
+            fin.ctr = ctr;
+            plan.tasks.push_back(fin);
+        }
+}
+
 inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const std::vector<int>& Ps, int workers,
-                            int Bq_nominal, int scheme, int Mt = 0)
+                            int Bq_nominal, int scheme, int Mt = 0, int Ms = 0)
 {
     // Ps[b]: block rows of matrix b.  A heterogeneous batch (matrices of several chunks) walks the block
     // rows of all its matrices together; a matrix simply drops out once its rows are used up.
@@ -830,7 +920,10 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
                 dag_emit(plan, DAG_OFF, b, q, j, 0, q, S_off, scheme,
                          (unsigned char)((j == q + 1 && fused(b)) ? DAG_NOSOLVE : 0));
     }
+    if (Ms > 0)
+        for (int b : mats) dag_emit_schur(plan, b, Ps[b], Ms);
 }
+
 
 // scheme: 0 throughput, 1 latency (dag_emit), -1 automatic: latency while the row-to-row dependency chain,
 // not the MFMA work, bounds the run time -- i.e. while a queue has too few block rows in flight to hide the
@@ -857,7 +950,7 @@ inline int dag_auto_scheme(const std::vector<int>& Ps)
     }
     return (max_rows <= DAG_LATENCY_QUEUE_ROWS || max_count <= 1) ? 1 : 0;
 }
-inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int scheme = -1, int Mt = 0)
+inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int scheme = -1, int Mt = 0, int Ms = 0)
 {
     DagPlan plan;
     const int B = (int)Ps.size();
@@ -870,7 +963,7 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
         plan.queues.first[g] = (unsigned int)plan.tasks.size();
         std::vector<int> mats;
         for (int b = g; b < B; b += DAG_QUEUES) mats.push_back(b);
-        dag_build_queue(plan, mats, Ps, per_queue, (B + DAG_QUEUES - 1) / DAG_QUEUES, scheme, Mt);
+        dag_build_queue(plan, mats, Ps, per_queue, (B + DAG_QUEUES - 1) / DAG_QUEUES, scheme, Mt, Ms);
         if (scheme == 1) {
             // Latency scheme: hand the tasks out in order of READINESS instead of block row by block row.
             // A task over panels [pa, pb) can run once block row pb-1 is finished ("stage" pb); within a
@@ -884,7 +977,7 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
             auto cls = [](const DagTask& t) {
                 const int ty = t.type & DAG_TYPE_MASK;
                 if (ty == DAG_OFF && (t.type & DAG_NOSOLVE)) return -1;
-                return ty == DAG_DIAG ? 0 : (ty == DAG_OFF ? 1 : 2);
+                return ty == DAG_DIAG ? 0 : (ty == DAG_OFF ? 1 : 2);      // PART and DAG_SCHUR: whatever is left of a stage
             };
             std::stable_sort(plan.tasks.begin() + plan.queues.first[g], plan.tasks.end(),
                              [&](const DagTask& a, const DagTask& b) {
@@ -928,9 +1021,9 @@ inline double dag_batch_flops(const std::vector<int>& Ps, int Mt = 0)
 }
 
 // uniform batch: B matrices of P block rows each
-inline DagPlan dag_build_tasks(int B, int P, int workers, int scheme = -1, int Mt = 0)
+inline DagPlan dag_build_tasks(int B, int P, int workers, int scheme = -1, int Mt = 0, int Ms = 0)
 {
-    return dag_build_tasks(std::vector<int>((size_t)(B > 0 ? B : 0), P), workers, scheme, Mt);
+    return dag_build_tasks(std::vector<int>((size_t)(B > 0 ? B : 0), P), workers, scheme, Mt, Ms);
 }
 
 

@@ -260,7 +260,7 @@ struct PredictWs {
     Grow<double, true> hSigma;   // pinned bounce buffer of the Sigma download
     Grow<double, true> hSmall;   // pinned: colx / m0 staging, mu
     // task list cache
-    int plan_P = -1, plan_Mt = -1, plan_workers = -1, plan_scheme = -2;
+    int plan_P = -1, plan_Mt = -1, plan_workers = -1, plan_scheme = -2, plan_Ms = -1;
     DagPlan plan;
     int workers = 0, n_cus = 0;   // persistent workgroups the device admits; compute units
     hipStream_t stream = nullptr;
@@ -270,7 +270,7 @@ struct PredictWs {
     static constexpr int SIGMA_GROUPS = 8;
     hipStream_t copy_stream = nullptr;
     hipEvent_t evRows[SIGMA_GROUPS] = {}, evCopied[SIGMA_GROUPS] = {};
-    Grow<double> Var, Prior;
+    Grow<double> Var, Prior, Rowx, Diag;
     PredictTimes times;
     ~PredictWs()
     {
@@ -355,16 +355,20 @@ struct SigmaMover {
         a0 = row0 + (int)((long long)rows * tix / n_threads);
         a1 = row0 + (int)((long long)rows * (tix + 1) / n_threads);
     }
-    void touch(int tix, size_t total_rows)
+    // first touch of exactly the rows this thread will fill later (program order then puts every touch before the data:
+    // with any other division a late-starting thread would zero a word of rows another thread has already filled)
+    void touch(int tix)
     {
-        int a0, a1;
-        share(tix, 0, (int)total_rows, a0, a1);
         const size_t step = 4096 / sizeof(double);
-        for (size_t i = (size_t)a0 * row_doubles; i < (size_t)a1 * row_doubles; i += step) dst[i] = 0.0;
+        for (int g = 0; g < n_groups; ++g) {
+            int a0, a1;
+            share(tix, group_rows[g], group_rows[g + 1], a0, a1);
+            for (size_t i = (size_t)a0 * row_doubles; i < (size_t)a1 * row_doubles; i += step) dst[i] = 0.0;
+        }
     }
-    void work(int tix, size_t total_rows)
+    void work(int tix)
     {
-        touch(tix, total_rows);
+        touch(tix);
         while (!layout_known.load(std::memory_order_acquire)) {
             if (abort.load(std::memory_order_relaxed)) return;
             std::this_thread::yield();
@@ -381,13 +385,19 @@ struct SigmaMover {
                        sizeof(double) * (size_t)(a1 - a0) * row_doubles);
         }
     }
-    void start(double* out, size_t rows, size_t cols)
+    // rows x cols output, delivered in groups of tile rows (128 rows each): the layout is fixed here, before any thread runs
+    void start(double* out, size_t rows, size_t cols, int tile_rows)
     {
         dst = out;
         row_doubles = cols;
+        n_groups = tile_rows < PredictWs::SIGMA_GROUPS ? tile_rows : PredictWs::SIGMA_GROUPS;
+        for (int g = 0; g <= n_groups; ++g) {
+            const long long r = (long long)tile_rows * g / n_groups * NB;
+            group_rows[g] = (int)(r < (long long)rows ? r : (long long)rows);
+        }
         const unsigned hw = std::thread::hardware_concurrency();
         n_threads = (int)(hw >= 32 ? 16 : (hw >= 8 ? 4 : 1));
-        for (int t = 1; t < n_threads; ++t) pool.emplace_back([this, t, rows] { work(t, rows); });
+        for (int t = 1; t < n_threads; ++t) pool.emplace_back([this, t] { work(t); });
     }
     void finish()
     {
@@ -429,6 +439,12 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
     // evaluated on the fly like B itself).  The transposed-mean variant (covariance.py:294) needs a
     // block whose ROW abscissae are the prediction grid and keeps the staged three-kernel loop.
     const bool use_dag = !transposed_mean && (P + Mt) <= 255;
+    // Sigma = A - W^T W is the Schur complement of the appended columns: with the persistent kernel its tiles are tasks
+    // of the same launch (DAG_SCHUR), left-looking updates that need no critical path and fill the workgroups the
+    // factorisation's row-to-row chain leaves idle.  PSOAP_PREDICT_FUSED=0: the separate product (k_syrk_sub_sym).
+    const char* env_fused = getenv("PSOAP_PREDICT_FUSED");
+    const bool fused_sigma = use_dag && Sigma_out && !(env_fused && atoi(env_fused) == 0);
+    const int Ms = fused_sigma ? Rq_pad / NB : 0;
     GpHost gall;
     for (int k = 0; k < 6; ++k) gall.v[k] = (k < 2 * c) ? gp[k] : 0.0;
 
@@ -436,7 +452,7 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         PR_TRY(hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
         for (auto& e : ws.ev) PR_TRY(hipEventCreate(&e));
     }
-    if (Sigma_out) mover.start(Sigma_out, (size_t)Rq, (size_t)Rq);
+    if (Sigma_out) mover.start(Sigma_out, (size_t)Rq, (size_t)Rq, Rq_pad / NB);
     if (Sigma_out && !ws.copy_stream) {
         PR_TRY(hipStreamCreateWithFlags(&ws.copy_stream, hipStreamNonBlocking));
         for (auto& e : ws.evRows) PR_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -453,12 +469,14 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
     PR_TRY(ws.Mu.need(Rq_pad));
     PR_TRY(ws.M0.need(Rq_pad));
     PR_TRY(ws.Part.need((size_t)nslab * Rtot_pad));
-    const size_t n_small = (size_t)c * Rq_pad + 3 * (size_t)Rq_pad + 64;
+    const size_t n_small = 2 * (size_t)c * Rq_pad + 4 * (size_t)Rq_pad + 64;
     PR_TRY(ws.hSmall.need(n_small));
     double* h_colx = ws.hSmall;                      // (c, Rq_pad)
     double* h_m0 = h_colx + (size_t)c * Rq_pad;      // (Rq_pad)
     double* h_mu = h_m0 + Rq_pad;                    // (Rq_pad)
     MatAcc* h_acc = reinterpret_cast<MatAcc*>(h_mu + Rq_pad);
+    double* h_rowx = h_mu + 2 * (size_t)Rq_pad + 8;   // (c, Rq_pad), behind h_acc and the variance staging
+    double* h_diag = h_rowx + (size_t)c * Rq_pad;     // (Rq_pad)
     double *dK = ws.K, *dW = ws.W, *dR = ws.R, *dLwl = ws.Lwl, *dPred = ws.Pred, *dGp = ws.Gp, *dMu = ws.Mu,
            *dM0 = ws.M0, *dPart = ws.Part;
     MatAcc* dAcc = ws.Acc;
@@ -496,8 +514,8 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         const int scheme = env_scheme ? atoi(env_scheme) : -1;
         const int workers = dag_pick_workers(dag_batch_flops(std::vector<int>(1, P), Mt), P, ws.n_cus > 0 ? ws.n_cus : ws.workers,
                                              ws.workers);
-        if (ws.plan_P != P || ws.plan_Mt != Mt || ws.plan_workers != workers || ws.plan_scheme != scheme) {
-            ws.plan = dag_build_tasks(1, P, workers, scheme, Mt);
+        if (ws.plan_P != P || ws.plan_Mt != Mt || ws.plan_workers != workers || ws.plan_scheme != scheme || ws.plan_Ms != Ms) {
+            ws.plan = dag_build_tasks(1, P, workers, scheme, Mt, Ms);
             PR_TRY(hipStreamSynchronize(st));
             PR_TRY(ws.Tasks.need(ws.plan.tasks.size()));
             PR_TRY(hipMemcpy(ws.Tasks, ws.plan.tasks.data(), sizeof(DagTask) * ws.plan.tasks.size(),
@@ -507,6 +525,7 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
             ws.plan_Mt = Mt;
             ws.plan_workers = workers;
             ws.plan_scheme = scheme;
+            ws.plan_Ms = Ms;
         }
         const DagPlan& plan = ws.plan;
         const size_t arrive_off = sizeof(DagCtl) + sizeof(MatFlags);
@@ -519,7 +538,36 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         PR_TRY(hipMemsetAsync(dW, 0, sizeof(double) * 2 * NB * NB, st));  // the strictly upper part of W stays zero
         hipLaunchKernelGGL(k_init_rhs, dim3((Npad + 255) / 256, 1), dim3(256), 0, st, dR, Npad, N, dFl, offset, dAcc);
         const int grid = (int)(plan.tasks.size() < (size_t)workers ? plan.tasks.size() : (size_t)workers);
-        const DagAug aug{P + Mt, Rq, Rq_pad, ws.Colx};
+        DagAug aug{P + Mt, Rq, Rq_pad, ws.Colx, nullptr, nullptr, nullptr, 0};
+        if (fused_sigma) {
+            // row abscissae of the Sigma tiles: the column ones with the opposite sentinel; prior variances for the diagonal
+            for (int cc = 0; cc < c; ++cc)
+                for (int q = 0; q < Rq_pad; ++q) {
+                    const double x = h_colx[(size_t)cc * Rq_pad + q];
+                    h_rowx[(size_t)cc * Rq_pad + q] = (x == 1e30) ? -1e30 : x;
+                }
+            for (int q = 0; q < Rq_pad; ++q) {
+                double a2 = 0.0;
+                if (q < Rq) {
+                    if (mode == 0) a2 = gp[2 * (q / M)] * gp[2 * (q / M)];
+                    else {
+                        a2 = gp[0] * gp[0];
+                        for (int k = 1; k < c; ++k) a2 = a2 + gp[2 * k] * gp[2 * k];
+                        if (mode == 1 && c == 2) a2 = a2 + 1e-8;
+                    }
+                }
+                h_diag[q] = a2;
+            }
+            PR_TRY(ws.Rowx.need((size_t)c * Rq_pad));
+            PR_TRY(ws.Diag.need(Rq_pad));
+            PR_TRY(ws.S.need((size_t)Rq_pad * Rq_pad));
+            PR_TRY(hipMemcpyAsync(ws.Rowx, h_rowx, sizeof(double) * (size_t)c * Rq_pad, hipMemcpyHostToDevice, st));
+            PR_TRY(hipMemcpyAsync(ws.Diag, h_diag, sizeof(double) * Rq_pad, hipMemcpyHostToDevice, st));
+            aug.rowx = ws.Rowx;
+            aug.diag = ws.Diag;
+            aug.S = ws.S;
+            aug.lds = (size_t)Rq_pad;
+        }
         MatFlags* fl_ = reinterpret_cast<MatFlags*>(ws.Dag.p + sizeof(DagCtl));
         DagCtl* ctl_ = reinterpret_cast<DagCtl*>(ws.Dag.p);
         DagMat hm{};
@@ -584,44 +632,44 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
     PR_TRY(hipMemcpyAsync(h_acc, dAcc, sizeof(MatAcc), hipMemcpyDeviceToHost, st));
 
     int n_groups = 0;
-    int group_row0[PredictWs::SIGMA_GROUPS + 1] = {};      // tile rows of every download group
     if (Sigma_out) {
         const int St = Rq_pad / NB;
         PR_TRY(ws.S.need((size_t)Rq_pad * Rq_pad));
         PR_TRY(ws.hSigma.need((size_t)Rq * Rq));
         double* dS = ws.S;
-        // prior covariance of the prediction, upper tiles only: k_syrk_sub mirrors the result
-        if (mode == 0) {
-            // A = blockdiag(V11_f_predict, V11_g_predict, ..)  (:124-125,:234-236)
-            hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, st, dS, (size_t)Rq_pad * Rq_pad);
-            for (int k = 0; k < c; ++k) {
-                GpHost g1;
-                g1.v[0] = gp[2 * k];
-                g1.v[1] = gp[2 * k + 1];
-                launch_region<1>(st, dS + (size_t)k * M * Rq_pad, (size_t)Rq_pad, k * M, M, M, dPred + (size_t)k * M, 0,
-                                 dPred + (size_t)k * M, 0, g1, 1, 0.0);
+        if (!fused_sigma) {
+            // prior covariance of the prediction, upper tiles only: k_syrk_sub mirrors the result
+            if (mode == 0) {
+                // A = blockdiag(V11_f_predict, V11_g_predict, ..)  (:124-125,:234-236)
+                hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, st, dS, (size_t)Rq_pad * Rq_pad);
+                for (int k = 0; k < c; ++k) {
+                    GpHost g1;
+                    g1.v[0] = gp[2 * k];
+                    g1.v[1] = gp[2 * k + 1];
+                    launch_region<1>(st, dS + (size_t)k * M * Rq_pad, (size_t)Rq_pad, k * M, M, M, dPred + (size_t)k * M, 0,
+                                     dPred + (size_t)k * M, 0, g1, 1, 0.0);
+                }
+            } else {
+                // V11 = sum of the component priors; 1e-8 nugget only in the two-component sum (:165 vs :271)
+                const double nug = (mode == 1 && c == 2) ? 1e-8 : 0.0;
+                if (Rq_pad != Rq) hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, st, dS, (size_t)Rq_pad * Rq_pad);
+                launch_region_c(st, c, dS, (size_t)Rq_pad, 0, M, M, dPred, (size_t)M, dPred, (size_t)M, gall, 1, nug);
             }
-        } else {
-            // V11 = sum of the component priors; 1e-8 nugget only in the two-component sum (:165 vs :271)
-            const double nug = (mode == 1 && c == 2) ? 1e-8 : 0.0;
-            if (Rq_pad != Rq) hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, st, dS, (size_t)Rq_pad * Rq_pad);
-            launch_region_c(st, c, dS, (size_t)Rq_pad, 0, M, M, dPred, (size_t)M, dPred, (size_t)M, gall, 1, nug);
+            PR_TRY(hipGetLastError());
+            // Sigma = A - W^T W: one launch -- every tile is one K = Npad loop and all of them fit the device at once, so they
+            // all finish together (launching tile rows one after the other serialises them: measured 2.2 -> 10.5 ms).  The
+            // download follows in row groups on the copy stream: each group lands in the pinned buffer and is moved on into
+            // the caller's array by host threads while the next group is on the wire.
+            hipLaunchKernelGGL(k_syrk_sub_sym, dim3(St * (St + 1) / 2), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, dK + Npad, ld,
+                               Npad, dS, (size_t)Rq_pad, St, 0);
+            PR_TRY(hipGetLastError());
         }
-        PR_TRY(hipGetLastError());
-        // Sigma = A - W^T W: one launch -- every tile is one K = Npad loop and all of them fit the device at once, so they
-        // all finish together (launching tile rows one after the other serialises them: measured 2.2 -> 10.5 ms).  The
-        // download follows in row groups on the copy stream: each group lands in the pinned buffer and is moved on into
-        // the caller's array by host threads while the next group is on the wire.
-        hipLaunchKernelGGL(k_syrk_sub_sym, dim3(St * (St + 1) / 2), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, dK + Npad, ld,
-                           Npad, dS, (size_t)Rq_pad, St, 0);
-        PR_TRY(hipGetLastError());
         PR_TRY(hipEventRecord(ws.ev[3], st));           // the device work of the call ends here
         PR_TRY(hipEventRecord(ws.evRows[0], st));
         PR_TRY(hipStreamWaitEvent(ws.copy_stream, ws.evRows[0], 0));
-        n_groups = St < PredictWs::SIGMA_GROUPS ? St : PredictWs::SIGMA_GROUPS;
-        for (int g = 0; g <= n_groups; ++g) group_row0[g] = (int)((long long)St * g / n_groups);
+        n_groups = mover.n_groups;
         for (int g = 0; g < n_groups; ++g) {
-            const int row0 = group_row0[g] * NB, row1 = (group_row0[g + 1] * NB < Rq) ? group_row0[g + 1] * NB : Rq;
+            const int row0 = mover.group_rows[g], row1 = mover.group_rows[g + 1];
             if (row1 > row0) {
                 if (Rq == Rq_pad)
                     PR_TRY(hipMemcpyAsync(ws.hSigma.p + (size_t)row0 * Rq, dS + (size_t)row0 * Rq_pad,
@@ -660,10 +708,8 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
     if (!Sigma_out) PR_TRY(hipEventRecord(ws.ev[3], st));
     if (Sigma_out) {
         mover.src = ws.hSigma.p;
-        mover.n_groups = n_groups;
-        for (int g = 0; g <= n_groups; ++g) mover.group_rows[g] = (group_row0[g] * NB < Rq) ? group_row0[g] * NB : Rq;
         mover.layout_known.store(1, std::memory_order_release);
-        mover.touch(0, (size_t)Rq);                      // this thread is worker 0
+        mover.touch(0);                                  // this thread is worker 0
         hipError_t cerr = hipSuccess;
         for (int g = 0; g < n_groups; ++g) {
             const hipError_t e = hipEventSynchronize(ws.evCopied[g]);

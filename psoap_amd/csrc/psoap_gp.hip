@@ -382,6 +382,25 @@ extern "C" int psoap_dag_plan(int B, int P, int workers, void* out, long long ma
     return 0;
 }
 
+// One matrix with Mt appended column tiles (predict) and, when Ms > 0, the Ms x Ms tiles of their Schur complement as
+// tasks of the same launch (DAG_SCHUR).  scheme: -1 automatic, 0 throughput, 1 latency.
+extern "C" int psoap_dag_plan_aug(int P, int Mt, int Ms, int workers, int scheme, void* out, long long max_tasks,
+                                  long long* n_tasks, long long* n_slots, long long* n_ctrs, unsigned int* queue_first)
+{
+    if (P < 1 || Mt < 0 || Ms < 0 || Ms > Mt || P + Mt > 255 || workers < 1 || !n_tasks)
+        FAIL("psoap_dag_plan_aug: bad arguments");
+    DagPlan plan = dag_build_tasks(1, P, workers, scheme, Mt, Ms);
+    *n_tasks = (long long)plan.tasks.size();
+    if (n_slots) *n_slots = plan.n_slots;
+    if (n_ctrs) *n_ctrs = plan.n_ctrs;
+    if (queue_first) memcpy(queue_first, plan.queues.first, sizeof plan.queues.first);
+    if (out) {
+        const long long n = max_tasks < *n_tasks ? max_tasks : *n_tasks;
+        memcpy(out, plan.tasks.data(), sizeof(DagTask) * n);
+    }
+    return 0;
+}
+
 // The same for a heterogeneous batch: matrix b has Ps[b] block rows.
 extern "C" int psoap_dag_plan_multi(int B, const int* Ps, int workers, void* out, long long max_tasks,
                                     long long* n_tasks, long long* n_slots, long long* n_ctrs,
@@ -1265,6 +1284,21 @@ extern "C" int psoap_predictor_run(psoap_predictor* p, int mode, int c, int N, i
     int status = 0;
     const int rc = predict_run(p->ws, mode, c, N, M, lwl, fl, sigma, nullptr, nullptr, lwl_pred, mu_c, gp, mu_out,
                                Sigma_out, &status, g_err);
+    if (status_out) *status_out = status;
+    return rc;
+}
+
+// mean and diag(Sigma) only (see psoap_chunk_predict_var)
+extern "C" int psoap_predictor_run_var(psoap_predictor* p, int mode, int c, int N, int M, const double* lwl,
+                                       const double* fl, const double* sigma, const double* lwl_pred, const double* mu_c,
+                                       const double* gp, double* mu_out, double* var_out, int* status_out)
+{
+    if (!p || !fl || !sigma || !var_out) FAIL("psoap_predictor_run_var: bad arguments");
+    if (int rc = predict_check(mode, c, N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
+    if (int rc = enter_device(p->device)) return rc;
+    int status = 0;
+    const int rc = predict_run(p->ws, mode, c, N, M, lwl, fl, sigma, nullptr, nullptr, lwl_pred, mu_c, gp, mu_out,
+                               nullptr, &status, g_err, var_out);
     if (status_out) *status_out = status;
     return rc;
 }

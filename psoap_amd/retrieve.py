@@ -45,6 +45,18 @@ def retrieve_components(model, chunk, parameters, n_pix_predict=None, get_Sigma=
     M = int(n_pix_predict) if n_pix_predict is not None else 2 * int(chunk.n_pix)
     lwl_predict = np.linspace(np.min(lwls[0]), np.max(lwls[0]), num=M)
     pred = [lwl_predict] * c
+    if isinstance(get_Sigma, str):
+        # get_Sigma="diag": the per-component means and standard deviations only -- what the scripts plot and save as
+        # f.npy / g.npy / h.npy -- without the (c M)^2 covariance matrix (psoap_predictor_run_var)
+        if get_Sigma != "diag":
+            raise ValueError('get_Sigma must be True, False or "diag"')
+        mu, var = covariance.predict_components_var(lwls, fl, sigma, pred, [0.0] * c, p_gp)
+        out = {"wl_predict": np.exp(lwl_predict), "lwl_predict": lwl_predict, "mu": mu, "Sigma": None, "lwls": lwls}
+        sd = np.sqrt(var)
+        for k in range(c):
+            out["mu_" + _NAMES[k]] = mu[k * M:(k + 1) * M]
+            out["sigma_" + _NAMES[k]] = sd[k * M:(k + 1) * M]
+        return out
     if c == 1:
         res = covariance.predict_f(lwls[0], fl, sigma, lwl_predict, *p_gp, mu_GP=0.0)
         mu, Sigma = res

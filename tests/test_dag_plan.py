@@ -184,3 +184,63 @@ def test_chain_bound_batches_get_one_workgroup_per_compute_unit():
     assert pick([64], Mt=24) == 512                      # predict at the retrieve shape: the appended columns are work
     assert pick([5], cus=256, mx=256) == 256             # a device that admits one workgroup per CU anyway
     assert pick([47], cus=304, mx=608) == 304
+
+
+@pytest.mark.parametrize("P,Mt,Ms,scheme", [(1, 2, 2, 1), (2, 3, 3, 1), (9, 4, 4, 1), (64, 24, 24, 1), (47, 5, 5, 0),
+                                            (16, 6, 3, 1), (20, 24, 24, -1)])
+def test_schur_tiles_of_the_augmented_launch(P, Mt, Ms, scheme):
+    """predict: the Ms x Ms upper tiles of Sigma = A - W^T W as tasks of the factorisation's own launch.  Every tile is a
+    chain of PARTs over [0, P-1) plus a final over the last panel; the chain ping-pongs between a slot pair of its own;
+    every wait (the predecessor in the chain, the block row a part needs) is satisfied by a smaller ticket."""
+    from psoap_amd import _lib
+    L = _lib.load()
+    SCHUR = 3
+    n, slots, ctrs = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+    first = (ctypes.c_uint32 * 9)()
+    assert L.psoap_dag_plan_aug(P, Mt, Ms, 512, scheme, None, 0, ctypes.byref(n), ctypes.byref(slots), ctypes.byref(ctrs), first) == 0
+    tasks = np.zeros(n.value, dtype=TASK)
+    assert L.psoap_dag_plan_aug(P, Mt, Ms, 512, scheme, tasks.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n),
+                                ctypes.byref(slots), ctypes.byref(ctrs), first) == 0
+    base = np.zeros(0, dtype=TASK)
+    nb = ctypes.c_longlong()
+    assert L.psoap_dag_plan_aug(P, Mt, 0, 512, scheme, None, 0, ctypes.byref(nb), None, None, None) == 0
+    ty = tasks["type"] & TYPE_MASK
+    chain = (tasks["type"] & CHAIN) != 0
+    schur = (tasks["q"] >= P)
+    assert schur.sum() == n.value - nb.value            # nothing else changes in the list
+    assert np.all(chain[schur]) and np.all(tasks["j"][schur] >= tasks["q"][schur]) and np.all(tasks["j"][schur] < P + Ms)
+    assert (ty[schur] == SCHUR).sum() == Ms * (Ms + 1) // 2 and not np.any(ty[~schur] == SCHUR)
+    # the last ticket that finishes a block row: a task over [pa, pb) may only be handed out behind the tasks of rows < pb
+    row_last = {}
+    for t, k in enumerate(tasks):
+        if k["q"] < P and ty[t] != PART:
+            row_last[int(k["q"])] = max(row_last.get(int(k["q"]), -1), t)
+    seen_pairs = {}
+    for i in range(Ms):
+        for j in range(i, Ms):
+            sel = np.where(schur & (tasks["q"] == P + i) & (tasks["j"] == P + j))[0]
+            parts = [t for t in sel if ty[t] == PART]
+            fin = [t for t in sel if ty[t] == SCHUR]
+            assert len(fin) == 1 and all(t < fin[0] for t in parts)
+            assert parts == sorted(parts) and [int(tasks["S"][t]) for t in parts] == list(range(len(parts)))
+            assert int(tasks["S"][fin[0]]) == len(parts) + 1 and int(tasks["pa"][fin[0]]) == P - 1 and int(tasks["pb"][fin[0]]) == P
+            # the parts tile [0, P-1) without gaps, every one at least one panel long
+            edges = [(int(tasks["pa"][t]), int(tasks["pb"][t])) for t in parts]
+            assert all(a < b for a, b in edges)
+            assert [a for a, _ in edges] == ([0] + [b for _, b in edges[:-1]] if edges else [])
+            assert (edges[-1][1] if edges else 0) == P - 1
+            # one arrival counter per tile, one even/odd slot pair per chain
+            assert len({int(tasks["ctr"][t]) for t in sel}) == 1
+            if parts:
+                pair = int(tasks["slot"][parts[0]]) >> 1
+                assert seen_pairs.setdefault(pair, (i, j)) == (i, j)
+                for t in parts:
+                    assert int(tasks["slot"][t]) >> 1 == pair and (int(tasks["slot"][t]) & 1) == (int(tasks["S"][t]) & 1)
+                assert int(tasks["slot"][fin[0]]) == int(tasks["slot"][parts[-1]]) and int(tasks["slot"][fin[0]]) < slots.value
+            # block rows a task reads are finished by smaller tickets
+            for t in list(parts) + fin:
+                for row in range(int(tasks["pa"][t]), int(tasks["pb"][t])):
+                    assert row_last[row] < t, (i, j, t, row)
+    # no other chain shares a Schur tile's slot pair
+    others = np.where(~schur & chain & (ty == PART))[0]
+    assert not ({int(tasks["slot"][t]) >> 1 for t in others} & set(seen_pairs))

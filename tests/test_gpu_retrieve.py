@@ -44,6 +44,11 @@ def test_retrieve_matches_oracle_pipeline(oracle, tmp_path, model, c, seed):
     np.testing.assert_allclose(res["mu"], mu_o, rtol=0, atol=1e-9)
     np.testing.assert_allclose(res["Sigma"], Sig_o, rtol=0, atol=1e-9)
     np.testing.assert_allclose(res["mu_g"], mu_o[M:2 * M], rtol=0, atol=1e-9)
+    # variance-only form: the same per-component curves, no covariance matrix
+    res_d = retrieve.retrieve_components(model, ch, pars, get_Sigma="diag")
+    assert res_d["Sigma"] is None and np.array_equal(res_d["mu"], res["mu"])
+    for k in "fgh"[:c]:
+        np.testing.assert_allclose(res_d["sigma_" + k], res["sigma_" + k], rtol=0, atol=1e-9)
     retrieve.save_components(res, str(tmp_path / "plots"))
     f = np.load(tmp_path / "plots" / "f.npy")
     assert f.shape == (3, M) and np.array_equal(f[0], res["wl_predict"]) and np.array_equal(f[1], res["mu_f"])
