@@ -257,7 +257,6 @@ struct PredictWs {
     Grow<unsigned char> Dag;
     Grow<DagTask> Tasks;
     Grow<DagMat> Mat;
-    Grow<double, true> hSigma;   // pinned bounce buffer of the Sigma download
     Grow<double, true> hSmall;   // pinned: colx / m0 staging, mu
     // task list cache
     int plan_P = -1, plan_Mt = -1, plan_workers = -1, plan_scheme = -2, plan_Ms = -1;
@@ -265,22 +264,12 @@ struct PredictWs {
     int workers = 0, n_cus = 0;   // persistent workgroups the device admits; compute units
     hipStream_t stream = nullptr;
     hipEvent_t ev[5] = {};
-    // Sigma download: groups of tile rows travel to a pinned buffer on a copy stream while later groups are still
-    // being computed; host threads move finished groups into the caller's (pageable) array
-    static constexpr int SIGMA_GROUPS = 8;
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t evRows[SIGMA_GROUPS] = {}, evCopied[SIGMA_GROUPS] = {};
     Grow<double> Var, Prior, Rowx, Diag;
     PredictTimes times;
     ~PredictWs()
     {
         if (stream) (void)hipStreamDestroy(stream);
-        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         for (auto e : ev)
-            if (e) (void)hipEventDestroy(e);
-        for (auto e : evRows)
-            if (e) (void)hipEventDestroy(e);
-        for (auto e : evCopied)
             if (e) (void)hipEventDestroy(e);
     }
 };
@@ -333,82 +322,47 @@ inline void factor_augmented(hipStream_t st, double* dK, size_t ld, int P, int M
 // mode 0: components (predict_f_g / predict_f_g_h); 1: sum (predict_f_g_sum / _h_sum); 2: predict_f
 // dFl_res / dSig_res: the data and noise vectors already resident on the device (a chunk handle's), or
 // nullptr -> fl / sigma are uploaded into the workspace.
-// Host side of the Sigma download.  The caller's array is pageable and, coming from numpy, freshly mapped: every page
-// faults on first touch.  A few threads (a) touch its pages while the GPU is still factoring, then (b) move the row
-// groups out of the pinned buffer as the copy stream delivers them -- group g while group g+1 is on the wire.
-// (Round 2 let the runtime stage the whole 75 MB of the retrieve shape after the product: 4.1 ms at ~18 GB/s.)
-struct SigmaMover {
-    double* dst = nullptr;
-    const double* src = nullptr;
-    size_t row_doubles = 0;
-    int n_groups = 0;
-    int group_rows[PredictWs::SIGMA_GROUPS + 1] = {};   // first row of every group, then the end
-    std::atomic<int> ready{0};        // groups delivered so far
-    std::atomic<int> layout_known{0};
-    std::atomic<int> abort{0};
-    std::vector<std::thread> pool;
-    int n_threads = 1;
+// Host side of the Sigma download.  The caller's array is pageable and, coming from numpy, freshly mapped; a plain D2H
+// into it is staged by the runtime at 6-25 GB/s with a large spread (3-12 ms for the 75 MB of the retrieve shape).  The
+// array is therefore page-locked IN PLACE (hipHostRegister: 2.6-3.1 ms, first-touch faults included) by a helper
+// thread while the GPU is still factoring, the copy then runs at the link rate (1.4 ms) straight into it, and the
+// registration is dropped afterwards (10 us).  (Round 3 first built a pinned bounce buffer emptied by 16 host threads:
+// 1.7 ms on one box, 3.7 ms on another -- NUMA placement of buffer and threads.)  Small outputs skip all that.
+struct SigmaPin {
+    double* ptr = nullptr;
+    size_t bytes = 0;
+    int device = 0;
+    std::thread th;
+    std::atomic<int> ok{0};
+    bool started = false;
+    static constexpr size_t MIN_BYTES = (size_t)4 << 20;
 
-    void share(int tix, int row0, int row1, int& a0, int& a1) const
+    void start(double* out, size_t n_bytes, int dev)
     {
-        const int rows = row1 - row0;
-        a0 = row0 + (int)((long long)rows * tix / n_threads);
-        a1 = row0 + (int)((long long)rows * (tix + 1) / n_threads);
+        if (n_bytes < MIN_BYTES) return;
+        ptr = out;
+        bytes = n_bytes;
+        device = dev;
+        started = true;
+        th = std::thread([this] {
+            if (hipSetDevice(device) == hipSuccess && hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess)
+                ok.store(1, std::memory_order_release);
+        });
     }
-    // first touch of exactly the rows this thread will fill later (program order then puts every touch before the data:
-    // with any other division a late-starting thread would zero a word of rows another thread has already filled)
-    void touch(int tix)
+    // -> true when the array is page-locked (the copy may then be asynchronous on any stream)
+    bool wait()
     {
-        const size_t step = 4096 / sizeof(double);
-        for (int g = 0; g < n_groups; ++g) {
-            int a0, a1;
-            share(tix, group_rows[g], group_rows[g + 1], a0, a1);
-            for (size_t i = (size_t)a0 * row_doubles; i < (size_t)a1 * row_doubles; i += step) dst[i] = 0.0;
-        }
+        if (started && th.joinable()) th.join();
+        return ok.load(std::memory_order_acquire) != 0;
     }
-    void work(int tix)
+    void release()
     {
-        touch(tix);
-        while (!layout_known.load(std::memory_order_acquire)) {
-            if (abort.load(std::memory_order_relaxed)) return;
-            std::this_thread::yield();
-        }
-        for (int g = 0; g < n_groups; ++g) {
-            while (ready.load(std::memory_order_acquire) <= g) {
-                if (abort.load(std::memory_order_relaxed)) return;
-                std::this_thread::yield();
-            }
-            int a0, a1;
-            share(tix, group_rows[g], group_rows[g + 1], a0, a1);
-            if (a1 > a0)
-                memcpy(dst + (size_t)a0 * row_doubles, src + (size_t)a0 * row_doubles,
-                       sizeof(double) * (size_t)(a1 - a0) * row_doubles);
-        }
+        if (started && th.joinable()) th.join();
+        if (ok.load()) (void)hipHostUnregister(ptr);
+        ok.store(0);
+        started = false;
     }
-    // rows x cols output, delivered in groups of tile rows (128 rows each): the layout is fixed here, before any thread runs
-    void start(double* out, size_t rows, size_t cols, int tile_rows)
-    {
-        dst = out;
-        row_doubles = cols;
-        n_groups = tile_rows < PredictWs::SIGMA_GROUPS ? tile_rows : PredictWs::SIGMA_GROUPS;
-        for (int g = 0; g <= n_groups; ++g) {
-            const long long r = (long long)tile_rows * g / n_groups * NB;
-            group_rows[g] = (int)(r < (long long)rows ? r : (long long)rows);
-        }
-        const unsigned hw = std::thread::hardware_concurrency();
-        n_threads = (int)(hw >= 32 ? 16 : (hw >= 8 ? 4 : 1));
-        for (int t = 1; t < n_threads; ++t) pool.emplace_back([this, t] { work(t); });
-    }
-    void finish()
-    {
-        for (auto& th : pool) th.join();
-        pool.clear();
-    }
-    ~SigmaMover()
-    {
-        abort.store(1);
-        finish();
-    }
+    ~SigmaPin() { release(); }
 };
 
 // var_out (optional): diag(Sigma) alone -- R doubles instead of R^2, and no N R^2 product
@@ -418,7 +372,7 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
                        std::string& err, double* var_out = nullptr)
 {
     const auto t_begin = std::chrono::steady_clock::now();
-    SigmaMover mover;     // declared first: its destructor joins the threads on every return path
+    SigmaPin pin;         // declared first: its destructor joins the helper thread and drops the registration on every return path
     const int Npad = round_up(N, NB), P = Npad / NB;
     const bool transposed_mean = (mode == 1 && c == 3);  // covariance.py:294 uses V12.T in the mean
     if (transposed_mean && M != N) {
@@ -452,12 +406,12 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         PR_TRY(hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
         for (auto& e : ws.ev) PR_TRY(hipEventCreate(&e));
     }
-    if (Sigma_out) mover.start(Sigma_out, (size_t)Rq, (size_t)Rq, Rq_pad / NB);
-    if (Sigma_out && !ws.copy_stream) {
-        PR_TRY(hipStreamCreateWithFlags(&ws.copy_stream, hipStreamNonBlocking));
-        for (auto& e : ws.evRows) PR_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto& e : ws.evCopied) PR_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (Sigma_out) {
+        int dev_now = 0;
+        PR_TRY(hipGetDevice(&dev_now));
+        pin.start(Sigma_out, sizeof(double) * (size_t)Rq * Rq, dev_now);
     }
+
     hipStream_t st = ws.stream;
     PR_TRY(ws.K.need((size_t)Npad * ld));
     PR_TRY(ws.W.need((size_t)2 * NB * NB));
@@ -631,11 +585,10 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
     PR_TRY(hipMemcpyAsync(h_mu, dMu, sizeof(double) * Rq, hipMemcpyDeviceToHost, st));
     PR_TRY(hipMemcpyAsync(h_acc, dAcc, sizeof(MatAcc), hipMemcpyDeviceToHost, st));
 
-    int n_groups = 0;
+    bool sigma_direct = false;
     if (Sigma_out) {
         const int St = Rq_pad / NB;
         PR_TRY(ws.S.need((size_t)Rq_pad * Rq_pad));
-        PR_TRY(ws.hSigma.need((size_t)Rq * Rq));
         double* dS = ws.S;
         if (!fused_sigma) {
             // prior covariance of the prediction, upper tiles only: k_syrk_sub mirrors the result
@@ -657,30 +610,19 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
             }
             PR_TRY(hipGetLastError());
             // Sigma = A - W^T W: one launch -- every tile is one K = Npad loop and all of them fit the device at once, so they
-            // all finish together (launching tile rows one after the other serialises them: measured 2.2 -> 10.5 ms).  The
-            // download follows in row groups on the copy stream: each group lands in the pinned buffer and is moved on into
-            // the caller's array by host threads while the next group is on the wire.
+            // all finish together (launching tile rows one after the other serialises them: measured 2.2 -> 10.5 ms)
             hipLaunchKernelGGL(k_syrk_sub_sym, dim3(St * (St + 1) / 2), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, dK + Npad, ld,
                                Npad, dS, (size_t)Rq_pad, St, 0);
             PR_TRY(hipGetLastError());
         }
         PR_TRY(hipEventRecord(ws.ev[3], st));           // the device work of the call ends here
-        PR_TRY(hipEventRecord(ws.evRows[0], st));
-        PR_TRY(hipStreamWaitEvent(ws.copy_stream, ws.evRows[0], 0));
-        n_groups = mover.n_groups;
-        for (int g = 0; g < n_groups; ++g) {
-            const int row0 = mover.group_rows[g], row1 = mover.group_rows[g + 1];
-            if (row1 > row0) {
-                if (Rq == Rq_pad)
-                    PR_TRY(hipMemcpyAsync(ws.hSigma.p + (size_t)row0 * Rq, dS + (size_t)row0 * Rq_pad,
-                                          sizeof(double) * (size_t)(row1 - row0) * Rq, hipMemcpyDeviceToHost, ws.copy_stream));
-                else
-                    PR_TRY(hipMemcpy2DAsync(ws.hSigma.p + (size_t)row0 * Rq, sizeof(double) * Rq, dS + (size_t)row0 * Rq_pad,
-                                            sizeof(double) * Rq_pad, sizeof(double) * Rq, (size_t)(row1 - row0),
-                                            hipMemcpyDeviceToHost, ws.copy_stream));
-            }
-            PR_TRY(hipEventRecord(ws.evCopied[g], ws.copy_stream));
-        }
+        // the download, queued right behind the product on the same stream: into the page-locked caller's array when the
+        // registration went through (it did its work under the factorisation), through the runtime's staging otherwise
+        const bool locked = pin.wait();
+        if (locked)
+            PR_TRY(hipMemcpy2DAsync(Sigma_out, sizeof(double) * Rq, dS, sizeof(double) * Rq_pad, sizeof(double) * Rq, (size_t)Rq,
+                                    hipMemcpyDeviceToHost, st));
+        sigma_direct = locked;
     }
     if (var_out) {
         // diag(Sigma) = diag(A) - column norms of W: the prior variances are the squared amplitudes of the components
@@ -706,26 +648,6 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         PR_TRY(hipMemcpyAsync(h_prior, ws.Var, sizeof(double) * Rq, hipMemcpyDeviceToHost, st));
     }
     if (!Sigma_out) PR_TRY(hipEventRecord(ws.ev[3], st));
-    if (Sigma_out) {
-        mover.src = ws.hSigma.p;
-        mover.layout_known.store(1, std::memory_order_release);
-        mover.touch(0);                                  // this thread is worker 0
-        hipError_t cerr = hipSuccess;
-        for (int g = 0; g < n_groups; ++g) {
-            const hipError_t e = hipEventSynchronize(ws.evCopied[g]);
-            if (e != hipSuccess && cerr == hipSuccess) cerr = e;
-            mover.ready.store(g + 1, std::memory_order_release);
-            int a0, a1;
-            mover.share(0, mover.group_rows[g], mover.group_rows[g + 1], a0, a1);
-            if (a1 > a0)
-                memcpy(Sigma_out + (size_t)a0 * Rq, ws.hSigma.p + (size_t)a0 * Rq, sizeof(double) * (size_t)(a1 - a0) * Rq);
-        }
-        mover.finish();
-        if (cerr != hipSuccess) {
-            err = std::string("predict: Sigma download: ") + hipGetErrorString(cerr);
-            return 1;
-        }
-    }
     PR_TRY(hipStreamSynchronize(st));
     if (use_dag) {
         unsigned int dag_err = 0;
@@ -735,6 +657,10 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
             return 1;
         }
     }
+    if (Sigma_out && !sigma_direct)
+        PR_TRY(hipMemcpy2D(Sigma_out, sizeof(double) * Rq, ws.S, sizeof(double) * Rq_pad, sizeof(double) * Rq, Rq,
+                           hipMemcpyDeviceToHost));
+    pin.release();
     *status = (h_acc->info != 0.0) ? 1 : 0;
     memcpy(mu_out, h_mu, sizeof(double) * Rq);
     if (var_out) memcpy(var_out, h_mu + Rq_pad + 8, sizeof(double) * Rq);

@@ -7,12 +7,13 @@ def one(pattern):
     return g[0] if g else None
 
 print(f"# rocprofv3 summary {tag}\n")
-print("Command profiled: `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras` on one MI355X (ROCm 7.2): 32 walkers x SB2")
+print("Command profiled: `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-strong` on one MI355X (ROCm 7.2): 32 walkers x SB2")
 print("N=6000 per step, so every k_chol_dag dispatch is the headline launch: 1 + 1 warm-up, 5 timed (H2D of the next")
 print("proposals under the evaluation), 1 + 5 proposals-resident, 1 event-profiled.  The k_stream_* / k_mfma_f64_peak /")
 print("k_tile_engine_bench kernels are the micro-benchmarks behind `measured_peak`.  The second trace (`trace_full`) is the")
 print("default `bench.py` with its side legs: the staged step that times k_fill_sym, predict at the retrieve shape")
-print("(k_chol_dag<3, true, true> + k_syrk_sub_sym), 8 chunks x 32 walkers in one launch, the lnprob(p) and sampler legs.\n")
+print("(k_chol_dag<3, true, true>, which since round 3 also computes Sigma as Schur-complement tasks), the configs[3] strong leg")
+print("(8 chunks x 32 walkers in one launch of k_chol_dag<2, false, false>: the one long dispatch of that kernel), the lnprob(p) and sampler legs.\n")
 f = one("trace/**/*kernel_stats.csv")
 if f:
     print("## --kernel-trace --stats\n")
