@@ -99,8 +99,10 @@ def compile_once(flags: list[str], out_dir: str) -> tuple[str, str]:
     return so, os.path.join(out_dir, asm[0])
 
 
-def compile_checked(extra: list[str], out_dir: str, verbose: bool = False) -> tuple[str, str, dict]:
-    """Walk FLAG_LADDER until the device assembly is clean -> (library, assembly, build record), all inside out_dir."""
+def compile_checked(extra: list[str], out_dir: str, verbose: bool = False, scan=asmcheck.scan_exec_restore
+                    ) -> tuple[str, str, dict]:
+    """Walk FLAG_LADDER until the device assembly is clean -> (library, assembly, build record), all inside out_dir.
+    ``scan``: the assembly check (tests substitute one that rejects a chosen rung)."""
     tried = []
     for k, rung in enumerate(FLAG_LADDER):
         flags = extra + rung
@@ -110,7 +112,7 @@ def compile_checked(extra: list[str], out_dir: str, verbose: bool = False) -> tu
             print(f"{hipcc()} {' '.join(BASE_FLAGS + flags)} psoap_gp.hip")
         so, asm_path = compile_once(flags, sub)
         with open(asm_path) as fh:
-            hits = asmcheck.scan_exec_restore(fh.read())
+            hits = scan(fh.read())
         tried.append((flags, hits))
         if hits:
             if verbose:

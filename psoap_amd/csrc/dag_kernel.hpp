@@ -49,8 +49,20 @@ struct alignas(64) MatFlags {
                       // needs all of row q)
     int next_done;    // q + 1 once U(q, q+1), the tile right of the diagonal, is final (fused into DIAG(q))
     int off1_ready;   // q + 1 once tile (q, q+1) holds its fully updated value, ready for the strip solve
-    int pad[10];
+    int step_w[4];    // per wave of the fused diagonal task: 8 q + b + 1 once its share of step b of block q (the row
+                      // of U11 and W_bb^T the strip solves need) is in the matrix's mailbox (dag_pss)
+    int pad[6];
 };
+static_assert(sizeof(MatFlags) == 64, "one cache line per matrix");
+
+// Mailbox of a matrix, right behind its two Wt tiles: the fused diagonal task publishes, step by step, what a strip
+// solve needs of block row b of the diagonal block it is factoring -- the blocks U_bJ (J > b) of U11's row b and
+// V_b = W_bb^T -- so that the strip solves of the row can FOLLOW the factorisation instead of starting behind it.
+//   slot (q & 1, b, J), J = 0..7: U_bJ (written for J > b);  J = 8: V_b.   Blocks in the accumulator-linear form.
+constexpr int MB_BLOCKS = 9;
+constexpr size_t MB_DOUBLES = (size_t)2 * 8 * MB_BLOCKS * 256;
+constexpr size_t WT_STRIDE = (size_t)2 * NB * NB + MB_DOUBLES;     // doubles per matrix: two Wt tiles + the mailbox
+__host__ __device__ inline size_t mb_slot(int q, int b, int J) { return ((size_t)((q & 1) * 8 + b) * MB_BLOCKS + J) * 256; }
 
 constexpr int DAG_QUEUES = 8;   // one ticket queue per XCD (MI355X: 8 XCDs, each with its own 4 MiB L2)
 
@@ -227,8 +239,10 @@ struct DagMat {
     int N, Npad, P, ld;
 };
 
-template <int C, bool AUG>
-__device__ __forceinline__ void dag_store_updated(const Tile& t, double* __restrict__ dest, size_t ldd, int k0, int j0,
+// INPLACE: the result replaces the accumulators instead of going to memory (the strip solve that follows works on the
+// tile in registers: dag_pss)
+template <int C, bool AUG, bool INPLACE = false>
+__device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ dest, size_t ldd, int k0, int j0,
                                                   const double* __restrict__ lw, const GpDev& g, double dsum,
                                                   const double* __restrict__ sigma, int N, double scale,
                                                   int Npad, const DagAug& aug, double* __restrict__ mirror = nullptr)
@@ -301,7 +315,9 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* __restr
                 const int jc = tile_col(wc, n, lane);                          // column inside the tile
                 const int ic = tile_row(wr, m, lane, r);                       // row inside the tile
                 const double out = scale * v - t.acc[m][n][r];
-                if (AUG && mirror) {
+                if (INPLACE) {
+                    t.acc[m][n][r] = out;
+                } else if (AUG && mirror) {
                     // a tile of Sigma, written twice: as it is and transposed.  A DIAGONAL tile (mirror == dest) comes out of
                     // the update with its lower-left quadrant missing (the symmetric update skips it): only the elements
                     // on and above the diagonal are stored, each also at its mirror position.
@@ -315,6 +331,33 @@ __device__ __forceinline__ void dag_store_updated(const Tile& t, double* __restr
             }
         }
     }
+}
+
+// the accumulators as a tile in memory (after dag_store_updated<.., INPLACE>): the same element map and mirror rule
+template <bool AUG>
+__device__ __forceinline__ void dag_store_tile(const Tile& t, double* __restrict__ dest, size_t ldd, double* __restrict__ mirror)
+{
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int lane = tid_ & 63, wave = tid_ >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ic = tile_row(wr, m, lane, r), jc = tile_col(wc, n, lane);
+                const double out = t.acc[m][n][r];
+                if (AUG && mirror) {
+                    if (mirror != dest || ic <= jc) {
+                        dest[(size_t)ic * ldd + (size_t)jc] = out;
+                        mirror[(size_t)jc * ldd + (size_t)ic] = out;
+                    }
+                } else {
+                    dest[(size_t)ic * ldd + (size_t)jc] = out;
+                }
+            }
 }
 
 // accumulators -= partial tiles prev[0 .. n_prev), in slot order (row-major 128 x 128 workspace slots).
@@ -447,7 +490,15 @@ PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double*
 #ifdef PSOAP_NO_SPINE
     potrf_blocked<0, true>(Km, ld, k0, Wm, Rv, acc, prev, Km + (size_t)(k0 - NB) * ld + k0, wait_dep, tl);
 #else
+    // (the mailbox sits behind the matrix's two Wt tiles: Wm is tile q & 1 of them)
+    double* wt0 = Wm - (size_t)(q & 1) * NB * NB;
+#ifndef PSOAP_FOLLOW
     potrf_spine_fused(Km, ld, k0, Wm, Rv, acc, prev, Km + (size_t)(k0 - NB) * ld + k0, wait_dep, tl, sm);
+    (void)wt0;
+#else
+    potrf_spine_fused(Km, ld, k0, Wm, Rv, acc, prev, Km + (size_t)(k0 - NB) * ld + k0, wait_dep, tl, sm,
+                      ps::SpinePub{wt0 + 2 * NB * NB + mb_slot(q, 0, 0), f->step_w, 8 * q});
+#endif
 #endif
     dag_drain();
     if (tl && threadIdx.x == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
@@ -470,6 +521,168 @@ PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double*
     }
     __builtin_amdgcn_s_setprio(0);
     if (tl && threadIdx.x == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
+}
+
+// ---- Progressive strip solve ("following", scheme 2) -- EXPERIMENTAL, compiled only with -DPSOAP_FOLLOW (round 3: the
+// results are right and bit-stable, and against the same build's scheme 1 it gains 7-14 % on single evaluations and small
+// batches, but merely having the path in the latency-scheme kernels makes hipcc's code for every OTHER task 12-24 %
+// slower -- N = 6000, B = 1: 3.56 ms without it, 4.42 / 4.10 ms (scheme 1 / 2) with it -- so the shipped build leaves it
+// out; DESIGN.md 8 has the measurements and what to try next).
+// Tile (q, j), j > q, stays in the accumulators after its update and is solved
+// block row by block row BEHIND the fused diagonal task that is factoring block q, instead of after it:
+//     step b:  X_b  = W_bb T_b                 (V_b = W_bb^T from the mailbox; the waves that own row block b)
+//              T_I -= U_bI^T X_b,  I > b        (U_bI from the mailbox, X_b through LDS; every wave, its row blocks)
+// -- the recurrence the in-block factorisation applies to its own right-hand-side column, carried on for the 8 column
+// blocks of this tile.  Same MFMA count as the product with the explicit inverse (1152 per tile), but no W operand to
+// stage, no store / drain / reload of the tile between update and solve, and the last row block is final one step
+// after the factorisation's last step.  A task that arrives late simply runs through the published steps.
+// All 256 threads; LDS: two row buffers of 8 blocks (32 KB) at the start of the dynamic array + one int behind them.
+template <class BoxPtr>
+__device__ __forceinline__ int dag_wait_steps(MatFlags* f, int target, DagCtl* ctl, BoxPtr box)
+{
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {            // wave 0: lanes 0..3 poll one wave's flag each
+        int v = 0;
+        long long spins = 0;
+        for (;;) {
+            int x = 0x7fffffff;
+            if (lane < 4) x = dag_peek(&f->step_w[lane]);
+            x = min(x, __shfl_xor(x, 1, 64));
+            x = min(x, __shfl_xor(x, 2, 64));
+            v = __builtin_amdgcn_readfirstlane(x);
+            if (v >= target) break;
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > DAG_MAX_SPINS) {
+                if (lane == 0 && __hip_atomic_fetch_or(&ctl->error, 1u, PSOAP_RLX_AGENT) == 0u) {
+                    __hip_atomic_store(&ctl->pad[0], 6u, PSOAP_RLX_AGENT);
+                    __hip_atomic_store(&ctl->pad[1], (unsigned int)target, PSOAP_RLX_AGENT);
+                    __hip_atomic_store(&ctl->pad[2], (unsigned int)v, PSOAP_RLX_AGENT);
+                }
+                v = 0x7fffffff;        // give up waiting: the results are invalid and reported as such
+                break;
+            }
+        }
+        if (lane == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *box = v;
+        }
+    }
+    __syncthreads();
+    return *box;
+}
+
+__device__ __forceinline__ d4 dag_mb_load(const double* __restrict__ mbq, int b, int J, int lane)
+{
+    const double* src = mbq + ((size_t)b * MB_BLOCKS + J) * 256;
+    d4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = src[r * 64 + lane];
+    return v;
+}
+
+// A function of its own, like dag_diag_fast and for the same reason (inlined, the kernel around it spills in every other
+// task); the tile travels through the stack (128 registers out, 128 in: ~1 us against the ~10 us of the store / drain /
+// reload it replaces), LDS is reached through the pointers the kernel hands over (gemm_core.hpp, SmemArg).
+template <int C, bool AUG>
+__device__ __attribute__((noinline)) void dag_pss(const Tile* tp, double* Km, int ld, int k0, int j0,
+                                                  const double* __restrict__ mbq, MatFlags* f, int q, DagCtl* ctl,
+                                                  double* Rv, int Npad, lds_double* smem, lds_double* zk, lds_double* colsum,
+                                                  const double* lw, const double* gp, const double* sigma, int N,
+                                                  double scale, const DagAug* aug)
+{
+    Tile t = *tp;
+    const SmemArg sm{smem};
+    {
+        // the accumulators become the tile: T = scale * K(i, j) - acc  (the arithmetic of every other task's store routine)
+        GpDev g;
+        load_gp(gp, C, g);
+        double dsum = g.a2[0];
+        {
+#pragma clang fp contract(off)
+            for (int c = 1; c < C; ++c) dsum = dsum + g.a2[c];
+        }
+        dag_store_updated<C, AUG, true>(t, nullptr, 0, k0, j0, lw, g, dsum, sigma, N, scale, Npad, *aug, nullptr);
+    }
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    lds_int* box = (lds_int*)sm.ptr(2 * 8 * 256);
+    int avail = 0;                              // steps of the factorisation known to be in the mailbox
+    // (rolled over the two halves of the block rows: the register slots stay statically indexed -- row block b is slot
+    // b & 3 of the wave row b >> 2 -- at half the code)
+#pragma unroll 1
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int b = 4 * hb + mb;
+        if (b >= avail) avail = dag_wait_steps(f, 8 * q + b + 1, ctl, box) - 8 * q;
+        const int buf = (b & 1) * 8 * 256;
+        // the operands of this step that come from the factorisation (issued together: one memory latency per step)
+        d4 V = {0.0, 0.0, 0.0, 0.0}, U[4];
+        if (wr == hb) V = dag_mb_load(mbq, b, 8, lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (4 * wr + m > b) U[m] = dag_mb_load(mbq, b, 4 * wr + m, lane);
+        // X_b: the waves whose row blocks include b (wave-uniform)
+        if (wr == hb) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const d4 res = pb::mma16(V, t.acc[mb][n], d4{0.0, 0.0, 0.0, 0.0});
+                t.acc[mb][n] = res;
+                pb::store_blk(buf + (4 * wc + n) * 256, lane, res, sm);
+            }
+        }
+        __syncthreads();
+        // T_I -= U_bI^T X_b on this wave's row blocks below b
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (4 * wr + m > b) {
+                const d4 xs = d4{-U[m][0], -U[m][1], -U[m][2], -U[m][3]};
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    t.acc[m][n] = pb::mma16(xs, pb::load_blk(buf + (4 * wc + n) * 256, lane, sm), t.acc[m][n]);
+            }
+    }
+    // the solved tile goes out; the right-hand side update needs z of this block row, final once the factorisation
+    // has written it (potrf_done)
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                Km[(size_t)(k0 + tile_row(wr, m, lane, r)) * ld + j0 + tile_col(wc, n, lane)] = t.acc[m][n][r];
+    dag_wait_ge(&f->potrf_done, q + 1, ctl, 7u);
+    if (tid_ < NB) zk[tid_] = Rv[k0 + tid_];
+    __syncthreads();
+    double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double z = zk[tile_row(wr, m, lane, r)];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) part[n] = fma(t.acc[m][n][r], z, part[n]);
+        }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        part[n] += __shfl_xor(part[n], 16, 64);
+        part[n] += __shfl_xor(part[n], 32, 64);
+    }
+    if (wr == 1 && lane < 16) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) colsum[tile_col(wc, n, lane)] = part[n];
+    }
+    __syncthreads();
+    if (wr == 0 && lane < 16 && j0 < Npad) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int col = tile_col(wc, n, lane);
+            Rv[j0 + col] -= part[n] + colsum[col];
+        }
+    }
 }
 
 // LAT: the instantiation launched for task lists of the latency scheme; only it contains the fused diagonal
@@ -585,16 +798,42 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         // round-2 forms of the LAT kernels (thread-id staging, plain strip solve): tools/lat_variants.py only -- with
         // -DPSOAP_WAIT_BEFORE_CALL this is the code shape on which hipcc produces the defect of DESIGN.md 3.4
         if constexpr (LAT)
-            dag_update(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl, (task.type & DAG_WAITNEXT) != 0,
+            dag_update(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl, ttype == DAG_DIAG && (task.type & DAG_WAITNEXT) != 0,
                        tlog ? tlog + ticket * 8 : nullptr);
         else
 #endif
-        dag_update<true>(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl, (task.type & DAG_WAITNEXT) != 0,
+        // (DAG_WAITNEXT on a DIAG task: its last panel needs only the tile right of the diagonal above; on an OFF task
+        // the bit means "follow the factorisation" and the last panel needs the whole block row above, as always)
+        dag_update<true>(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl, ttype == DAG_DIAG && (task.type & DAG_WAITNEXT) != 0,
                          tlog ? tlog + ticket * 8 : nullptr, wave_s);
         if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 5] = __builtin_amdgcn_s_memrealtime();
         if (!preload && n_wait > 0) dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);
         if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 6] = __builtin_amdgcn_s_memrealtime();
         dag_sub_partials(t, prev, n_prev);
+#ifdef PSOAP_FOLLOW
+        if (LAT && ttype == DAG_OFF && (task.type & DAG_WAITNEXT)) {
+            // scheme 2: the strip solve follows the factorisation of block q step by step, on the tile in registers; the
+            // covariance evaluation that turns the accumulators into the tile happens inside the routine as well (a second
+            // instance of it in the kernel body makes hipcc spill in every other task)
+            __syncthreads();     // the K-loop's LDS is free: every wave has left it
+            {
+                const Tile handed = t;     // a copy whose address leaves: `t` itself must stay a register object for the K-loops
+                const DagAug aug_copy = aug;
+                const bool carries_k = chain ? task.S <= 1 : true;
+                dag_pss<C, AUG>(&handed, Km, ld, k0, j0, mat.Wt + 2 * NB * NB + mb_slot(q, 0, 0), f, q, ctl, Rv, Npad,
+                                dag_opaque_lds(psoap_smem), dag_opaque_lds(vec1), dag_opaque_lds(vec2), mat.lw, mat.gp,
+                                mat.sigma, N, carries_k ? 1.0 : 0.0, &aug_copy);
+            }
+            dag_drain();
+            if (threadIdx.x == 0) {
+                dag_release_fence();
+                if (task.type & DAG_NOSOLVE) __hip_atomic_store(&f->next_done, q + 1, PSOAP_RLX_AGENT);   // tile (q, q+1)
+                dag_task_done(f, q, ntasks_row);
+            }
+            if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+            continue;
+        }
+#endif
         {
             GpDev g;
             load_gp(mat.gp, C, g);
@@ -708,8 +947,8 @@ inline int dag_split_factor(int tasks_in_row, int q, int workers, int scheme)
     // PSOAP_DAG_SPLIT_PCT / PSOAP_DAG_SPLIT_MIN override both numbers (experiments).
     static const int env_pct = getenv("PSOAP_DAG_SPLIT_PCT") ? atoi(getenv("PSOAP_DAG_SPLIT_PCT")) : 0;
     static const int env_min = getenv("PSOAP_DAG_SPLIT_MIN") ? atoi(getenv("PSOAP_DAG_SPLIT_MIN")) : 0;
-    const int pct = env_pct > 0 ? env_pct : (scheme == 1 ? 50 : 100);
-    const int minp = env_min > 0 ? env_min : (scheme == 1 ? 4 : 2);
+    const int pct = env_pct > 0 ? env_pct : (scheme >= 1 ? 50 : 100);
+    const int minp = env_min > 0 ? env_min : (scheme >= 1 ? 4 : 2);
     int S = 1;
     while (S < 8 && tasks_in_row * S * 100 < workers * pct && minp * S <= q) S *= 2;
     return S;
@@ -731,7 +970,7 @@ inline int dag_split_factor(int tasks_in_row, int q, int workers, int scheme)
 inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first, int pb_last, int nsplit, int scheme,
                      unsigned char final_flags = 0)
 {
-    const bool chain = (scheme == 1) && nsplit > 1;
+    const bool chain = (scheme >= 1) && nsplit > 1;
     const int nparts = chain ? nsplit : nsplit - 1;                 // PART tasks
     const unsigned int ctr = (nparts > 0) ? plan.n_ctrs++ : 0u;
     if (chain) plan.n_slots += plan.n_slots & 1u;                   // a chain ping-pongs between an even/odd slot pair
@@ -850,13 +1089,18 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
         const int S_off = dag_split_factor((int)row_tiles, q, workers, scheme);
         // latency scheme: DIAG(q) also solves the tile right of the diagonal (DAG_FUSED) whenever a next
         // diagonal tile exists, and DIAG(q >= 1) waits only for that tile of the row above (DAG_WAITNEXT)
-        auto fused = [&](int b) { return scheme == 1 && q + 1 < Ps[b]; };
+        // scheme 2 ("following"): from block row 2 on -- where the diagonal task is the fused fast one, which publishes its
+        // block rows step by step -- the strip solves FOLLOW the factorisation (dag_pss: DAG_WAITNEXT on an OFF task),
+        // the diagonal task solves nothing itself, and the strip solve of tile (q, q+1) publishes next_done (DAG_NOSOLVE
+        // on a following OFF task).  Rows 0 and 1 keep the forms of scheme 1.
+        const bool following = (scheme == 2) && q >= 2;
+        auto fused = [&](int b) { return scheme >= 1 && !following && q + 1 < Ps[b]; };
         // 1. DIAG finals of this row
         if (q <= 1) {
             for (int b : mats)
                 if (q < Ps[b])
                     dag_emit(plan, DAG_DIAG, b, q, q, 0, q, 1, scheme,
-                             (unsigned char)((fused(b) ? DAG_FUSED : 0) | (scheme == 1 && q == 1 ? DAG_WAITNEXT : 0)));
+                             (unsigned char)((fused(b) ? DAG_FUSED : 0) | (scheme >= 1 && q == 1 ? DAG_WAITNEXT : 0)));
         } else {
             for (const DagTask& t : early_final[q]) plan.tasks.push_back(t);
         }
@@ -868,7 +1112,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
             for (int b : mats) {
                 if (q + 1 >= Ps[b]) continue;
                 const unsigned int ctr = plan.n_ctrs++;
-                const bool chain = (scheme == 1);
+                const bool chain = (scheme >= 1);
                 if (chain) plan.n_slots += plan.n_slots & 1u;
                 const unsigned int slot0 = plan.n_slots;
                 const unsigned char flag = chain ? DAG_CHAIN : 0;
@@ -903,7 +1147,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
                 DagTask fin{};
                 fin.type = DAG_DIAG | flag;
                 if (chain) fin.type |= DAG_WAITNEXT;
-                if (chain && q + 2 < Ps[b]) fin.type |= DAG_FUSED;
+                if (chain && q + 2 < Ps[b] && !(scheme == 2 && q + 1 >= 2)) fin.type |= DAG_FUSED;
                 fin.b = (unsigned short)b;
                 fin.q = fin.j = (unsigned char)(q + 1);
                 fin.S = (unsigned char)(n_parts + 1);
@@ -918,7 +1162,8 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
         for (int b : mats)
             for (int j = q + 1; j < Ps[b] + Mt && q < Ps[b]; ++j)
                 dag_emit(plan, DAG_OFF, b, q, j, 0, q, S_off, scheme,
-                         (unsigned char)((j == q + 1 && fused(b)) ? DAG_NOSOLVE : 0));
+                         following ? (unsigned char)(DAG_WAITNEXT | ((j == q + 1 && q + 1 < Ps[b]) ? DAG_NOSOLVE : 0))
+                                   : (unsigned char)((j == q + 1 && fused(b)) ? DAG_NOSOLVE : 0));
     }
     if (Ms > 0)
         for (int b : mats) dag_emit_schur(plan, b, Ps[b], Ms);
@@ -955,6 +1200,9 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
     DagPlan plan;
     const int B = (int)Ps.size();
     if (scheme < 0) scheme = dag_auto_scheme(Ps);
+#ifndef PSOAP_FOLLOW
+    if (scheme == 2) scheme = 1;       // the following scheme needs the kernels built with -DPSOAP_FOLLOW
+#endif
     plan.scheme = scheme;
     // workgroups of XCDs whose own queue is empty steal, so the workers are shared by the queues in use
     const int used = B < DAG_QUEUES ? (B > 0 ? B : 1) : DAG_QUEUES;
@@ -964,7 +1212,7 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
         std::vector<int> mats;
         for (int b = g; b < B; b += DAG_QUEUES) mats.push_back(b);
         dag_build_queue(plan, mats, Ps, per_queue, (B + DAG_QUEUES - 1) / DAG_QUEUES, scheme, Mt, Ms);
-        if (scheme == 1) {
+        if (scheme >= 1) {
             // Latency scheme: hand the tasks out in order of READINESS instead of block row by block row.
             // A task over panels [pa, pb) can run once block row pb-1 is finished ("stage" pb); within a
             // stage the diagonal final (the in-block Cholesky everybody waits for) comes first, then the
@@ -976,7 +1224,7 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
             // front of it: every wait still targets a smaller ticket)
             auto cls = [](const DagTask& t) {
                 const int ty = t.type & DAG_TYPE_MASK;
-                if (ty == DAG_OFF && (t.type & DAG_NOSOLVE)) return -1;
+                if (ty == DAG_OFF && (t.type & DAG_NOSOLVE) && !(t.type & DAG_WAITNEXT)) return -1;   // update-only: in front of its DIAG
                 return ty == DAG_DIAG ? 0 : (ty == DAG_OFF ? 1 : 2);      // PART and DAG_SCHUR: whatever is left of a stage
             };
             std::stable_sort(plan.tasks.begin() + plan.queues.first[g], plan.tasks.end(),

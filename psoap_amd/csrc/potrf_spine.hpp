@@ -67,11 +67,52 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 __device__ __forceinline__ d4 neg(const d4& v) { return d4{-v[0], -v[1], -v[2], -v[3]}; }
 
+// Where the fused diagonal task publishes its progress for the strip solves that follow it (dag_kernel.hpp: mailbox,
+// dag_pss).  mb == nullptr: nothing is published.
+struct SpinePub {
+    double* mb;        // this block's half of the matrix's mailbox: slot (b, J) at ((b * 9) + J) * 256
+    int* step_w;       // MatFlags::step_w
+    int base;          // 8 q
+};
+// one block, accumulator-linear, with agent-scope (write-through) stores: no L2 write-back is needed before the flag
+__device__ __forceinline__ void pub_block(const SpinePub& pub, int b, int J, int lane, const d4& v)
+{
+    double* dst = pub.mb + ((size_t)b * 9 + J) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) __hip_atomic_store(dst + r * 64 + lane, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// This wave's share of steps < n_steps is in the mailbox.  `younger`: how many of its vector-memory operations were
+// issued AFTER the stores the flag vouches for (they may still be in flight: stores complete in issue order, and these
+// waves issue nothing but stores inside the step loop).  Waiting for everything instead stalled every wave of the
+// factorisation by ~1.3 us per step -- the write-through stores take longer than a step to be acknowledged.
+__device__ __forceinline__ void pub_flag(const SpinePub& pub, int wave, int n_steps, int lane, int younger = 0)
+{
+    switch (younger) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+    if (lane == 0) __hip_atomic_store(pub.step_w + wave, pub.base + n_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// blocks of U11's row I that worker wave W publishes (its owned blocks right of the diagonal)
+constexpr int pub_count(int W, int I)
+{
+    int n = 0;
+    for (int s = 0; s < 3; ++s) {
+        const int J = ((W - 1 - I) % 3 + 3) % 3 + 3 * s;
+        if (J <= 8 && J != I && J > I && J < 8) ++n;
+    }
+    return n;
+}
+
 // ---- the three worker waves ------------------------------------------------------------------------------
 template <int W, class WaitFn, class SM>
 __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, double* Rv,
                                        const double* __restrict__ part, const double* __restrict__ strip,
-                                       WaitFn& wait_dep, SM sm)
+                                       WaitFn& wait_dep, SM sm, const SpinePub& pub)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = lane >> 4, c = lane & 15;
@@ -157,6 +198,7 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
                         const int J = col0(W, I) + 3 * s;
                         pb::store_blk(base + J * BLK, lane, res[s], sm);
                         blk[3 * I + s] = res[s];
+                        if (pub.mb && J > I && J < 8) pub_block(pub, I, J, lane, res[s]);   // U_bJ for the followers
                     }
             }
         }
@@ -208,9 +250,13 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
                 }
         }
 #endif
+        // this wave's blocks of rows < bb are in the mailbox by now; younger than those: row bb's blocks (phase B above) and,
+        // in wave 1, the four stores of W_(bb-1) at the end of the previous step
+        if (pub.mb && bb > 0) pub_flag(pub, W, bb, lane, 4 * pub_count(W, bb) + (W == 1 ? 4 : 0));
         // W_bb itself (parked by the spine in the row buffer) goes out to memory from here, off the spine's chain
         if (W == 1) pb::emit_w(pb::load_blk(row_off(bb) + bb * BLK, lane, sm), bb, bb, lane, 1, Wm, sm);
     }
+    if (pub.mb) pub_flag(pub, W, 8, lane);
     double zz = 0.0;
 #ifndef PSOAP_SPINE_INLOOP_OUT
     // ---- outputs of this wave: its blocks of W (strictly lower), of U11 (strictly upper) and of z
@@ -246,7 +292,7 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
 // ---- wave 0 --------------------------------------------------------------------------------------------
 // factor diagonal block bb (d), park W_bb and W_bb^T (the X operand of W_bb Y) in LDS, announce
 template <class SM>
-__device__ __forceinline__ void spine_factor(d4& d, int bb, int lane, int& bad, double& logsum, SM sm)
+__device__ __forceinline__ void spine_factor(d4& d, int bb, int lane, int& bad, double& logsum, SM sm, const SpinePub& pub)
 {
     const int q = lane >> 4, c = lane & 15;
     d4 wdiag;
@@ -260,6 +306,7 @@ __device__ __forceinline__ void spine_factor(d4& d, int bb, int lane, int& bad, 
     for (int r = 0; r < 4; ++r) v[r] = sm[pb::OFF_TR + c * 17 + q + 4 * r];
     __builtin_amdgcn_wave_barrier();
     pb::store_blk(OFF_V, lane, v, sm);
+    if (pub.mb) pub_block(pub, bb, 8, lane, v);                  // V_b = W_bb^T for the followers
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_store(flag_ptr(sm), bb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     double dg = 1.0;
@@ -270,7 +317,8 @@ __device__ __forceinline__ void spine_factor(d4& d, int bb, int lane, int& bad, 
 
 template <class WaitFn, class SM>
 __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* __restrict__ part,
-                                      const double* __restrict__ strip, WaitFn& wait_dep, unsigned long long* tl, SM sm)
+                                      const double* __restrict__ strip, WaitFn& wait_dep, unsigned long long* tl, SM sm,
+                                      const SpinePub& pub)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = lane >> 4, c = lane & 15;
@@ -305,7 +353,7 @@ __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* 
     __syncthreads();   // [S0]
     int bad = 0;
     double logsum = 0.0;
-    spine_factor(d[0], 0, lane, bad, logsum, sm);
+    spine_factor(d[0], 0, lane, bad, logsum, sm, pub);
 #pragma unroll 1
     for (int bb = 0; bb < 7; ++bb) {
         lds_barrier();     // [S1 + bb] block row bb is published
@@ -316,7 +364,7 @@ __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* 
             if (I == bb + 1) {
                 const d4 xi = pb::load_blk(base + I * BLK, lane, sm);
                 d[I] = pb::mma16(neg(xi), xi, d[I]);
-                spine_factor(d[I], I, lane, bad, logsum, sm);
+                spine_factor(d[I], I, lane, bad, logsum, sm, pub);
             }
         // ---- deferred: the other diagonal blocks, while the workers finish row bb+1
 #pragma unroll
@@ -325,8 +373,10 @@ __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* 
                 const d4 xi = pb::load_blk(base + I * BLK, lane, sm);
                 d[I] = pb::mma16(neg(xi), xi, d[I]);
             }
+        if (pub.mb) pub_flag(pub, 0, bb + 1, lane, 4);  // V_0 .. V_bb are published; only V_(bb+1), just issued, may be in flight
     }
     lds_barrier();         // [S1 + 7]
+    if (pub.mb) pub_flag(pub, 0, 8, lane);
     if (tl && lane == 0) tl[6] = __builtin_amdgcn_s_memrealtime();
     // ---- outputs: the diagonal blocks of U11; log-determinant share and the not-positive-definite flag for
     // the caller (through LDS: the accumulators are updated after the closing barrier)
@@ -350,13 +400,14 @@ __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* 
 template <class WaitFn, class SM = SmemKernel>
 __device__ __forceinline__ void potrf_spine_fused(double* Km, int ld, int k0, double* Wm, double* Rv, MatAcc* acc,
                                                   const double* __restrict__ part, const double* __restrict__ strip,
-                                                  WaitFn wait_dep, unsigned long long* tl = nullptr, SM sm = SM())
+                                                  WaitFn wait_dep, unsigned long long* tl = nullptr, SM sm = SM(),
+                                                  ps::SpinePub pub = ps::SpinePub{nullptr, nullptr, 0})
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) ps::spine(Km, ld, k0, part, strip, wait_dep, tl, sm);
-    else if (wave == 1) ps::worker<1>(Km, ld, k0, Wm, Rv, part, strip, wait_dep, sm);
-    else if (wave == 2) ps::worker<2>(Km, ld, k0, Wm, Rv, part, strip, wait_dep, sm);
-    else ps::worker<3>(Km, ld, k0, Wm, Rv, part, strip, wait_dep, sm);
+    if (wave == 0) ps::spine(Km, ld, k0, part, strip, wait_dep, tl, sm, pub);
+    else if (wave == 1) ps::worker<1>(Km, ld, k0, Wm, Rv, part, strip, wait_dep, sm, pub);
+    else if (wave == 2) ps::worker<2>(Km, ld, k0, Wm, Rv, part, strip, wait_dep, sm, pub);
+    else ps::worker<3>(Km, ld, k0, Wm, Rv, part, strip, wait_dep, sm, pub);
     __syncthreads();   // all outputs issued, the reductions are in LDS
     if (threadIdx.x == 0) {
         const double l = sm[pb::OFF_RED + 0];

@@ -414,7 +414,7 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
 
     hipStream_t st = ws.stream;
     PR_TRY(ws.K.need((size_t)Npad * ld));
-    PR_TRY(ws.W.need((size_t)2 * NB * NB));
+    PR_TRY(ws.W.need(WT_STRIDE));
     PR_TRY(ws.R.need(Npad));
     PR_TRY(ws.Acc.need(1));
     PR_TRY(ws.Lwl.need((size_t)c * N));
@@ -535,7 +535,7 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
     hipLaunchKernelGGL((k_chol_dag<CC, true, LAT>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, ws.Mat.p,  \
                        ws.Tasks.p, plan.queues, fl_, reinterpret_cast<int*>(ws.Dag.p + arrive_off), ws.Ws.p, ctl_,  \
                        (unsigned long long*)nullptr, aug)
-        const bool lat = plan.scheme == 1;
+        const bool lat = plan.scheme >= 1;
         if (c == 1) { if (lat) PSOAP_LAUNCH_AUG(1, true); else PSOAP_LAUNCH_AUG(1, false); }
         else if (c == 2) { if (lat) PSOAP_LAUNCH_AUG(2, true); else PSOAP_LAUNCH_AUG(2, false); }
         else { if (lat) PSOAP_LAUNCH_AUG(3, true); else PSOAP_LAUNCH_AUG(3, false); }

@@ -213,8 +213,8 @@ static int chunk_alloc(psoap_chunk* h, const double* fl, const double* sigma)
     HIP_TRY(hipMalloc(&h->dFl, sizeof(double) * N));
     HIP_TRY(hipMalloc(&h->dSigma, sizeof(double) * N));
     HIP_TRY(hipMalloc(&h->dK, sizeof(double) * nb * h->mat_stride));
-    HIP_TRY(hipMalloc(&h->dWt, sizeof(double) * nb * 2 * NB * NB));
-    HIP_TRY(hipMemset(h->dWt, 0, sizeof(double) * nb * 2 * NB * NB));   // the strictly upper part of every W stays zero
+    HIP_TRY(hipMalloc(&h->dWt, sizeof(double) * nb * WT_STRIDE));       // two Wt tiles + the mailbox per matrix
+    HIP_TRY(hipMemset(h->dWt, 0, sizeof(double) * nb * WT_STRIDE));   // the strictly upper part of every W stays zero
     HIP_TRY(hipMalloc(&h->dR, sizeof(double) * nb * h->Npad));
     HIP_TRY(hipMalloc(&h->dAcc, sizeof(MatAcc) * nb));
     HIP_TRY(hipMalloc(&h->dOut, sizeof(double) * nb));
@@ -659,7 +659,7 @@ static void fill_mats(const psoap_chunk* h, const BatchSlot& sl, DagMat* out)
         DagMat m{};
         m.K = h->dK + (size_t)b * h->mat_stride;
         m.R = h->dR + (size_t)b * h->Npad;
-        m.Wt = h->dWt + (size_t)b * 2 * NB * NB;
+        m.Wt = h->dWt + (size_t)b * WT_STRIDE;
         m.lw = sl.dLwl + (size_t)b * sl.C * h->N;
         m.gp = sl.dGp + (size_t)b * 2 * sl.C;
         m.sigma = h->dSigma;
@@ -767,7 +767,7 @@ static int eval_dag(psoap_chunk* h)
     hipLaunchKernelGGL((k_chol_dag<CC, false, LAT>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, sl.dMats, \
                        h->dTasks, h->plan_queues, fl_, reinterpret_cast<int*>(h->dDag + h->arrive_off), h->dWs,   \
                        ctl_, h->dTlog, DagAug{P, 0, 0, nullptr})
-        const bool lat = h->plan_scheme == 1;
+        const bool lat = h->plan_scheme >= 1;
         if (C == 1) { if (lat) PSOAP_LAUNCH_DAG(1, true); else PSOAP_LAUNCH_DAG(1, false); }
         else if (C == 2) { if (lat) PSOAP_LAUNCH_DAG(2, true); else PSOAP_LAUNCH_DAG(2, false); }
         else { if (lat) PSOAP_LAUNCH_DAG(3, true); else PSOAP_LAUNCH_DAG(3, false); }
@@ -1064,7 +1064,7 @@ extern "C" int psoap_group_eval(psoap_group* g)
     hipLaunchKernelGGL((k_chol_dag<CC, false, LAT>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, g->dMats, \
                        g->dTasks, g->queues, fl_, reinterpret_cast<int*>(g->dDag + g->arrive_off), g->dWs, ctl_,  \
                        (unsigned long long*)nullptr, DagAug{0, 0, 0, nullptr})
-        const bool lat = g->scheme == 1;
+        const bool lat = g->scheme >= 1;
         if (C == 1) { if (lat) PSOAP_LAUNCH_GROUP(1, true); else PSOAP_LAUNCH_GROUP(1, false); }
         else if (C == 2) { if (lat) PSOAP_LAUNCH_GROUP(2, true); else PSOAP_LAUNCH_GROUP(2, false); }
         else { if (lat) PSOAP_LAUNCH_GROUP(3, true); else PSOAP_LAUNCH_GROUP(3, false); }

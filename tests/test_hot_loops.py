@@ -51,16 +51,28 @@ def test_no_vector_write_ahead_of_an_exec_restore():
 
 
 @needs_hipcc
-def test_build_falls_back_when_the_default_flags_show_the_defect(tmp_path):
-    """With the round-2 code shape (the PART-chain wait as a one-lane poll right in front of the call of dag_diag_fast,
-    round-2 staging forms in the LAT kernels) this compiler produces the defect in k_chol_dag<3, true, true>: the build
-    must reject that binary and take the next rung of the ladder (diagonal routine inlined), which is clean."""
-    from psoap_amd import build
-    shape = ["-DPSOAP_WAIT_BEFORE_CALL", "-DPSOAP_LAT_PLAIN"]
-    so, asm, rec = build.compile_checked(shape, str(tmp_path))
-    assert rec["fallback_rung"] == 1
-    assert rec["rejected"] == [{"flags": shape, "kernels": ["k_chol_dag<3,true,true>"]}]
+def test_build_falls_back_when_the_default_flags_show_the_defect(tmp_path, monkeypatch):
+    """The build's flag ladder: a binary whose assembly shows the defect is rejected and the next rung (diagonal routine
+    inlined: no call, nothing parked around one) is taken and recorded; if every rung shows it, the build fails.  Which
+    source shapes make THIS compiler produce the defect changes with every edit of the kernels (the 68-build matrix in
+    profiles/ is the record of that), so the ladder is driven here by a scanner that reports the real faulting join block
+    for the first rung only."""
+    from psoap_amd import asmcheck, build
+    with open(os.path.join(ROOT, "profiles", "r3_lat_fault_joinblock.s")) as fh:
+        faulty = "_ZN5psoap10k_chol_dagILi3ELb1ELb1EEEv:\n\ts_cbranch_execz .LBB46_1318\n" + fh.read()
+    calls = []
+
+    def scan_first_rung_faulty(text):
+        calls.append(len(text))
+        return asmcheck.scan_exec_restore(faulty if len(calls) == 1 else text)
+
+    so, asm, rec = build.compile_checked([], str(tmp_path), scan=scan_first_rung_faulty)
+    assert len(calls) == 2 and rec["fallback_rung"] == 1
+    assert rec["rejected"] == [{"flags": [], "kernels": ["k_chol_dag<3,true,true>"]}]
     assert os.path.exists(so) and "-DPSOAP_DIAG_INLINE" in rec["flags"]
+    monkeypatch.setattr(build, "compile_once", lambda flags, out_dir: (so, asm))      # no third and fourth compile
+    with pytest.raises(build.BuildError, match="every flag set"):
+        build.compile_checked([], str(tmp_path / "all"), scan=lambda text: asmcheck.scan_exec_restore(faulty))
 
 
 def test_exec_restore_scanner_flags_the_faulting_join_block():
