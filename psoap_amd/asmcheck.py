@@ -43,6 +43,9 @@ def short(mangled: str | None) -> str:
     if m:
         return "k_chol_dag<%s,%s,%s>" % (m.group(1), "true" if m.group(2) == "1" else "false",
                                          "true" if m.group(3) == "1" else "false")
+    m = re.match(r"_ZN5psoap11dag_specialILi(\d)ELb([01])EEE", mangled or "")
+    if m:
+        return "dag_special<%s,%s>" % (m.group(1), "true" if m.group(2) == "1" else "false")
     return mangled or "?"
 
 
@@ -95,12 +98,13 @@ def scan_exec_restore(text: str):
 
 
 def scan_hot_loops(text: str):
-    """-> {kernel: (number of 64-MFMA K-loop stage blocks, scratch accesses inside them)} for every k_chol_dag"""
+    """-> {function: (number of 64-MFMA K-loop stage blocks, scratch accesses inside them)} for every k_chol_dag kernel
+    and every dag_special<C, AUG> (the out-of-line routine that runs the following strip-solve tasks, K-loops included)"""
     lines = text.split("\n")
     out = {}
     i = 0
     while i < len(lines):
-        m = re.match(r"^(_ZN5psoap10k_chol_dag\w+):", lines[i])
+        m = re.match(r"^(_ZN5psoap(?:10k_chol_dag|11dag_special)\w+):", lines[i])
         if not m:
             i += 1
             continue

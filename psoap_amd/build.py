@@ -25,10 +25,10 @@ HASH_PATH = LIB_PATH + ".srchash"                      # JSON: what the library 
 ASM_PATH = os.path.join(CSRC, "libpsoap_gp.device.s")   # device assembly of that build (kept for the CPU tests)
 
 BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
-# Flag sets tried in order until the device assembly is clean.  The second compiles the diagonal routine of the
-# latency-scheme kernels into the kernels (no function call, so no values parked around one): 2-5 % slower single
-# evaluations, and the form that never showed the defect.
-FLAG_LADDER = [[], ["-DPSOAP_DIAG_INLINE"]]
+# Flag sets tried in order until the device assembly is clean.  The second drops the out-of-line routines of the
+# latency-scheme kernels: no following strip solves, and the fused diagonal task compiled into the kernels (no function
+# call, so no values parked around one): 2-10 % slower single evaluations, and the form that never showed the defect.
+FLAG_LADDER = [[], ["-DPSOAP_NO_FOLLOW", "-DPSOAP_DIAG_INLINE"]]
 
 
 class BuildError(RuntimeError):

@@ -30,6 +30,13 @@
 #pragma once
 #include <stdlib.h>
 
+// The following scheme (scheme 2: strip solves that follow the factorisation step by step, dag_pss / dag_special) is part
+// of the build unless -DPSOAP_NO_FOLLOW is given (the build's fallback rung and the variant matrix of DESIGN.md 3.4 use
+// the older structure, in which the fused diagonal task is the only out-of-line routine).
+#if !defined(PSOAP_NO_FOLLOW) && !defined(PSOAP_FOLLOW)
+#define PSOAP_FOLLOW 1
+#endif
+
 #include <algorithm>
 #include <utility>
 #include <vector>
@@ -177,23 +184,23 @@ __device__ __forceinline__ void dag_task_done(MatFlags* f, int q, int ntasks_row
 
 // left-looking update over finished block rows [pa, pb) with look-ahead: all but the last panel
 // need rows_done >= pb-1, the last one rows_done >= pb
-template <bool SW = false>
+template <bool SW = false, class SM = SmemKernel, bool ROWMAP = false>
 __device__ __forceinline__ void dag_update(Tile& t, double* Km, int ld, int k0, int j0, int pa, int pb, MatFlags* f,
-                                           DagCtl* ctl, bool wait_next, unsigned long long* tl, int wave_s = -1)
+                                           DagCtl* ctl, bool wait_next, unsigned long long* tl, int wave_s = -1, SM sm = SM())
 {
     if (pb <= pa) return;
     const bool diag = (k0 == j0);
     if (pb - pa > 1) {
         dag_wait_ge(&f->rows_done, pb - 1, ctl, 1u);
         const size_t r0 = (size_t)pa * NB;
-        tile_gemm_tn<SW>(t, Km + r0 * ld + k0, (size_t)ld, Km + r0 * ld + j0, (size_t)ld, (pb - 1 - pa) * NB, diag, 0x7fffffff, wave_s);
+        tile_gemm_tn<SW, SM, ROWMAP>(t, Km + r0 * ld + k0, (size_t)ld, Km + r0 * ld + j0, (size_t)ld, (pb - 1 - pa) * NB, diag, 0x7fffffff, wave_s, sm);
     }
     // the last panel: the whole block row above, or (diagonal tile of the latency scheme) only its tile
     // right of the diagonal -- U(pb-1, pb), all this tile reads of that row
     dag_wait_ge(wait_next ? &f->next_done : &f->rows_done, pb, ctl, 2u);
     if (tl && threadIdx.x == 0) tl[4] = __builtin_amdgcn_s_memrealtime();
     const size_t r1 = (size_t)(pb - 1) * NB;
-    tile_gemm_tn<SW>(t, Km + r1 * ld + k0, (size_t)ld, Km + r1 * ld + j0, (size_t)ld, NB, diag, 0x7fffffff, wave_s);
+    tile_gemm_tn<SW, SM, ROWMAP>(t, Km + r1 * ld + k0, (size_t)ld, Km + r1 * ld + j0, (size_t)ld, NB, diag, 0x7fffffff, wave_s, sm);
 }
 
 // The ONE consumer of the accumulators.  Every task ends its update here:
@@ -241,7 +248,7 @@ struct DagMat {
 
 // INPLACE: the result replaces the accumulators instead of going to memory (the strip solve that follows works on the
 // tile in registers: dag_pss)
-template <int C, bool AUG, bool INPLACE = false>
+template <int C, bool AUG, bool INPLACE = false, bool ROWMAP = false>
 __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ dest, size_t ldd, int k0, int j0,
                                                   const double* __restrict__ lw, const GpDev& g, double dsum,
                                                   const double* __restrict__ sigma, int N, double scale,
@@ -278,7 +285,7 @@ __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ 
         int ii[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            ii[r] = k0 + tile_row(wr, m, lane, r);
+            ii[r] = k0 + (ROWMAP ? 16 * tile_rowblock(wr, m) + (lane >> 4) + 4 * r : tile_row(wr, m, lane, r));
             if (rowcross) {
                 const int e = ii[r] - Npad;        // the same index map as the columns: equal indices = the diagonal of A
 #pragma unroll
@@ -313,7 +320,7 @@ __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ 
                     v = (i == j) ? 1.0 : 0.0;
                 }
                 const int jc = tile_col(wc, n, lane);                          // column inside the tile
-                const int ic = tile_row(wr, m, lane, r);                       // row inside the tile
+                const int ic = ROWMAP ? 16 * tile_rowblock(wr, m) + (lane >> 4) + 4 * r : tile_row(wr, m, lane, r);   // row inside the tile
                 const double out = scale * v - t.acc[m][n][r];
                 if (INPLACE) {
                     t.acc[m][n][r] = out;
@@ -365,6 +372,7 @@ __device__ __forceinline__ void dag_store_tile(const Tile& t, double* __restrict
 // the store routine free of them (a load per element between its stores serialised on the memory
 // latency: 64 round trips, 44 us per tile).  A chain's final calls this BEFORE it waits for the block row
 // above -- its PARTs ran ahead -- so the running sum is read off the row-to-row path.
+template <bool ROWMAP = false>
 __device__ __forceinline__ void dag_sub_partials(Tile& t, const double* __restrict__ prev, int n_prev)
 {
     // (opaque copy of the thread id, as in dag_store_updated: otherwise the 64 per-lane element offsets below are
@@ -381,7 +389,8 @@ __device__ __forceinline__ void dag_sub_partials(Tile& t, const double* __restri
             for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    t.acc[m][n][r] -= ps[(size_t)tile_row(wr, m, lane, r) * NB + (size_t)tile_col(wc, n, lane)];
+                    t.acc[m][n][r] -= ps[(size_t)(ROWMAP ? 16 * tile_rowblock(wr, m) + (lane >> 4) + 4 * r : tile_row(wr, m, lane, r)) * NB +
+                                         (size_t)tile_col(wc, n, lane)];
     }
 }
 
@@ -455,12 +464,12 @@ __device__ __forceinline__ lds_double* dag_opaque_lds(double* shared_obj)
     asm volatile("" : "+s"(a));
     return (lds_double*)(uintptr_t)a;
 }
-#ifdef PSOAP_DIAG_INLINE
+#if defined(PSOAP_DIAG_INLINE) || defined(PSOAP_FOLLOW)
 #define PSOAP_DIAG_FN __device__ __forceinline__
 #else
 #define PSOAP_DIAG_FN __device__ __attribute__((noinline))
 #endif
-#if defined(PSOAP_DIAG_INLINE) || defined(PSOAP_DIAG_LDS_TABLE)
+#if (defined(PSOAP_DIAG_INLINE) || defined(PSOAP_DIAG_LDS_TABLE)) && !defined(PSOAP_FOLLOW)
 #define PSOAP_DIAG_SMEM(smem) SmemKernel()
 #else
 #define PSOAP_DIAG_SMEM(smem) SmemArg{smem}
@@ -523,11 +532,12 @@ PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double*
     if (tl && threadIdx.x == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
 }
 
-// ---- Progressive strip solve ("following", scheme 2) -- EXPERIMENTAL, compiled only with -DPSOAP_FOLLOW (round 3: the
-// results are right and bit-stable, and against the same build's scheme 1 it gains 7-14 % on single evaluations and small
-// batches, but merely having the path in the latency-scheme kernels makes hipcc's code for every OTHER task 12-24 %
-// slower -- N = 6000, B = 1: 3.56 ms without it, 4.42 / 4.10 ms (scheme 1 / 2) with it -- so the shipped build leaves it
-// out; DESIGN.md 8 has the measurements and what to try next).
+// ---- Progressive strip solve ("following", scheme 2; round 3).  Measured against scheme 1 (profiles/r3_follow_table.txt):
+// 6-10 % faster for single evaluations and batches of up to four matrices at N <= 4096, a tie at N = 6000, 3-5 % slower
+// beyond (a late task runs through the published steps at about the cost of the product with the explicit inverse,
+// and its row blocks are not balanced over the waves) -- dag_auto_scheme picks it accordingly.  The whole task lives in
+// the out-of-line routine dag_special: with any part of it in the kernel body, hipcc's code for every other task of the
+// latency-scheme kernels got 12-24 % slower.
 // Tile (q, j), j > q, stays in the accumulators after its update and is solved
 // block row by block row BEHIND the fused diagonal task that is factoring block q, instead of after it:
 //     step b:  X_b  = W_bb T_b                 (V_b = W_bb^T from the mailbox; the waves that own row block b)
@@ -585,7 +595,7 @@ __device__ __forceinline__ d4 dag_mb_load(const double* __restrict__ mbq, int b,
 // task); the tile travels through the stack (128 registers out, 128 in: ~1 us against the ~10 us of the store / drain /
 // reload it replaces), LDS is reached through the pointers the kernel hands over (gemm_core.hpp, SmemArg).
 template <int C, bool AUG>
-__device__ __attribute__((noinline)) void dag_pss(const Tile* tp, double* Km, int ld, int k0, int j0,
+__device__ __forceinline__ void dag_pss(const Tile* tp, double* Km, int ld, int k0, int j0,
                                                   const double* __restrict__ mbq, MatFlags* f, int q, DagCtl* ctl,
                                                   double* Rv, int Npad, lds_double* smem, lds_double* zk, lds_double* colsum,
                                                   const double* lw, const double* gp, const double* sigma, int N,
@@ -611,7 +621,9 @@ __device__ __attribute__((noinline)) void dag_pss(const Tile* tp, double* Km, in
     lds_int* box = (lds_int*)sm.ptr(2 * 8 * 256);
     int avail = 0;                              // steps of the factorisation known to be in the mailbox
     // (rolled over the two halves of the block rows: the register slots stay statically indexed -- row block b is slot
-    // b & 3 of the wave row b >> 2 -- at half the code)
+    // b & 3 of the wave row b >> 2 -- at half the code.  Measured and not kept: row blocks dealt to the wave rows by work
+    // -- {0, 1, 7, 6} / {2, 3, 5, 4}, 288 MFMAs per wave instead of 416 / 160, with the update's operand rows permuted to
+    // match -- together with the next step's operands requested a step early: 5-10 % SLOWER on single evaluations.)
 #pragma unroll 1
     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
@@ -647,13 +659,14 @@ __device__ __attribute__((noinline)) void dag_pss(const Tile* tp, double* Km, in
     }
     // the solved tile goes out; the right-hand side update needs z of this block row, final once the factorisation
     // has written it (potrf_done)
+    auto row_of = [&](int m, int r) { return tile_row(wr, m, lane, r); };
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int n = 0; n < 4; ++n)
-                Km[(size_t)(k0 + tile_row(wr, m, lane, r)) * ld + j0 + tile_col(wc, n, lane)] = t.acc[m][n][r];
+                Km[(size_t)(k0 + row_of(m, r)) * ld + j0 + tile_col(wc, n, lane)] = t.acc[m][n][r];
     dag_wait_ge(&f->potrf_done, q + 1, ctl, 7u);
     if (tid_ < NB) zk[tid_] = Rv[k0 + tid_];
     __syncthreads();
@@ -662,7 +675,7 @@ __device__ __attribute__((noinline)) void dag_pss(const Tile* tp, double* Km, in
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const double z = zk[tile_row(wr, m, lane, r)];
+            const double z = zk[row_of(m, r)];
 #pragma unroll
             for (int n = 0; n < 4; ++n) part[n] = fma(t.acc[m][n][r], z, part[n]);
         }
@@ -684,6 +697,70 @@ __device__ __attribute__((noinline)) void dag_pss(const Tile* tp, double* Km, in
         }
     }
 }
+
+#ifdef PSOAP_FOLLOW
+// ONE out-of-line routine for the two kinds of task that do not fit the kernel body -- the fused diagonal task and the
+// following strip solve -- behind ONE call site that takes ONE pointer: with a second call (and its two dozen arguments)
+// in the persistent loop, hipcc's allocation for the in-kernel strip solve broke down (spills in every stage of it).
+struct DagSpecialArgs {
+    int mode;                      // 0: fused diagonal task, 1: following strip solve
+    double* Km;
+    int ld, k0, j0;
+    double* Wm;
+    double* Rv;
+    MatAcc* acc;
+    const double* prev;
+    int Npad;
+    MatFlags* f;
+    DagCtl* ctl;
+    int q, ntasks_row, fused;
+    int* chain_ctr;
+    int chain_len;
+    lds_double *smem, *zk, *colsum;
+    unsigned long long* tl;
+    const double* mbq;
+    const double *lw, *gp, *sigma;
+    int N, pubnext;
+    double scale;
+    DagAug aug;
+    int pa, pb, n_wait, preload, n_prev;       // the following task does its own update (the task record's fields)
+    int* arrive_ctr;
+};
+
+template <int C, bool AUG>
+__device__ __attribute__((noinline)) void dag_special(const DagSpecialArgs* a)
+{
+    if (a->mode == 0) {
+        dag_diag_fast(a->Km, a->ld, a->k0, a->Wm, a->Rv, a->acc, a->prev, a->Npad, a->f, a->ctl, a->q, a->ntasks_row,
+                      a->fused != 0, a->chain_ctr, a->chain_len, a->smem, a->zk, a->colsum, a->tl);
+        return;
+    }
+    // the whole task: left-looking update (the kernel's own sequence: preloaded chain sum, K-loops, gathered partial sums),
+    // then the tile -- still in the accumulators -- is solved behind the factorisation
+    const SmemArg sm{a->smem};
+    const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    Tile t;
+    t.zero();
+    int n_prev = a->n_prev;
+    if (a->preload) {
+        dag_wait_ge(a->arrive_ctr, a->n_wait, a->ctl, 4u);
+        dag_sub_partials(t, a->prev, 1);
+        n_prev = 0;
+    }
+    dag_update<true, SmemArg>(t, a->Km, a->ld, a->k0, a->j0, a->pa, a->pb, a->f, a->ctl, false, a->tl, wave_s, sm);
+    if (!a->preload && a->n_wait > 0) dag_wait_ge(a->arrive_ctr, a->n_wait, a->ctl, 4u);
+    dag_sub_partials(t, a->prev, n_prev);
+    __syncthreads();     // the K-loop's LDS is free: every wave has left it
+    dag_pss<C, AUG>(&t, a->Km, a->ld, a->k0, a->j0, a->mbq, a->f, a->q, a->ctl, a->Rv, a->Npad, a->smem, a->zk, a->colsum,
+                    a->lw, a->gp, a->sigma, a->N, a->scale, &a->aug);
+    dag_drain();
+    if (threadIdx.x == 0) {
+        dag_release_fence();
+        if (a->pubnext) __hip_atomic_store(&a->f->next_done, a->q + 1, PSOAP_RLX_AGENT);   // tile (q, q+1) is final
+        dag_task_done(a->f, a->q, a->ntasks_row);
+    }
+}
+#endif
 
 // LAT: the instantiation launched for task lists of the latency scheme; only it contains the fused diagonal
 // fast path (dag_diag_fast).  With that path compiled into the one kernel, hipcc keeps a spilled value in the
@@ -778,6 +855,32 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         // chained PART: the predecessor's tile sits in the other slot of the even/odd pair
         const double* prev = wspace + (size_t)(is_part ? task.slot ^ 1u : task.slot) * SLOT;
         const bool preload = !is_part && chain && n_wait > 0;
+#ifdef PSOAP_FOLLOW
+        // (-DPSOAP_FOLLOW: both out-of-line task kinds go through dag_special, further down, at one call site)
+        const bool fast_diag = LAT && preload && ttype == DAG_DIAG && (task.type & DAG_WAITNEXT) && task.pb - task.pa == 1;
+        const bool follow = LAT && ttype == DAG_OFF && (task.type & DAG_WAITNEXT);
+        if (fast_diag || follow) {
+            // scheme 2's strip solves follow the factorisation of block q step by step, on the tile in registers; the
+            // whole task -- update, covariance evaluation, solve -- runs in the out-of-line routine
+            DagSpecialArgs args;
+            args.mode = fast_diag ? 0 : 1;
+            args.Km = Km; args.ld = ld; args.k0 = k0; args.j0 = j0; args.Wm = Wm; args.Rv = Rv; args.acc = mat.acc;
+            args.prev = prev; args.Npad = Npad; args.f = f; args.ctl = ctl; args.q = q; args.ntasks_row = ntasks_row;
+            args.fused = (task.type & DAG_FUSED) != 0; args.chain_ctr = &arrive[task.ctr]; args.chain_len = n_wait;
+            args.smem = dag_opaque_lds(psoap_smem); args.zk = dag_opaque_lds(vec1); args.colsum = dag_opaque_lds(vec2);
+            args.tl = tlog ? tlog + ticket * 8 : nullptr;
+            args.mbq = mat.Wt + 2 * NB * NB + mb_slot(q, 0, 0);
+            args.lw = mat.lw; args.gp = mat.gp; args.sigma = mat.sigma; args.N = N;
+            args.pubnext = (task.type & DAG_NOSOLVE) != 0;
+            args.scale = (chain ? task.S <= 1 : true) ? 1.0 : 0.0;
+            args.aug = aug;
+            args.pa = task.pa; args.pb = task.pb; args.n_wait = n_wait; args.preload = preload ? 1 : 0; args.n_prev = n_prev;
+            args.arrive_ctr = &arrive[task.ctr];
+            dag_special<C, AUG>(&args);
+            if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+            continue;
+        }
+#else
         if (LAT && preload && ttype == DAG_DIAG && (task.type & DAG_WAITNEXT) && task.pb - task.pa == 1) {
 #ifdef PSOAP_WAIT_BEFORE_CALL
             dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);   // round-2 placement, kept for tools/lat_variants.py only
@@ -787,6 +890,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
                           tlog ? tlog + ticket * 8 : nullptr);
             continue;
         }
+#endif
         t.zero();
         if (preload) {
             // the chain ran ahead (its PARTs need older block rows): normally no wait at all
@@ -810,30 +914,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         if (!preload && n_wait > 0) dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);
         if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 6] = __builtin_amdgcn_s_memrealtime();
         dag_sub_partials(t, prev, n_prev);
-#ifdef PSOAP_FOLLOW
-        if (LAT && ttype == DAG_OFF && (task.type & DAG_WAITNEXT)) {
-            // scheme 2: the strip solve follows the factorisation of block q step by step, on the tile in registers; the
-            // covariance evaluation that turns the accumulators into the tile happens inside the routine as well (a second
-            // instance of it in the kernel body makes hipcc spill in every other task)
-            __syncthreads();     // the K-loop's LDS is free: every wave has left it
-            {
-                const Tile handed = t;     // a copy whose address leaves: `t` itself must stay a register object for the K-loops
-                const DagAug aug_copy = aug;
-                const bool carries_k = chain ? task.S <= 1 : true;
-                dag_pss<C, AUG>(&handed, Km, ld, k0, j0, mat.Wt + 2 * NB * NB + mb_slot(q, 0, 0), f, q, ctl, Rv, Npad,
-                                dag_opaque_lds(psoap_smem), dag_opaque_lds(vec1), dag_opaque_lds(vec2), mat.lw, mat.gp,
-                                mat.sigma, N, carries_k ? 1.0 : 0.0, &aug_copy);
-            }
-            dag_drain();
-            if (threadIdx.x == 0) {
-                dag_release_fence();
-                if (task.type & DAG_NOSOLVE) __hip_atomic_store(&f->next_done, q + 1, PSOAP_RLX_AGENT);   // tile (q, q+1)
-                dag_task_done(f, q, ntasks_row);
-            }
-            if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-            continue;
-        }
-#endif
         {
             GpDev g;
             load_gp(mat.gp, C, g);
@@ -1179,6 +1259,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
 // more than one matrix; throughput beyond (N = 6000, B = 32: 39.2 vs 39.9 ms; N = 8192, B = 32: 95.0 vs 96.1).
 // (Readiness ordering was also tried for the throughput scheme: 800 -> 776 evals/s, not adopted.)
 constexpr int DAG_LATENCY_QUEUE_ROWS = 150;
+constexpr int DAG_FOLLOW_MAX_ROWS = 32;
 inline int dag_auto_scheme(const std::vector<int>& Ps)
 {
     long long rows[DAG_QUEUES] = {};
@@ -1193,7 +1274,15 @@ inline int dag_auto_scheme(const std::vector<int>& Ps)
         max_rows = rows[g] > max_rows ? rows[g] : max_rows;
         max_count = count[g] > max_count ? count[g] : max_count;
     }
-    return (max_rows <= DAG_LATENCY_QUEUE_ROWS || max_count <= 1) ? 1 : 0;
+    const int latency = (max_rows <= DAG_LATENCY_QUEUE_ROWS || max_count <= 1) ? 1 : 0;
+#ifdef PSOAP_FOLLOW
+    // following strip solves (scheme 2) where they were measured to win: up to four matrices of at most 32 block rows
+    // (N <= 4096): N = 2000, B = 1..4: 1.13 -> 1.04 ms; N = 4096, B = 1: 2.21 -> 2.08 ms
+    int Pmax = 0;
+    for (int P : Ps) Pmax = P > Pmax ? P : Pmax;
+    if (latency == 1 && Ps.size() <= 4 && Pmax <= DAG_FOLLOW_MAX_ROWS) return 2;
+#endif
+    return latency;
 }
 inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int scheme = -1, int Mt = 0, int Ms = 0)
 {

@@ -37,6 +37,12 @@ struct Staging {
     d2 a[4], b[4];
 };
 
+// Row blocks (16 rows) of a tile dealt to the two wave rows by the WORK a triangular solve has for them instead of by
+// position (0-3 / 4-7): wave row 0 owns {0, 1, 7, 6}, wave row 1 {2, 3, 5, 4} (slots 0..3) -- two from the top counted
+// up, two from the bottom counted down, so that a wave's four operand addresses are two scalar bases with fixed
+// offsets.  (ROWMAP) the update + following solve of dag_pss.
+__device__ __forceinline__ constexpr int tile_rowblock(int wr, int m) { return m < 2 ? 2 * wr + m : 7 - 2 * wr - (m - 2); }
+
 __device__ __forceinline__ void stage_load(Staging& s, const double* __restrict__ A, size_t lda,
                                            const double* __restrict__ B, size_t ldb, int k, int tid)
 {
@@ -89,8 +95,8 @@ __device__ __forceinline__ void stage_store(const Staging& s, int buf, int tid)
 }
 
 // m_first > 0 (wave-uniform): the wave's first m_first 16-row blocks issue no MFMA in this chunk
-template <bool PARTIAL_M = false>
-__device__ __forceinline__ void tile_mma_chunk(Tile& t, int buf, int wr, int wc, int lane, int m_first = 0)
+template <bool PARTIAL_M = false, class SM = SmemKernel, bool ROWMAP = false>
+__device__ __forceinline__ void tile_mma_chunk(Tile& t, int buf, int wr, int wc, int lane, int m_first = 0, SM sm = SM())
 {
     // the fragment offsets are recomputed per stage from the lane id (opaque to the optimiser) instead of
     // being hoisted out of the K-loop: as loop invariants they are the values hipcc spills first when the
@@ -102,15 +108,18 @@ __device__ __forceinline__ void tile_mma_chunk(Tile& t, int buf, int wr, int wc,
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     (void)lane;
     const int fr = l & 15, fk = l >> 4;
-    const int baseA = buf * LDS_BUFFER + fk * LDS_LD + wr * 64 + fr;
+    const int baseA = buf * LDS_BUFFER + fk * LDS_LD + (ROWMAP ? 32 * wr : wr * 64) + fr;
+    const int baseA2 = buf * LDS_BUFFER + fk * LDS_LD + 16 * (7 - 2 * wr) + fr;      // ROWMAP: slots 2, 3 count down from here
     const int baseB = buf * LDS_BUFFER + LDS_OPERAND + fk * LDS_LD + wc * 64 + fr;
 #pragma unroll
     for (int ks = 0; ks < KB / 4; ++ks) {
         double a[4], b[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a[m] = psoap_smem[baseA + ks * 4 * LDS_LD + m * 16];
+        for (int m = 0; m < 4; ++m)
+            a[m] = ROWMAP ? (m < 2 ? sm[baseA + ks * 4 * LDS_LD + m * 16] : sm[baseA2 + ks * 4 * LDS_LD - (m - 2) * 16])
+                          : sm[baseA + ks * 4 * LDS_LD + m * 16];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) b[n] = psoap_smem[baseB + ks * 4 * LDS_LD + n * 16];
+        for (int n = 0; n < 4; ++n) b[n] = sm[baseB + ks * 4 * LDS_LD + n * 16];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             if (PARTIAL_M && m < m_first) continue;
@@ -183,8 +192,9 @@ __device__ __forceinline__ void stage_glds(const double* __restrict__ A, size_t 
 
 // the same with the wave index given as a scalar and the lane taken from the exec mask: no thread-id register
 // lives across the K-loop (tile_gemm_tn with wave_s >= 0)
+template <class SM = SmemKernel>
 __device__ __forceinline__ void stage_glds_w(const double* __restrict__ A, size_t lda, const double* __restrict__ B,
-                                             size_t ldb, int k, int buf, int wave)
+                                             size_t ldb, int k, int buf, int wave, SM sm = SM())
 {
     typedef __attribute__((address_space(3))) void* lds_ptr;
     typedef const __attribute__((address_space(1))) void* glb_ptr;
@@ -193,9 +203,9 @@ __device__ __forceinline__ void stage_glds_w(const double* __restrict__ A, size_
     for (int it = 0; it < 4; ++it) {
         const int row = wave + 4 * it;
         const int off = buf * LDS_BUFFER + row * LDS_LD;
-        __builtin_amdgcn_global_load_lds((glb_ptr)(A + (size_t)(k + row) * lda + 2 * lane), (lds_ptr)(psoap_smem + off), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(A + (size_t)(k + row) * lda + 2 * lane), (lds_ptr)sm.ptr(off), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_ptr)(B + (size_t)(k + row) * ldb + 2 * lane),
-                                         (lds_ptr)(psoap_smem + off + LDS_OPERAND), 16, 0, 0);
+                                         (lds_ptr)sm.ptr(off + LDS_OPERAND), 16, 0, 0);
     }
 }
 
@@ -218,24 +228,24 @@ __device__ __forceinline__ void stage_glds_one(const double* __restrict__ A, siz
 
 // SW (scalar wave): the caller passes the wave index as a scalar it keeps (wave_s) and the staging takes the lane from
 // the exec mask (stage_glds_w) -- no thread-id register lives across the K-loop.  SW = false is the plain form.
-template <bool SW = false>
+template <bool SW = false, class SM = SmemKernel, bool ROWMAP = false>
 __device__ __forceinline__ void tile_gemm_tn(Tile& t, const double* __restrict__ A, size_t lda,
                                                   const double* __restrict__ B, size_t ldb, int K,
                                                   bool skip_lower_left = false, int k_limit_upper = 0x7fffffff,
-                                                  int wave_s = -1)
+                                                  int wave_s = -1, SM sm = SM())
 {
     if constexpr (SW) {
         const int wave = wave_s;
         const int wr = wave >> 1, wc = wave & 1;
         if (K <= 0) return;
-        stage_glds_w(A, lda, B, ldb, 0, 0, wave);
+        stage_glds_w(A, lda, B, ldb, 0, 0, wave, sm);
         __syncthreads();
         const int nchunk = K / KB;
         for (int c = 0; c < nchunk; ++c) {
             const int cur = c & 1;
-            if (c + 1 < nchunk) stage_glds_w(A, lda, B, ldb, (c + 1) * KB, cur ^ 1, wave);
+            if (c + 1 < nchunk) stage_glds_w(A, lda, B, ldb, (c + 1) * KB, cur ^ 1, wave, sm);
             const bool idle = (skip_lower_left && wr == 1 && wc == 0) || (wr == 0 && c * KB >= k_limit_upper);
-            if (!idle) tile_mma_chunk(t, cur, wr, wc, 0);
+            if (!idle) tile_mma_chunk<false, SM, ROWMAP>(t, cur, wr, wc, 0, 0, sm);
             __syncthreads();
         }
         return;

@@ -50,6 +50,9 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
     q_rows = [sum(Ps[g::8]) for g in range(8)]
     q_count = [len(Ps[g::8]) for g in range(8)]
     want_chain = max(q_rows) <= 150 or max(q_count) <= 1
+    # ... and within that, the following scheme (scheme 2) for up to four matrices of at most 32 block rows: from block
+    # row 2 on the strip solves follow the factorisation (DAG_WAITNEXT on OFF finals), the diagonal task solves nothing
+    following = want_chain and B <= 4 and max(Ps) <= 32
     assert np.all(chain[tasks["S"] > 1] == want_chain) if (tasks["S"] > 1).any() else True
     # one queue per XCD: matrix b lives in queue b mod 8, queues are contiguous ranges of the list
     first = plan.queue_first
@@ -108,11 +111,19 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
         # the update over block rows [pa, pb) needs rows < pb complete: all finals of those rows are earlier
         # -- except a diagonal final of the latency scheme (WAITNEXT), which reads of the last row only the
         # tile right of its diagonal, solved by that row's DIAG task itself (FUSED)
-        wait_next = bool(flags[t] & WAITNEXT)
+        follows = bool(flags[t] & WAITNEXT) and k["type"] == OFF      # on an OFF final the bit means "follow the factorisation"
+        wait_next = bool(flags[t] & WAITNEXT) and not follows
+        if follows:
+            assert following and q >= 2 and diag_final_ticket[(b, q)] < t      # behind the task whose progress it polls
         if wait_next:
             assert want_chain and k["type"] == DIAG and int(k["pb"]) == q and int(k["pb"]) - int(k["pa"]) == 1
             prev = diag_final_ticket[(b, q - 1)]
-            assert prev < t and flags[prev] & FUSED
+            if following and q - 1 >= 2:
+                # the tile right of the diagonal above is solved by its own (following) task, which announces it
+                solver = finals[(b, q - 1, q)]
+                assert solver < t and (flags[solver] & NOSOLVE) and (flags[solver] & WAITNEXT) and not flags[prev] & FUSED
+            else:
+                assert prev < t and flags[prev] & FUSED
         for m in range(int(k["pb"]) - (1 if wait_next else 0)):
             assert row_final_last_ticket[(b, m)] < t
         if flags[t] & FUSED:
@@ -121,9 +132,10 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
             upd = finals[(b, q, q + 1)]
             assert upd < t and flags[upd] & NOSOLVE
         if flags[t] & NOSOLVE:
-            assert k["type"] == OFF and j == q + 1 and flags[diag_final_ticket[(b, q)]] & FUSED
+            assert k["type"] == OFF and j == q + 1
+            assert bool(flags[diag_final_ticket[(b, q)]] & FUSED) == (not follows)
         if want_chain and k["type"] == DIAG:
-            assert bool(flags[t] & FUSED) == (q + 1 < Ps[b]) and wait_next == (q >= 1)
+            assert bool(flags[t] & FUSED) == (q + 1 < Ps[b] and not (following and q >= 2)) and wait_next == (q >= 1)
         if not want_chain:
             assert not flags[t] & (NOSOLVE | WAITNEXT | FUSED)
         if k["type"] != PART:
@@ -244,3 +256,43 @@ def test_schur_tiles_of_the_augmented_launch(P, Mt, Ms, scheme):
     # no other chain shares a Schur tile's slot pair
     others = np.where(~schur & chain & (ty == PART))[0]
     assert not ({int(tasks["slot"][t]) >> 1 for t in others} & set(seen_pairs))
+
+
+@pytest.mark.parametrize("P", [3, 16, 32, 47])
+def test_following_scheme_task_flags_and_ticket_order(P):
+    """Scheme 2: from block row 2 on the diagonal task solves nothing (no DAG_FUSED), every strip solve follows it
+    (DAG_WAITNEXT on an OFF final) and therefore sits BEHIND it in the ticket order, and the strip solve of tile
+    (q, q+1) -- flagged DAG_NOSOLVE, here "publishes next_done" -- sits in front of the next diagonal task, which waits
+    for it.  Rows 0 and 1 keep the forms of scheme 1."""
+    from psoap_amd import _lib
+    L = _lib.load()
+    n, slots, ctrs = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+    first = (ctypes.c_uint32 * 9)()
+    assert L.psoap_dag_plan_aug(P, 0, 0, 256, 2, None, 0, ctypes.byref(n), ctypes.byref(slots), ctypes.byref(ctrs), first) == 0
+    tasks = np.zeros(n.value, dtype=TASK)
+    assert L.psoap_dag_plan_aug(P, 0, 0, 256, 2, tasks.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n),
+                                ctypes.byref(slots), ctypes.byref(ctrs), first) == 0
+    ty = tasks["type"] & TYPE_MASK
+    flags = tasks["type"]
+    diag_ticket, off_tickets = {}, {}
+    for t, k in enumerate(tasks):
+        q, j = int(k["q"]), int(k["j"])
+        if ty[t] == DIAG:
+            diag_ticket[q] = t
+            assert bool(flags[t] & FUSED) == (q < 2 and q + 1 < P), (q, hex(flags[t]))
+        elif ty[t] == OFF:
+            off_tickets.setdefault(q, {})[j] = t
+            if q >= 2:
+                assert flags[t] & WAITNEXT, (q, j)                                    # follows
+                assert bool(flags[t] & NOSOLVE) == (j == q + 1), (q, j)                 # the tile the next diagonal waits for
+            else:
+                assert not (flags[t] & WAITNEXT)
+                assert bool(flags[t] & NOSOLVE) == (j == q + 1 and q + 1 < P)           # update-only, solved by the fused DIAG
+    assert sorted(diag_ticket) == list(range(P))
+    for q in range(2, P):
+        for j, t in off_tickets.get(q, {}).items():
+            assert diag_ticket[q] < t, (q, j)                  # a follower waits on its leader's progress
+        if q + 1 < P:
+            assert off_tickets[q][q + 1] < diag_ticket[q + 1]  # next_done(q) comes from a smaller ticket
+    # every tile exactly once, as in the other schemes
+    assert sum(len(v) for v in off_tickets.values()) == P * (P - 1) // 2

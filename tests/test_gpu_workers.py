@@ -184,9 +184,9 @@ def test_bench_launches_its_own_ranks_gloo_dry_run():
 
 
 # ---------------------------------------------------------------------------------------------- forced split schemes
-@pytest.mark.parametrize("scheme", ["0", "1"])
+@pytest.mark.parametrize("scheme", ["0", "1", "2"])
 def test_parity_under_forced_split_scheme(scheme):
-    """PSOAP_DAG_SCHEME pins the throughput (0) or latency (1) task lists -- and with them the kernel instantiation
+    """PSOAP_DAG_SCHEME pins the throughput (0), latency (1) or following (2: strip solves behind the factorisation) task lists -- and with them the kernel instantiation
     (k_chol_dag<.., LAT>) -- for every launch, also where the automatic rule would pick the other one (predict under
     the throughput scheme, 32-walker batches under the latency scheme).  The golden / oracle parity tests must hold
     for both.  (A child process: the variable is read when the library builds its first plan.)"""
