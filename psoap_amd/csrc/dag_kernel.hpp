@@ -59,14 +59,18 @@ struct alignas(64) MatFlags {
     int step_w[4];    // per wave of the fused diagonal task: 8 q + b + 1 once its share of step b of block q (the row
                       // of U11 and W_bb^T the strip solves need) is in the matrix's mailbox (dag_pss)
     int pad[6];
+    int xcol[256][2]; // per column tile j, per publishing wave of the following strip solve of tile (q, j): 8 q + b + 1
+                      // once its half of row block b of the solved tile is in memory -- the tasks of block row q+1 that
+                      // read the tile (the diagonal task of block q+1, the strip solves of tiles (q+1, .)) follow it in turn
 };
-static_assert(sizeof(MatFlags) == 64, "one cache line per matrix");
+static_assert(sizeof(MatFlags) == 64 + 2048, "one cache line of row state + the per-column progress words");
 
 // Mailbox of a matrix, right behind its two Wt tiles: the fused diagonal task publishes, step by step, what a strip
 // solve needs of block row b of the diagonal block it is factoring -- the blocks U_bJ (J > b) of U11's row b and
 // V_b = W_bb^T -- so that the strip solves of the row can FOLLOW the factorisation instead of starting behind it.
-//   slot (q & 1, b, J), J = 0..7: U_bJ (written for J > b);  J = 8: V_b.   Blocks in the accumulator-linear form.
-constexpr int MB_BLOCKS = 9;
+//   slot (q & 1, b, J), J = 0..7: U_bJ (written for J > b);  J = 8: V_b;  J = 9: the right-hand side block z_b (first
+//   column).   Blocks in the accumulator-linear form.
+using ps::MB_BLOCKS;
 constexpr size_t MB_DOUBLES = (size_t)2 * 8 * MB_BLOCKS * 256;
 constexpr size_t WT_STRIDE = (size_t)2 * NB * NB + MB_DOUBLES;     // doubles per matrix: two Wt tiles + the mailbox
 __host__ __device__ inline size_t mb_slot(int q, int b, int J) { return ((size_t)((q & 1) * 8 + b) * MB_BLOCKS + J) * 256; }
@@ -201,6 +205,44 @@ __device__ __forceinline__ void dag_update(Tile& t, double* Km, int ld, int k0, 
     if (tl && threadIdx.x == 0) tl[4] = __builtin_amdgcn_s_memrealtime();
     const size_t r1 = (size_t)(pb - 1) * NB;
     tile_gemm_tn<SW, SM, ROWMAP>(t, Km + r1 * ld + k0, (size_t)ld, Km + r1 * ld + j0, (size_t)ld, NB, diag, 0x7fffffff, wave_s, sm);
+}
+
+// The last panel of a following strip solve's update, K = 128: its operands -- tiles (q-1, q) and (q-1, j) -- are being
+// solved by tasks that follow the factorisation of block q-1 and deliver their row blocks one by one (dag_pss, xpub;
+// MatFlags::xcol): stage ch is row block ch of both.  A stage is requested ahead of the products of the one before it
+// when it is known to be there, behind them otherwise (every wave stages its own rows and polls for itself).
+template <class SM>
+__device__ __forceinline__ void dag_update_following(Tile& t, const double* __restrict__ A, const double* __restrict__ B,
+                                                     size_t ld, int* xa, int* xb, int base, unsigned int* err, int wave, SM sm,
+                                                     unsigned long long* tl = nullptr)
+{
+    const int wr = wave >> 1, wc = wave & 1;
+    const int lane = hw_lane();
+    int avail = ps::x_wait(xa, xb, base, err, 1, lane);
+    if (tl && threadIdx.x == 0) tl[4] = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    stage_glds_w(A, ld, B, ld, 0, 0, wave, sm);
+    __syncthreads();
+#pragma unroll 1
+    for (int ch = 0; ch < NB / KB; ++ch) {
+        const int cur = ch & 1;
+        bool early = false;
+        if (ch + 1 < NB / KB) {
+            if (avail < ch + 2) avail = ps::x_steps(xa, xb, base, lane);
+            if (avail >= ch + 2) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                stage_glds_w(A, ld, B, ld, (ch + 1) * KB, cur ^ 1, wave, sm);
+                early = true;
+            }
+        }
+        tile_mma_chunk<false, SM>(t, cur, wr, wc, 0, 0, sm);
+        if (ch + 1 < NB / KB && !early) {
+            avail = ps::x_wait(xa, xb, base, err, ch + 2, lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            stage_glds_w(A, ld, B, ld, (ch + 1) * KB, cur ^ 1, wave, sm);
+        }
+        __syncthreads();
+    }
 }
 
 // The ONE consumer of the accumulators.  Every task ends its update here:
@@ -478,7 +520,7 @@ PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double*
                                                         const double* prev, int Npad, MatFlags* f, DagCtl* ctl, int q,
                                                         int ntasks_row, bool fused, int* chain_ctr, int chain_len,
                                                         lds_double* smem, lds_double* zk, lds_double* colsum,
-                                                        unsigned long long* tl)
+                                                        unsigned long long* tl, bool xfollow = false, bool two_panels = false)
 {
 #ifdef PSOAP_PAD_CALLEE
     // variant matrix (tools/lat_variants.py): code placement only
@@ -492,8 +534,11 @@ PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double*
     dag_wait_ge(chain_ctr, chain_len, ctl, 4u);
 #endif
     __builtin_amdgcn_s_setprio(3);
-    auto wait_dep = [f, ctl, q, tl]() {
-        dag_wait_ge(&f->next_done, q, ctl, 2u);
+    // (xfollow: no wait for the finished tile above -- its row blocks are awaited one by one inside the update)
+    // (two_panels: the final also applies tile (q-2, q), final with the whole of block row q-2)
+    auto wait_dep = [f, ctl, q, tl, xfollow, two_panels]() {
+        if (!xfollow) dag_wait_ge(&f->next_done, q, ctl, 2u);
+        else if (two_panels) dag_wait_ge(&f->rows_done, q - 1, ctl, 1u);
         if (tl && threadIdx.x == 0) tl[4] = __builtin_amdgcn_s_memrealtime();
     };
 #ifdef PSOAP_NO_SPINE
@@ -506,7 +551,10 @@ PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double*
     (void)wt0;
 #else
     potrf_spine_fused(Km, ld, k0, Wm, Rv, acc, prev, Km + (size_t)(k0 - NB) * ld + k0, wait_dep, tl, sm,
-                      ps::SpinePub{wt0 + 2 * NB * NB + mb_slot(q, 0, 0), f->step_w, 8 * q});
+                      ps::SpinePub{wt0 + 2 * NB * NB + mb_slot(q, 0, 0), f->step_w, 8 * q},
+                      xfollow ? ps::SpineFollow{wt0 + 2 * NB * NB + mb_slot(q - 1, 0, 0), f->xcol[q], 8 * (q - 1), &ctl->error,
+                                                two_panels ? Km + (size_t)(k0 - 2 * NB) * ld + k0 : nullptr}
+                              : ps::SpineFollow{nullptr, nullptr, 0, nullptr, nullptr});
 #endif
 #endif
     dag_drain();
@@ -595,25 +643,13 @@ __device__ __forceinline__ d4 dag_mb_load(const double* __restrict__ mbq, int b,
 // task); the tile travels through the stack (128 registers out, 128 in: ~1 us against the ~10 us of the store / drain /
 // reload it replaces), LDS is reached through the pointers the kernel hands over (gemm_core.hpp, SmemArg).
 template <int C, bool AUG>
-__device__ __forceinline__ void dag_pss(const Tile* tp, double* Km, int ld, int k0, int j0,
+__device__ __forceinline__ void dag_pss(Tile& t, double* Km, int ld, int k0, int j0,
                                                   const double* __restrict__ mbq, MatFlags* f, int q, DagCtl* ctl,
                                                   double* Rv, int Npad, lds_double* smem, lds_double* zk, lds_double* colsum,
-                                                  const double* lw, const double* gp, const double* sigma, int N,
-                                                  double scale, const DagAug* aug)
+                                                  int xpub, int skip_rv)
 {
-    Tile t = *tp;
+    // t: the updated tile (the caller evaluated the covariance into the accumulators: dag_special)
     const SmemArg sm{smem};
-    {
-        // the accumulators become the tile: T = scale * K(i, j) - acc  (the arithmetic of every other task's store routine)
-        GpDev g;
-        load_gp(gp, C, g);
-        double dsum = g.a2[0];
-        {
-#pragma clang fp contract(off)
-            for (int c = 1; c < C; ++c) dsum = dsum + g.a2[c];
-        }
-        dag_store_updated<C, AUG, true>(t, nullptr, 0, k0, j0, lw, g, dsum, sigma, N, scale, Npad, *aug, nullptr);
-    }
     int tid_ = threadIdx.x;
     asm volatile("" : "+v"(tid_));
     const int lane = tid_ & 63, wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
@@ -647,6 +683,19 @@ __device__ __forceinline__ void dag_pss(const Tile* tp, double* Km, int ld, int 
             }
         }
         __syncthreads();
+        // xpub (the tasks of block row q+1 that read this tile follow THIS task): row block b goes to its place in the
+        // matrix right away, with write-through stores, from the upper wave row -- it has the fewer products below (none
+        // from step 4 on) -- and the flag rises behind them
+        if (xpub && wr == 0) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const d4 xb = pb::load_blk(buf + (4 * wc + n) * 256, lane, sm);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    __hip_atomic_store(&Km[(size_t)(k0 + tile_row(hb, mb, lane, r)) * ld + j0 + tile_col(wc, n, lane)], xb[r],
+                                       PSOAP_RLX_AGENT);
+            }
+        }
         // T_I -= U_bI^T X_b on this wave's row blocks below b
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -656,17 +705,26 @@ __device__ __forceinline__ void dag_pss(const Tile* tp, double* Km, int ld, int 
                 for (int n = 0; n < 4; ++n)
                     t.acc[m][n] = pb::mma16(xs, pb::load_blk(buf + (4 * wc + n) * 256, lane, sm), t.acc[m][n]);
             }
+        if (xpub && wr == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&f->xcol[j0 / NB][wc], 8 * q + b + 1, PSOAP_RLX_AGENT);
+        }
     }
-    // the solved tile goes out; the right-hand side update needs z of this block row, final once the factorisation
-    // has written it (potrf_done)
+    // (skip_rv -- tile (q, q+1), delivered to a diagonal task that follows it: that task takes the tile's contribution
+    // to the right-hand side itself -- potrf_spine.hpp, SpineFollow)
+    if (skip_rv) return;
+    // the solved tile goes out (xpub: it is in memory already); the right-hand side update needs z of this block row,
+    // final once the factorisation has written it (potrf_done)
     auto row_of = [&](int m, int r) { return tile_row(wr, m, lane, r); };
+    if (!xpub) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int n = 0; n < 4; ++n)
-                Km[(size_t)(k0 + row_of(m, r)) * ld + j0 + tile_col(wc, n, lane)] = t.acc[m][n][r];
+                for (int n = 0; n < 4; ++n)
+                    Km[(size_t)(k0 + row_of(m, r)) * ld + j0 + tile_col(wc, n, lane)] = t.acc[m][n][r];
+    }
     dag_wait_ge(&f->potrf_done, q + 1, ctl, 7u);
     if (tid_ < NB) zk[tid_] = Rv[k0 + tid_];
     __syncthreads();
@@ -698,6 +756,16 @@ __device__ __forceinline__ void dag_pss(const Tile* tp, double* Km, int ld, int 
     }
 }
 
+__device__ __forceinline__ void dag_negate(Tile& t)
+{
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t.acc[m][n][r] = -t.acc[m][n][r];
+}
+
 #ifdef PSOAP_FOLLOW
 // ONE out-of-line routine for the two kinds of task that do not fit the kernel body -- the fused diagonal task and the
 // following strip solve -- behind ONE call site that takes ONE pointer: with a second call (and its two dozen arguments)
@@ -725,6 +793,8 @@ struct DagSpecialArgs {
     DagAug aug;
     int pa, pb, n_wait, preload, n_prev;       // the following task does its own update (the task record's fields)
     int* arrive_ctr;
+    int xlink;                     // diagonal task: the strip above arrives row block by row block (SpineFollow);
+                                   // following strip solve: it delivers its tile that way (dag_pss, xpub)
 };
 
 template <int C, bool AUG>
@@ -732,32 +802,84 @@ __device__ __attribute__((noinline)) void dag_special(const DagSpecialArgs* a)
 {
     if (a->mode == 0) {
         dag_diag_fast(a->Km, a->ld, a->k0, a->Wm, a->Rv, a->acc, a->prev, a->Npad, a->f, a->ctl, a->q, a->ntasks_row,
-                      a->fused != 0, a->chain_ctr, a->chain_len, a->smem, a->zk, a->colsum, a->tl);
+                      a->fused != 0, a->chain_ctr, a->chain_len, a->smem, a->zk, a->colsum, a->tl, a->xlink != 0,
+                      a->pb - a->pa == 2);
         return;
     }
-    // the whole task: left-looking update (the kernel's own sequence: preloaded chain sum, K-loops, gathered partial sums),
-    // then the tile -- still in the accumulators -- is solved behind the factorisation
-    const SmemArg sm{a->smem};
+    // the whole task: the tile so far (covariance - the running sum of its chain), the left-looking update over the
+    // panels that are left -- the last one FOLLOWING the strip solves of the row above where they deliver row block by
+    // row block -- and then the tile, still in the accumulators, is solved behind the factorisation of block q.
+    // (The argument record is read ONCE, into scalars: behind a pointer every use is a load of its own -- the stores in
+    // between may alias -- and each costs a memory round trip on the chain.)
+    const auto si = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    const auto sp = [](auto* p) {
+        const unsigned long long u = (unsigned long long)(uintptr_t)p;
+        const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)u), hi = __builtin_amdgcn_readfirstlane((unsigned int)(u >> 32));
+        return (decltype(p))(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    };
+    // (... and only what the update needs before it: whatever else is live across the K-loops is what hipcc spills and
+    // reloads inside their stages)
+    double* const Km = sp(a->Km);
+    const double* const prev = sp(a->prev);
+    MatFlags* const f = sp(a->f);
+    DagCtl* const ctl = sp(a->ctl);
+    int* const arrive_ctr = sp(a->arrive_ctr);
+    unsigned long long* const tl = sp(a->tl);
+    const int ld = si(a->ld), k0 = si(a->k0), j0 = si(a->j0), q = si(a->q);
+    const int pa = si(a->pa), pb = si(a->pb), n_wait = si(a->n_wait), preload = si(a->preload), n_prev = si(a->n_prev);
+    const int xlink = si(a->xlink);
+    const double scale = a->scale;
+    lds_double* const smem = (lds_double*)(uintptr_t)(unsigned int)si((int)(unsigned int)(uintptr_t)a->smem);   // wave-uniform: a scalar
+    const SmemArg sm{smem};
     const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     Tile t;
     t.zero();
-    int n_prev = a->n_prev;
-    if (a->preload) {
-        dag_wait_ge(a->arrive_ctr, a->n_wait, a->ctl, 4u);
-        dag_sub_partials(t, a->prev, 1);
-        n_prev = 0;
+    if (n_wait > 0) {
+        dag_wait_ge(arrive_ctr, n_wait, ctl, 4u);
+        if (tl && threadIdx.x == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
+        dag_sub_partials(t, prev, preload ? 1 : n_prev);
     }
-    dag_update<true, SmemArg>(t, a->Km, a->ld, a->k0, a->j0, a->pa, a->pb, a->f, a->ctl, false, a->tl, wave_s, sm);
-    if (!a->preload && a->n_wait > 0) dag_wait_ge(a->arrive_ctr, a->n_wait, a->ctl, 4u);
-    dag_sub_partials(t, a->prev, n_prev);
+    // the covariance goes in BEFORE the wait for the row above (the accumulators then hold -(tile) during the update);
+    // the final of a chain has nothing to add -- the chain's first part carried K
+    if (scale != 0.0) {
+        GpDev g;
+        load_gp(a->gp, C, g);
+        double dsum = g.a2[0];
+        {
+#pragma clang fp contract(off)
+            for (int c = 1; c < C; ++c) dsum = dsum + g.a2[c];
+        }
+        dag_store_updated<C, AUG, true>(t, nullptr, 0, k0, j0, a->lw, g, dsum, a->sigma, a->N, scale, a->Npad, a->aug, nullptr);
+        dag_negate(t);
+    }
+    const int xupd = xlink && q >= 3;      // the row above is a following one that delivers its tiles progressively
+    if (xupd) {
+        if (pb - pa > 1) {
+            dag_wait_ge(&f->rows_done, pb - 1, ctl, 1u);
+            const size_t r0 = (size_t)pa * NB;
+            tile_gemm_tn<true, SmemArg>(t, Km + r0 * ld + k0, (size_t)ld, Km + r0 * ld + j0, (size_t)ld, (pb - 1 - pa) * NB, false,
+                                        0x7fffffff, wave_s, sm);
+        }
+        const size_t r1 = (size_t)(pb - 1) * NB;
+        if (tl && threadIdx.x == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
+        dag_update_following(t, Km + r1 * ld + k0, Km + r1 * ld + j0, (size_t)ld, f->xcol[q], f->xcol[j0 / NB], 8 * (q - 1),
+                             &ctl->error, wave_s, sm, tl);
+    } else {
+        dag_update<true, SmemArg>(t, Km, ld, k0, j0, pa, pb, f, ctl, false, tl, wave_s, sm);
+    }
+    dag_negate(t);       // the accumulators hold the sums with the opposite sign: tile = -acc
+    if (tl && threadIdx.x == 0) tl[5] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();     // the K-loop's LDS is free: every wave has left it
-    dag_pss<C, AUG>(&t, a->Km, a->ld, a->k0, a->j0, a->mbq, a->f, a->q, a->ctl, a->Rv, a->Npad, a->smem, a->zk, a->colsum,
-                    a->lw, a->gp, a->sigma, a->N, a->scale, &a->aug);
+    double* const Rv = sp(a->Rv);
+    const double* const mbq = sp(a->mbq);
+    const int Npad = si(a->Npad), ntasks_row = si(a->ntasks_row), pubnext = si(a->pubnext);
+    dag_pss<C, AUG>(t, Km, ld, k0, j0, mbq, f, q, ctl, Rv, Npad, smem, a->zk, a->colsum, xlink, xlink && pubnext);
+    if (tl && threadIdx.x == 0) tl[6] = __builtin_amdgcn_s_memrealtime();
     dag_drain();
     if (threadIdx.x == 0) {
         dag_release_fence();
-        if (a->pubnext) __hip_atomic_store(&a->f->next_done, a->q + 1, PSOAP_RLX_AGENT);   // tile (q, q+1) is final
-        dag_task_done(a->f, a->q, a->ntasks_row);
+        if (pubnext) __hip_atomic_store(&f->next_done, q + 1, PSOAP_RLX_AGENT);   // tile (q, q+1) is final
+        dag_task_done(f, q, ntasks_row);
     }
 }
 #endif
@@ -857,7 +979,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         const bool preload = !is_part && chain && n_wait > 0;
 #ifdef PSOAP_FOLLOW
         // (-DPSOAP_FOLLOW: both out-of-line task kinds go through dag_special, further down, at one call site)
-        const bool fast_diag = LAT && preload && ttype == DAG_DIAG && (task.type & DAG_WAITNEXT) && task.pb - task.pa == 1;
+        const bool fast_diag = LAT && preload && ttype == DAG_DIAG && (task.type & DAG_WAITNEXT) &&
+                               (task.pb - task.pa == 1 || ((task.type & DAG_NOSOLVE) && task.pb - task.pa == 2));
         const bool follow = LAT && ttype == DAG_OFF && (task.type & DAG_WAITNEXT);
         if (fast_diag || follow) {
             // scheme 2's strip solves follow the factorisation of block q step by step, on the tile in registers; the
@@ -876,6 +999,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
             args.aug = aug;
             args.pa = task.pa; args.pb = task.pb; args.n_wait = n_wait; args.preload = preload ? 1 : 0; args.n_prev = n_prev;
             args.arrive_ctr = &arrive[task.ctr];
+            // second level of following: DAG_NOSOLVE on the diagonal task (it follows the strip solve of the tile above),
+            // DAG_FUSED on a strip solve (it delivers its tile row block by row block, and follows the row above likewise)
+            args.xlink = fast_diag ? ((task.type & DAG_NOSOLVE) != 0) : ((task.type & DAG_FUSED) != 0);
             dag_special<C, AUG>(&args);
             if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
             continue;
@@ -1016,7 +1142,7 @@ struct DagPlan {
     int scheme = 0;            // 0 throughput, 1 latency: selects the kernel instantiation (k_chol_dag<.., LAT>)
 };
 
-inline int dag_split_factor(int tasks_in_row, int q, int workers, int scheme)
+inline int dag_split_factor(int tasks_in_row, int q, int workers, int scheme, int n_mats = 0)
 {
     // cut tiles of sparse block rows until the row offers about `workers` tasks (at most 8 parts).
     // Throughput scheme: full occupancy, parts at least two panels long.  Latency scheme: half the workers,
@@ -1027,7 +1153,10 @@ inline int dag_split_factor(int tasks_in_row, int q, int workers, int scheme)
     // PSOAP_DAG_SPLIT_PCT / PSOAP_DAG_SPLIT_MIN override both numbers (experiments).
     static const int env_pct = getenv("PSOAP_DAG_SPLIT_PCT") ? atoi(getenv("PSOAP_DAG_SPLIT_PCT")) : 0;
     static const int env_min = getenv("PSOAP_DAG_SPLIT_MIN") ? atoi(getenv("PSOAP_DAG_SPLIT_MIN")) : 0;
-    const int pct = env_pct > 0 ? env_pct : (scheme >= 1 ? 50 : 100);
+    // (scheme 2, a single matrix: a quarter -- with the PARTs handed out just in time the chains run ahead of the
+    // finals anyway, and every part less is a partial-tile hand-over less: N = 6000: 3.06 -> 2.80 ms; with four matrices
+    // the same setting costs 3-8 %)
+    const int pct = env_pct > 0 ? env_pct : (scheme == 2 && n_mats == 1 ? 25 : (scheme >= 1 ? 50 : 100));
     const int minp = env_min > 0 ? env_min : (scheme >= 1 ? 4 : 2);
     int S = 1;
     while (S < 8 && tasks_in_row * S * 100 < workers * pct && minp * S <= q) S *= 2;
@@ -1047,15 +1176,39 @@ inline int dag_split_factor(int tasks_in_row, int q, int workers, int scheme)
 // Encoding: PART.S = index in the chain (0 when gathered), PART.slot = its output (gathered:
 // consecutive slots; chained: an even/odd pair used alternately); final.S = number of pieces,
 // final.slot = first slot to read (gather: the first PART's, chain: the last PART's).  nsplit == 1: one final over the whole range.
-inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first, int pb_last, int nsplit, int scheme,
-                     unsigned char final_flags = 0)
+inline int dag_final_panels()
 {
+    const char* e = getenv("PSOAP_FINAL_PANELS");      // experiments
+    return e ? atoi(e) : 2;
+}
+inline int dag_jit_rows()
+{
+    const char* e = getenv("PSOAP_DAG_JIT");      // experiments; 0: readiness order
+    return e ? atoi(e) : 6;
+}
+inline bool dag_xfollow_enabled()
+{
+    const char* e = getenv("PSOAP_XFOLLOW");
+    return !(e && e[0] == '0');
+}
+// final_panels: how many of the last panels a chain's final takes itself (1: only the one that depends on the block row
+// above; 2 -- following strip solves: the chain's last PART then needs the row before that only and is folded in a whole
+// row period before the final gets its last operands -- the hand-over of a partial tile costs 30-40 us)
+inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first, int pb_last, int nsplit, int scheme,
+                     unsigned char final_flags = 0, int final_panels = 1)
+{
+    if (final_panels > 1) {
+        const int left = pb_last - final_panels - pa_first;         // panels for the PARTs
+        if (left <= 0) nsplit = 1;
+        else if (nsplit > left) nsplit = left;
+        if (scheme < 1 || nsplit <= 1) final_panels = 1;            // (only a chain's final has a fixed range)
+    }
     const bool chain = (scheme >= 1) && nsplit > 1;
     const int nparts = chain ? nsplit : nsplit - 1;                 // PART tasks
     const unsigned int ctr = (nparts > 0) ? plan.n_ctrs++ : 0u;
     if (chain) plan.n_slots += plan.n_slots & 1u;                   // a chain ping-pongs between an even/odd slot pair
     const unsigned int slot0 = plan.n_slots;
-    const int pb_parts = chain ? pb_last - 1 : pb_last;
+    const int pb_parts = chain ? pb_last - final_panels : pb_last;
     const int span = pb_parts - pa_first;
     const unsigned char flag = chain ? DAG_CHAIN : 0;
     for (int sidx = 0; sidx < nparts; ++sidx) {
@@ -1080,7 +1233,7 @@ inline void dag_emit(DagPlan& plan, int type, int b, int q, int j, int pa_first,
     t.q = (unsigned char)q;
     t.j = (unsigned char)j;
     t.S = (unsigned char)(nparts + 1);
-    t.pa = (unsigned char)(chain ? pb_last - 1 : pa_first + (long long)span * (nsplit - 1) / nsplit);
+    t.pa = (unsigned char)(chain ? pb_last - final_panels : pa_first + (long long)span * (nsplit - 1) / nsplit);
     t.pb = (unsigned char)pb_last;
     t.slot = (nparts > 0) ? (chain ? slot0 + (unsigned int)((nparts - 1) & 1) : slot0) : 0u;
     t.ctr = ctr;
@@ -1166,7 +1319,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
             live = Bq_nominal;
         }
         const int Bq = live;
-        const int S_off = dag_split_factor((int)row_tiles, q, workers, scheme);
+        const int S_off = dag_split_factor((int)row_tiles, q, workers, scheme, (int)Ps.size());
         // latency scheme: DIAG(q) also solves the tile right of the diagonal (DAG_FUSED) whenever a next
         // diagonal tile exists, and DIAG(q >= 1) waits only for that tile of the row above (DAG_WAITNEXT)
         // scheme 2 ("following"): from block row 2 on -- where the diagonal task is the fused fast one, which publishes its
@@ -1174,6 +1327,10 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
         // the diagonal task solves nothing itself, and the strip solve of tile (q, q+1) publishes next_done (DAG_NOSOLVE
         // on a following OFF task).  Rows 0 and 1 keep the forms of scheme 1.
         const bool following = (scheme == 2) && q >= 2;
+        // (block row r: its solved tiles are delivered row block by row block (DAG_FUSED on a following OFF task) to the
+        // tasks of block row r+1 that read them -- the diagonal task of block r+1 (DAG_NOSOLVE on a DIAG task) and the
+        // last panel of the strip solves' updates; PSOAP_XFOLLOW=0 keeps the first level only -- A/B measurements)
+        auto xlink = [&](int r) { return scheme == 2 && r >= 2 && dag_xfollow_enabled(); };
         auto fused = [&](int b) { return scheme >= 1 && !following && q + 1 < Ps[b]; };
         // 1. DIAG finals of this row
         if (q <= 1) {
@@ -1188,7 +1345,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
         // Latency scheme: the PART that needs the block row just above (panel q-1, available only when ALL
         // of row q-1 is finished) is one panel long; the long ones cover [0, q-1) and run a row earlier.
         if (q + 1 < P && q >= 1) {
-            const int S_pre = dag_split_factor(Bq, q, workers / 4 > 0 ? workers / 4 : 1, scheme);
+            const int S_pre = dag_split_factor(Bq, q, workers / 4 > 0 ? workers / 4 : 1, scheme, (int)Ps.size());
             for (int b : mats) {
                 if (q + 1 >= Ps[b]) continue;
                 const unsigned int ctr = plan.n_ctrs++;
@@ -1198,13 +1355,16 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
                 const unsigned char flag = chain ? DAG_CHAIN : 0;
                 // ranges of the PARTs
                 std::vector<std::pair<int, int>> ranges;
+                // (second level of following, two-panel finals: the diagonal task itself applies panel q-1 -- with a PART
+                // for it, the hand-over of the partial tile sat on the row-to-row path)
+                const bool two = xlink(q) && dag_final_panels() == 2;
                 if (chain && q >= 2) {
                     int S_long = S_pre;
                     while (S_long > 1 && (q - 1) / S_long < 1) S_long /= 2;
                     for (int sidx = 0; sidx < S_long; ++sidx)
                         ranges.emplace_back((int)((long long)(q - 1) * sidx / S_long),
                                             (int)((long long)(q - 1) * (sidx + 1) / S_long));
-                    ranges.emplace_back(q - 1, q);
+                    if (!two) ranges.emplace_back(q - 1, q);
                 } else {
                     for (int sidx = 0; sidx < S_pre; ++sidx)
                         ranges.emplace_back((int)((long long)q * sidx / S_pre), (int)((long long)q * (sidx + 1) / S_pre));
@@ -1228,10 +1388,13 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
                 fin.type = DAG_DIAG | flag;
                 if (chain) fin.type |= DAG_WAITNEXT;
                 if (chain && q + 2 < Ps[b] && !(scheme == 2 && q + 1 >= 2)) fin.type |= DAG_FUSED;
+                // second level of following: the strip solve of tile (q, q+1) follows the factorisation of block q
+                // (q >= 2) and this task follows IT -- DAG_NOSOLVE here, DAG_FUSED on that strip solve (step 3 below)
+                if (xlink(q)) fin.type |= DAG_NOSOLVE;
                 fin.b = (unsigned short)b;
                 fin.q = fin.j = (unsigned char)(q + 1);
                 fin.S = (unsigned char)(n_parts + 1);
-                fin.pa = (unsigned char)q;
+                fin.pa = (unsigned char)(two && chain && q >= 2 ? q - 1 : q);
                 fin.pb = (unsigned char)(q + 1);
                 fin.slot = chain ? slot0 + (unsigned int)((n_parts - 1) & 1) : slot0;
                 fin.ctr = ctr;
@@ -1242,8 +1405,10 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
         for (int b : mats)
             for (int j = q + 1; j < Ps[b] + Mt && q < Ps[b]; ++j)
                 dag_emit(plan, DAG_OFF, b, q, j, 0, q, S_off, scheme,
-                         following ? (unsigned char)(DAG_WAITNEXT | ((j == q + 1 && q + 1 < Ps[b]) ? DAG_NOSOLVE : 0))
-                                   : (unsigned char)((j == q + 1 && fused(b)) ? DAG_NOSOLVE : 0));
+                         following ? (unsigned char)(DAG_WAITNEXT | (xlink(q) ? DAG_FUSED : 0) |
+                                                     ((j == q + 1 && q + 1 < Ps[b]) ? DAG_NOSOLVE : 0))
+                                   : (unsigned char)((j == q + 1 && fused(b)) ? DAG_NOSOLVE : 0),
+                         following ? dag_final_panels() : 1);
     }
     if (Ms > 0)
         for (int b : mats) dag_emit_schur(plan, b, Ps[b], Ms);
@@ -1259,7 +1424,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
 // more than one matrix; throughput beyond (N = 6000, B = 32: 39.2 vs 39.9 ms; N = 8192, B = 32: 95.0 vs 96.1).
 // (Readiness ordering was also tried for the throughput scheme: 800 -> 776 evals/s, not adopted.)
 constexpr int DAG_LATENCY_QUEUE_ROWS = 150;
-constexpr int DAG_FOLLOW_MAX_ROWS = 32;
+constexpr int DAG_FOLLOW_MAX_MATS = 8;
 inline int dag_auto_scheme(const std::vector<int>& Ps)
 {
     long long rows[DAG_QUEUES] = {};
@@ -1276,11 +1441,9 @@ inline int dag_auto_scheme(const std::vector<int>& Ps)
     }
     const int latency = (max_rows <= DAG_LATENCY_QUEUE_ROWS || max_count <= 1) ? 1 : 0;
 #ifdef PSOAP_FOLLOW
-    // following strip solves (scheme 2) where they were measured to win: up to four matrices of at most 32 block rows
-    // (N <= 4096): N = 2000, B = 1..4: 1.13 -> 1.04 ms; N = 4096, B = 1: 2.21 -> 2.08 ms
-    int Pmax = 0;
-    for (int P : Ps) Pmax = P > Pmax ? P : Pmax;
-    if (latency == 1 && Ps.size() <= 4 && Pmax <= DAG_FOLLOW_MAX_ROWS) return 2;
+    // following strip solves (scheme 2) where they were measured to win (profiles/r3_follow_table.txt: N = 2000 .. 8192): up
+    // to eight matrices -- single evaluations 13-30 % faster than scheme 1, eight matrices 4-9 %; a tie or a loss from 16 on
+    if (latency == 1 && Ps.size() <= (size_t)DAG_FOLLOW_MAX_MATS) return 2;
 #endif
     return latency;
 }
@@ -1316,12 +1479,36 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
                 if (ty == DAG_OFF && (t.type & DAG_NOSOLVE) && !(t.type & DAG_WAITNEXT)) return -1;   // update-only: in front of its DIAG
                 return ty == DAG_DIAG ? 0 : (ty == DAG_OFF ? 1 : 2);      // PART and DAG_SCHUR: whatever is left of a stage
             };
+            // (scheme 2: a final that covers two panels -- a following strip solve or the diagonal task that follows
+            // one, from block row 4 on -- starts with the older panel, i.e. a stage early, and it is the row-to-row path:
+            // behind the PARTs of that stage it was picked up a whole round of them late, 110 us at N = 6000, q = 8)
+            // (scheme 2, PARTs: not before block row q - jit is the current one.  In pure readiness order the early stages
+            // hold every far row's first PARTs -- ~300 tasks per stage at N = 6000 against ~50 at the end -- and the
+            // finals of the next rows queue up behind them: 90 us per block row over the first third of the matrix
+            // instead of 45.  Just in time, every stage holds about one block row's worth of PARTs.)
+            const int jit = scheme == 2 ? dag_jit_rows() : 0;
+            // (the PARTs of the Schur tiles of predict, rows q >= P, keep their place: they are the filler work)
+            auto jit_part = [jit, &Ps](const DagTask& t) {
+                return jit > 0 && (t.type & DAG_TYPE_MASK) == DAG_PART && (t.type & DAG_CHAIN) && (int)t.q < Ps[t.b];
+            };
+            auto stage = [jit, &jit_part](const DagTask& t) {
+                const int ty = t.type & DAG_TYPE_MASK;
+                if (jit_part(t)) return std::max((int)t.pb, (int)t.q - jit);
+                const bool follows = (ty == DAG_OFF && (t.type & DAG_WAITNEXT)) || (ty == DAG_DIAG && (t.type & DAG_NOSOLVE));
+                return (follows && t.q >= 4 && t.pb - t.pa >= 2) ? t.pb - 1 : (int)t.pb;   // (q >= 4: what it follows is a stage early too)
+            };
+            // (the finals of a stage row by row -- only scheme 2 has finals of two rows in one stage, and those of the
+            // lower row follow those of the upper one)
             std::stable_sort(plan.tasks.begin() + plan.queues.first[g], plan.tasks.end(),
                              [&](const DagTask& a, const DagTask& b) {
-                                 if (a.pb != b.pb) return a.pb < b.pb;
+                                 if (stage(a) != stage(b)) return stage(a) < stage(b);
                                  const int ca = cls(a), cb = cls(b);
+                                 if ((ca == 2) != (cb == 2)) return cb == 2;
+                                 if (a.q != b.q) return a.q < b.q;
                                  if (ca != cb) return ca < cb;
-                                 if (ca == 2 && a.q != b.q) return a.q < b.q;
+                                 // (just in time: the chains of a row's tiles side by side -- first parts, second parts, ...
+                                 // -- not tile after tile: a part waits for its predecessor)
+                                 if (jit_part(a) && jit_part(b) && a.S != b.S) return a.S < b.S;
                                  return false;
                              });
         }

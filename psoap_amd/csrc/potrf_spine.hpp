@@ -69,15 +69,64 @@ __device__ __forceinline__ d4 neg(const d4& v) { return d4{-v[0], -v[1], -v[2], 
 
 // Where the fused diagonal task publishes its progress for the strip solves that follow it (dag_kernel.hpp: mailbox,
 // dag_pss).  mb == nullptr: nothing is published.
+constexpr int MB_BLOCKS = 10;      // per step b: U_bJ (J = 0..7, written for J > b), V_b = W_bb^T (8), the rhs block z_b (9)
 struct SpinePub {
-    double* mb;        // this block's half of the matrix's mailbox: slot (b, J) at ((b * 9) + J) * 256
+    double* mb;        // this block's half of the matrix's mailbox: slot (b, J) at ((b * MB_BLOCKS) + J) * 256
     int* step_w;       // MatFlags::step_w
     int base;          // 8 q
 };
+// The second level of following: the strip above this diagonal tile -- tile (q-1, q) -- is being solved by a task that
+// itself follows the factorisation of block q-1 and stores its row blocks one by one (dag_pss, `xpub`): the symmetric
+// update here consumes them as they arrive (16 rows = one LDS stage of the update), and this task also applies that
+// tile's contribution to its own right-hand side block (z of block q-1 comes step by step from the mailbox of the
+// factorisation above).  xstep == nullptr: the strip is final when wait_dep() returns (every other use).
+struct SpineFollow {
+    const double* zmb;     // the mailbox half of block q-1
+    int* xstep;            // MatFlags::xcol[q]: 8 (q-1) + b + 1 once row block b of tile (q-1, q) is in memory (two waves)
+    int base;              // 8 (q-1)
+    unsigned int* err;     // DagCtl::error (a wait that gives up)
+    const double* strip0;  // != nullptr: the final covers TWO panels -- tile (q-2, q), final when wait_dep() returns, is
+                           // applied first (eight plain stages), then the following stages of tile (q-1, q)
+};
+// row blocks delivered so far of the tile(s) whose two-flag records are xa and xb (the same record twice for one tile)
+__device__ __forceinline__ int x_steps(int* xa, int* xb, int base, int lane)
+{
+    int x = 0x7fffffff;
+    if (lane < 4) x = __hip_atomic_fetch_add((lane < 2 ? xa : xb) + (lane & 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    x = min(x, __shfl_xor(x, 1, 64));
+    x = min(x, __shfl_xor(x, 2, 64));
+    return __builtin_amdgcn_readfirstlane(x) - base;
+}
+__device__ __forceinline__ int x_wait(int* xa, int* xb, int base, unsigned int* err, int need, int lane)
+{
+    int v = x_steps(xa, xb, base, lane);
+    for (long long spins = 0; v < need; ++spins) {
+        if (spins > 4000000) {            // seconds: give up, the results are invalid and reported as such
+            if (lane == 0) __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return 8;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        v = x_steps(xa, xb, base, lane);
+    }
+    return v;
+}
+__device__ __forceinline__ int x_steps(const SpineFollow& xf, int lane) { return x_steps(xf.xstep, xf.xstep, xf.base, lane); }
+__device__ __forceinline__ int x_wait(const SpineFollow& xf, int need, int lane)
+{
+    return x_wait(xf.xstep, xf.xstep, xf.base, xf.err, need, lane);
+}
+__device__ __forceinline__ d4 x_zblock(const SpineFollow& xf, int b, int lane)
+{
+    const double* src = xf.zmb + ((size_t)b * MB_BLOCKS + 9) * 256;
+    d4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = src[r * 64 + lane];
+    return v;
+}
 // one block, accumulator-linear, with agent-scope (write-through) stores: no L2 write-back is needed before the flag
 __device__ __forceinline__ void pub_block(const SpinePub& pub, int b, int J, int lane, const d4& v)
 {
-    double* dst = pub.mb + ((size_t)b * 9 + J) * 256;
+    double* dst = pub.mb + ((size_t)b * MB_BLOCKS + J) * 256;
 #pragma unroll
     for (int r = 0; r < 4; ++r) __hip_atomic_store(dst + r * 64 + lane, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -97,13 +146,13 @@ __device__ __forceinline__ void pub_flag(const SpinePub& pub, int wave, int n_st
     }
     if (lane == 0) __hip_atomic_store(pub.step_w + wave, pub.base + n_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// blocks of U11's row I that worker wave W publishes (its owned blocks right of the diagonal)
+// blocks of row I that worker wave W publishes (its owned blocks right of the diagonal, the right-hand side included)
 constexpr int pub_count(int W, int I)
 {
     int n = 0;
     for (int s = 0; s < 3; ++s) {
         const int J = ((W - 1 - I) % 3 + 3) % 3 + 3 * s;
-        if (J <= 8 && J != I && J > I && J < 8) ++n;
+        if (J <= 8 && J != I && J > I) ++n;
     }
     return n;
 }
@@ -112,7 +161,7 @@ constexpr int pub_count(int W, int I)
 template <int W, class WaitFn, class SM>
 __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, double* Rv,
                                        const double* __restrict__ part, const double* __restrict__ strip,
-                                       WaitFn& wait_dep, SM sm, const SpinePub& pub)
+                                       WaitFn& wait_dep, SM sm, const SpinePub& pub, const SpineFollow& xf)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = lane >> 4, c = lane & 15;
@@ -141,6 +190,73 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
                 for (int r = 0; r < 4; ++r) blk[3 * I + s][r] = (c == 0) ? PSOAP_SG(Rv)[k0 + 16 * I + q + 4 * r] : 0.0;
             }
     // ---- T -= strip^T strip on the upper blocks this wave owns (K = 128 in eight LDS stages)
+    if (xf.xstep) {
+        // ... behind the strip solve that is producing the strip (SpineFollow): a following stage holds one of its row
+        // blocks.  A stage is requested ahead of the products of the one before when it is known to be there, behind
+        // them otherwise; the right-hand side blocks take that tile's contribution here as well (r_I -= X_I^T z: one
+        // more column).  With an older panel in front (strip0) its eight stages come first, unconditionally.
+        const int fr = lane & 15, fk = lane >> 4;
+        const int n0 = xf.strip0 ? NB / KB : 0, nch = n0 + NB / KB;
+        int avail = 0;
+        d4 zc = {0.0, 0.0, 0.0, 0.0}, zn = zc;
+        if (n0) {
+            stage_glds_one(xf.strip0, (size_t)ld, 0, 0, tid, sm);
+        } else {
+            avail = x_wait(xf, 1, lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            stage_glds_one(strip, (size_t)ld, 0, 0, tid, sm);
+            zc = x_zblock(xf, 0, lane);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ch = 0; ch < nch; ++ch) {
+            const int cur = ch & 1;
+            const int need = ch + 2 - n0;          // steps of the strip solve the next stage needs (<= 0: none)
+            bool early = false;
+            if (ch + 1 < nch) {
+                if (need <= 0) {
+                    stage_glds_one(xf.strip0, (size_t)ld, (ch + 1) * KB, cur ^ 1, tid, sm);
+                    early = true;
+                } else {
+                    if (avail < need) avail = x_steps(xf, lane);
+                    if (avail >= need) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        stage_glds_one(strip, (size_t)ld, (need - 1) * KB, cur ^ 1, tid, sm);
+                        zn = x_zblock(xf, need - 1, lane);
+                        early = true;
+                    }
+                }
+            }
+            const int base = cur * LDS_BUFFER + fk * LDS_LD + fr;
+            const bool with_rhs = ch >= n0;
+#pragma unroll
+            for (int I = 0; I < 8; ++I) {
+                double x[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) x[ks] = -sm[base + ks * 4 * LDS_LD + 16 * I];
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    if (owned(W, I, s) && col0(W, I) + 3 * s > I) {
+                        const int J = col0(W, I) + 3 * s;
+                        if (J == 8 && !with_rhs) continue;
+                        double y[4];
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) y[ks] = J < 8 ? sm[base + ks * 4 * LDS_LD + 16 * J] : zc[ks];
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+                            blk[3 * I + s] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[ks], y[ks], blk[3 * I + s], 0, 0, 0);
+                    }
+            }
+            if (ch + 1 < nch && !early) {
+                avail = x_wait(xf, need, lane);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                stage_glds_one(strip, (size_t)ld, (need - 1) * KB, cur ^ 1, tid, sm);
+                zn = x_zblock(xf, need - 1, lane);
+            }
+            zc = zn;
+            __syncthreads();
+        }
+    } else {
     stage_glds_one(strip, (size_t)ld, 0, 0, tid, sm);
     __syncthreads();
     {
@@ -170,6 +286,7 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
             __syncthreads();
         }
     }
+    }
     __syncthreads();   // [S0] the spine has reset the flag; the stage buffers are free for the block rows
 
 #pragma unroll 1
@@ -198,7 +315,7 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
                         const int J = col0(W, I) + 3 * s;
                         pb::store_blk(base + J * BLK, lane, res[s], sm);
                         blk[3 * I + s] = res[s];
-                        if (pub.mb && J > I && J < 8) pub_block(pub, I, J, lane, res[s]);   // U_bJ for the followers
+                        if (pub.mb && J > I) pub_block(pub, I, J < 8 ? J : 9, lane, res[s]);   // U_bJ (z_b) for the followers
                     }
             }
         }
@@ -318,7 +435,7 @@ __device__ __forceinline__ void spine_factor(d4& d, int bb, int lane, int& bad, 
 template <class WaitFn, class SM>
 __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* __restrict__ part,
                                       const double* __restrict__ strip, WaitFn& wait_dep, unsigned long long* tl, SM sm,
-                                      const SpinePub& pub)
+                                      const SpinePub& pub, const SpineFollow& xf)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = lane >> 4, c = lane & 15;
@@ -328,9 +445,56 @@ __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* 
 #pragma unroll
         for (int r = 0; r < 4; ++r) d[I][r] = PSOAP_SGC(part)[(size_t)(16 * I + q + 4 * r) * NB + 16 * I + c];
     wait_dep();
-    stage_glds_one(strip, (size_t)ld, 0, 0, tid, sm);
-    __syncthreads();
-    {
+    if (xf.xstep) {
+        // the same stages as the workers', requested as the strip solve above delivers them (worker<W>)
+        const int fr = lane & 15, fk = lane >> 4;
+        const int n0 = xf.strip0 ? NB / KB : 0, nch = n0 + NB / KB;
+        int avail = 0;
+        if (n0) {
+            stage_glds_one(xf.strip0, (size_t)ld, 0, 0, tid, sm);
+        } else {
+            avail = x_wait(xf, 1, lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            stage_glds_one(strip, (size_t)ld, 0, 0, tid, sm);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ch = 0; ch < nch; ++ch) {
+            const int cur = ch & 1;
+            const int need = ch + 2 - n0;
+            bool early = false;
+            if (ch + 1 < nch) {
+                if (need <= 0) {
+                    stage_glds_one(xf.strip0, (size_t)ld, (ch + 1) * KB, cur ^ 1, tid, sm);
+                    early = true;
+                } else {
+                    if (avail < need) avail = x_steps(xf, lane);
+                    if (avail >= need) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        stage_glds_one(strip, (size_t)ld, (need - 1) * KB, cur ^ 1, tid, sm);
+                        early = true;
+                    }
+                }
+            }
+            const int base = cur * LDS_BUFFER + fk * LDS_LD + fr;
+#pragma unroll
+            for (int I = 0; I < 8; ++I) {
+                double x[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) x[ks] = sm[base + ks * 4 * LDS_LD + 16 * I];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) d[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x[ks], x[ks], d[I], 0, 0, 0);
+            }
+            if (ch + 1 < nch && !early) {
+                avail = x_wait(xf, need, lane);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                stage_glds_one(strip, (size_t)ld, (need - 1) * KB, cur ^ 1, tid, sm);
+            }
+            __syncthreads();
+        }
+    } else {
+        stage_glds_one(strip, (size_t)ld, 0, 0, tid, sm);
+        __syncthreads();
         const int fr = lane & 15, fk = lane >> 4;
 #pragma unroll 1
         for (int ch = 0; ch < NB / KB; ++ch) {
@@ -401,13 +565,14 @@ template <class WaitFn, class SM = SmemKernel>
 __device__ __forceinline__ void potrf_spine_fused(double* Km, int ld, int k0, double* Wm, double* Rv, MatAcc* acc,
                                                   const double* __restrict__ part, const double* __restrict__ strip,
                                                   WaitFn wait_dep, unsigned long long* tl = nullptr, SM sm = SM(),
-                                                  ps::SpinePub pub = ps::SpinePub{nullptr, nullptr, 0})
+                                                  ps::SpinePub pub = ps::SpinePub{nullptr, nullptr, 0},
+                                                  ps::SpineFollow xf = ps::SpineFollow{nullptr, nullptr, 0, nullptr, nullptr})
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) ps::spine(Km, ld, k0, part, strip, wait_dep, tl, sm, pub);
-    else if (wave == 1) ps::worker<1>(Km, ld, k0, Wm, Rv, part, strip, wait_dep, sm, pub);
-    else if (wave == 2) ps::worker<2>(Km, ld, k0, Wm, Rv, part, strip, wait_dep, sm, pub);
-    else ps::worker<3>(Km, ld, k0, Wm, Rv, part, strip, wait_dep, sm, pub);
+    if (wave == 0) ps::spine(Km, ld, k0, part, strip, wait_dep, tl, sm, pub, xf);
+    else if (wave == 1) ps::worker<1>(Km, ld, k0, Wm, Rv, part, strip, wait_dep, sm, pub, xf);
+    else if (wave == 2) ps::worker<2>(Km, ld, k0, Wm, Rv, part, strip, wait_dep, sm, pub, xf);
+    else ps::worker<3>(Km, ld, k0, Wm, Rv, part, strip, wait_dep, sm, pub, xf);
     __syncthreads();   // all outputs issued, the reductions are in LDS
     if (threadIdx.x == 0) {
         const double l = sm[pb::OFF_RED + 0];

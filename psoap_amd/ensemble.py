@@ -7,7 +7,9 @@ per-chunk likelihoods (/root/reference/psoap/sample_parallel.py:258-278 fork,
 ensemble for them, and the per-(chunk, walker) log-probabilities are exchanged with a
 single ``all_gather`` (RCCL over xGMI when the tensors are on the GPU, gloo in the CPU
 tests).  Every rank then sums over chunks in the fixed order k = 0..n_chunks-1, so the
-walker log-probabilities are bit-identical on every rank and for every G.
+walker log-probabilities are bit-identical on every rank.  (Across world sizes they agree to a
+few ulp: how a rank's matrices are scheduled -- and with it the order of the partial sums inside
+the factorisation -- depends on how many of them share a launch.)
 
 There is no other communication on the path: chunks are independent.
 """

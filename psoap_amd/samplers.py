@@ -13,8 +13,11 @@ One proposal per iteration cannot fill a GPU (a single N = 6000 evaluation takes
 39 ms), and the reference's own workflow already runs several independent chains side by side
 (``run_index`` directories, /root/reference/scripts/psoap_gelman_rubin.py).  ``MultiChainMHSampler``
 advances B such chains in lock-step: every iteration draws one proposal per chain and evaluates all B
-with ONE ``lnprob_batch`` call.  Each chain owns its random stream, so chain b is bit-identical to a
-scalar ``MHSampler`` run with that stream -- the batching changes throughput, not statistics.
+with ONE ``lnprob_batch`` call.  Each chain owns its random stream, so chain b takes the draws and -- given the same
+log-probabilities -- the decisions of a scalar ``MHSampler`` run with that stream: the batching changes throughput, not
+statistics.  (A batched device evaluation agrees with a single one to a few ulp, not bit for bit: the persistent kernel
+schedules 1-4 matrices differently from 32, so its sums round differently; results are bit-reproducible for a given
+batch size.)
 """
 from __future__ import annotations
 

@@ -50,9 +50,9 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
     q_rows = [sum(Ps[g::8]) for g in range(8)]
     q_count = [len(Ps[g::8]) for g in range(8)]
     want_chain = max(q_rows) <= 150 or max(q_count) <= 1
-    # ... and within that, the following scheme (scheme 2) for up to four matrices of at most 32 block rows: from block
+    # ... and within that, the following scheme (scheme 2) for up to eight matrices: from block
     # row 2 on the strip solves follow the factorisation (DAG_WAITNEXT on OFF finals), the diagonal task solves nothing
-    following = want_chain and B <= 4 and max(Ps) <= 32
+    following = want_chain and B <= 8
     assert np.all(chain[tasks["S"] > 1] == want_chain) if (tasks["S"] > 1).any() else True
     # one queue per XCD: matrix b lives in queue b mod 8, queues are contiguous ranges of the list
     first = plan.queue_first
@@ -116,7 +116,8 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
         if follows:
             assert following and q >= 2 and diag_final_ticket[(b, q)] < t      # behind the task whose progress it polls
         if wait_next:
-            assert want_chain and k["type"] == DIAG and int(k["pb"]) == q and int(k["pb"]) - int(k["pa"]) == 1
+            assert want_chain and k["type"] == DIAG and int(k["pb"]) == q
+            assert int(k["pb"]) - int(k["pa"]) == (2 if flags[t] & NOSOLVE else 1)    # (a following diagonal task: two panels)
             prev = diag_final_ticket[(b, q - 1)]
             if following and q - 1 >= 2:
                 # the tile right of the diagonal above is solved by its own (following) task, which announces it
@@ -126,12 +127,25 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
                 assert prev < t and flags[prev] & FUSED
         for m in range(int(k["pb"]) - (1 if wait_next else 0)):
             assert row_final_last_ticket[(b, m)] < t
-        if flags[t] & FUSED:
+        # the second level of the following scheme: the strip solve of tile (q, q+1), q >= 2, delivers its tile row block
+        # by row block (FUSED on a following OFF final) to the diagonal task of block q+1 (NOSOLVE on a DIAG final), which
+        # must be one the out-of-line fast path takes: chained, a one-panel final with a running sum to start from
+        xpub = follows and bool(flags[t] & FUSED)
+        xdiag = k["type"] == DIAG and bool(flags[t] & NOSOLVE)
+        assert xpub == follows           # every following strip solve delivers its tile progressively
+        if xpub and j == q + 1 and q + 1 < Ps[b]:
+            nxt = diag_final_ticket[(b, q + 1)]
+            assert flags[t] & NOSOLVE and flags[nxt] & NOSOLVE and t < nxt
+        if xdiag:
+            assert following and q >= 3 and wait_next and chain[t] and k["S"] >= 2
+            src = finals[(b, q - 1, q)]
+            assert src < t and flags[src] & FUSED and flags[src] & WAITNEXT
+        if flags[t] & FUSED and not xpub:
             # DIAG(q) also solves tile (q, q+1): its update-only task comes earlier in the list
             assert k["type"] == DIAG and q + 1 < Ps[b]
             upd = finals[(b, q, q + 1)]
             assert upd < t and flags[upd] & NOSOLVE
-        if flags[t] & NOSOLVE:
+        if flags[t] & NOSOLVE and not xdiag:
             assert k["type"] == OFF and j == q + 1
             assert bool(flags[diag_final_ticket[(b, q)]] & FUSED) == (not follows)
         if want_chain and k["type"] == DIAG:
@@ -154,7 +168,9 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
                     assert [int(tasks[p]["S"]) for p in parts] == list(range(len(parts)))
                     assert got == [(got[0] & ~1) + (i & 1) for i in range(len(parts))]     # even/odd ping-pong
                     assert int(k["slot"]) == got[-1]
-                    assert int(k["pb"]) - int(k["pa"]) == 1
+                    # (a following strip solve takes the last TWO panels: its chain then needs the row before the row
+                    # above only, and the hand-over of the partial tile is off the row-to-row path)
+                    assert int(k["pb"]) - int(k["pa"]) == (2 if follows or (k["type"] == DIAG and flags[t] & NOSOLVE) else 1)
                 else:
                     # gathered: PARTs wait for nothing, the final reads all of them from the first slot
                     assert all(int(tasks[p]["S"]) == 0 for p in parts)
@@ -280,11 +296,13 @@ def test_following_scheme_task_flags_and_ticket_order(P):
         if ty[t] == DIAG:
             diag_ticket[q] = t
             assert bool(flags[t] & FUSED) == (q < 2 and q + 1 < P), (q, hex(flags[t]))
+            assert bool(flags[t] & NOSOLVE) == (q >= 3), (q, hex(flags[t]))       # follows the strip solve of tile (q-1, q)
         elif ty[t] == OFF:
             off_tickets.setdefault(q, {})[j] = t
             if q >= 2:
                 assert flags[t] & WAITNEXT, (q, j)                                    # follows
                 assert bool(flags[t] & NOSOLVE) == (j == q + 1), (q, j)                 # the tile the next diagonal waits for
+                assert flags[t] & FUSED, (q, j)                                        # delivers its tile row block by row block
             else:
                 assert not (flags[t] & WAITNEXT)
                 assert bool(flags[t] & NOSOLVE) == (j == q + 1 and q + 1 < P)           # update-only, solved by the fused DIAG

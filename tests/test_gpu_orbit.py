@@ -55,7 +55,8 @@ def test_lnprob_of_p_matches_reference(gorb, model, c, shape, seeds, key):
         got = w.lnprob_batch(fit)
         for i in range(len(want)):
             assert abs(got[i] - want[i]) <= LNP_RTOL * max(1.0, abs(want[i])), (model, i, got[i], want[i])
-        assert w.lnprob(fit[1]) == got[1]
+        one = w.lnprob(fit[1])               # a single evaluation is scheduled differently from the batch: a few ulp
+        assert abs(one - got[1]) <= 1e-13 * abs(got[1]) and w.lnprob(fit[1]) == one
         if model == "SB2":
             fast = fit[0].copy()
             fast[1] = 4.0e5                       # K: faster than light -> -inf (sample_parallel.py:186-187)

@@ -42,10 +42,14 @@ def test_upload_overlaps_eval_without_mixing_batches(mode):
         h.upload(*sets[1])
         h.eval()
         assert np.array_equal(h.fetch(), serial[1])
-        # smaller batch after a larger one, and the velocity upload path through the same slots
+        # smaller batch after a larger one, and the velocity upload path through the same slots (two matrices are
+        # scheduled differently from six -- the following scheme -- so the sums round differently: a few ulp)
         h.upload(sets[3][0][:2], sets[3][1][:2])
         h.eval()
-        assert np.array_equal(h.fetch(), serial[3][:2])
+        two = h.fetch()
+        assert np.all(np.abs(two - serial[3][:2]) <= 1e-13 * np.abs(serial[3][:2]))
+        h.eval()
+        assert np.array_equal(h.fetch(), two)
 
 
 def test_pipeline_with_device_side_doppler_shift():

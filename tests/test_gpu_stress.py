@@ -46,10 +46,14 @@ def test_many_back_to_back_batches_same_handle():
     lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, 8, seed=4))
     with ChunkHandle(ch.fl, ch.sigma, max_batch=8) as h:
         ref = h.lnlike_batch(lw, gps)
+        first = {}
         for rep in range(40):
             B = 1 + rep % 8
             got = h.lnlike_batch(lw[:B], gps[:B])
-            assert np.array_equal(got, ref[:B]), rep
+            # bit for bit the same whenever the same batch size comes round again; across batch sizes the schedule
+            # (throughput / latency / following scheme) and with it the order of the sums may differ: a few ulp
+            assert np.array_equal(got, first.setdefault(B, got)), rep
+            assert np.all(np.abs(got - ref[:B]) <= 1e-13 * np.abs(ref[:B])), rep
 
 
 def test_not_positive_definite_inside_batch():
