@@ -1153,10 +1153,9 @@ inline int dag_split_factor(int tasks_in_row, int q, int workers, int scheme, in
     // PSOAP_DAG_SPLIT_PCT / PSOAP_DAG_SPLIT_MIN override both numbers (experiments).
     static const int env_pct = getenv("PSOAP_DAG_SPLIT_PCT") ? atoi(getenv("PSOAP_DAG_SPLIT_PCT")) : 0;
     static const int env_min = getenv("PSOAP_DAG_SPLIT_MIN") ? atoi(getenv("PSOAP_DAG_SPLIT_MIN")) : 0;
-    // (scheme 2, a single matrix: a quarter -- with the PARTs handed out just in time the chains run ahead of the
-    // finals anyway, and every part less is a partial-tile hand-over less: N = 6000: 3.06 -> 2.80 ms; with four matrices
-    // the same setting costs 3-8 %)
-    const int pct = env_pct > 0 ? env_pct : (scheme == 2 && n_mats == 1 ? 25 : (scheme >= 1 ? 50 : 100));
+    // (scheme 2: 35 % -- with the PARTs handed out just in time the chains run ahead of the finals anyway, and every part
+    // less is a partial-tile hand-over less; measured over N = 4096 .. 8192, B = 1 .. 8: 25 / 35 / 50 / 70 %)
+    const int pct = env_pct > 0 ? env_pct : (scheme == 2 ? 35 : (scheme >= 1 ? 50 : 100));
     const int minp = env_min > 0 ? env_min : (scheme >= 1 ? 4 : 2);
     int S = 1;
     while (S < 8 && tasks_in_row * S * 100 < workers * pct && minp * S <= q) S *= 2;
@@ -1424,7 +1423,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
 // more than one matrix; throughput beyond (N = 6000, B = 32: 39.2 vs 39.9 ms; N = 8192, B = 32: 95.0 vs 96.1).
 // (Readiness ordering was also tried for the throughput scheme: 800 -> 776 evals/s, not adopted.)
 constexpr int DAG_LATENCY_QUEUE_ROWS = 150;
-constexpr int DAG_FOLLOW_MAX_MATS = 8;
+constexpr int DAG_FOLLOW_MAX_MATS = 16;
 inline int dag_auto_scheme(const std::vector<int>& Ps)
 {
     long long rows[DAG_QUEUES] = {};
@@ -1441,8 +1440,9 @@ inline int dag_auto_scheme(const std::vector<int>& Ps)
     }
     const int latency = (max_rows <= DAG_LATENCY_QUEUE_ROWS || max_count <= 1) ? 1 : 0;
 #ifdef PSOAP_FOLLOW
-    // following strip solves (scheme 2) where they were measured to win (profiles/r3_follow_table.txt: N = 2000 .. 8192): up
-    // to eight matrices -- single evaluations 13-30 % faster than scheme 1, eight matrices 4-9 %; a tie or a loss from 16 on
+    // following strip solves (scheme 2) where they were measured to win (profiles/r3_follow_table.txt: N = 2000 .. 8192, B =
+    // 1 .. 32): up to sixteen matrices -- single evaluations 15-30 % faster than scheme 1, eight matrices 4-11 %, sixteen
+    // 1-2 %; 0-2 % slower from 24 on
     if (latency == 1 && Ps.size() <= (size_t)DAG_FOLLOW_MAX_MATS) return 2;
 #endif
     return latency;
@@ -1491,9 +1491,21 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
             auto jit_part = [jit, &Ps](const DagTask& t) {
                 return jit > 0 && (t.type & DAG_TYPE_MASK) == DAG_PART && (t.type & DAG_CHAIN) && (int)t.q < Ps[t.b];
             };
-            auto stage = [jit, &jit_part](const DagTask& t) {
+            // (measured: 6 block rows ahead; 4 .. 12 within 2 %, a lead that grows with the row index 5-8 % worse)
+            // (... and a chain's parts one after the other over the stages of that lead, not all in its first one: a part
+            // waits for its predecessor, and a workgroup that holds a waiting part works on nothing else)
+            std::vector<int> chain_parts(plan.n_ctrs + 1, 1);
+            if (jit > 0)
+                for (size_t i = plan.queues.first[g]; i < plan.tasks.size(); ++i) {
+                    const DagTask& t = plan.tasks[i];
+                    if ((t.type & DAG_TYPE_MASK) != DAG_PART && (t.type & DAG_CHAIN) && t.S > 1) chain_parts[t.ctr] = t.S - 1;
+                }
+            auto stage = [jit, &jit_part, &chain_parts](const DagTask& t) {
                 const int ty = t.type & DAG_TYPE_MASK;
-                if (jit_part(t)) return std::max((int)t.pb, (int)t.q - jit);
+                if (jit_part(t)) {
+                    const int spread = jit > 2 ? (int)t.S * (jit - 2) / chain_parts[t.ctr] : 0;
+                    return std::max((int)t.pb, (int)t.q - jit + spread);
+                }
                 const bool follows = (ty == DAG_OFF && (t.type & DAG_WAITNEXT)) || (ty == DAG_DIAG && (t.type & DAG_NOSOLVE));
                 return (follows && t.q >= 4 && t.pb - t.pa >= 2) ? t.pb - 1 : (int)t.pb;   // (q >= 4: what it follows is a stage early too)
             };
@@ -1504,6 +1516,8 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
                                  if (stage(a) != stage(b)) return stage(a) < stage(b);
                                  const int ca = cls(a), cb = cls(b);
                                  if ((ca == 2) != (cb == 2)) return cb == 2;
+                                 // (tried: within a stage the PARTs that wait for nothing ahead of the ones that need the row
+                                 // just finishing -- 3-5 % slower: those are the chains of the nearest rows)
                                  if (a.q != b.q) return a.q < b.q;
                                  if (ca != cb) return ca < cb;
                                  // (just in time: the chains of a row's tiles side by side -- first parts, second parts, ...
