@@ -1541,12 +1541,15 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
 // (tools/latency_quick.py under PSOAP_DAG_WORKERS), one per compute unit wins while
 //     algorithmic flops of the batch  <=  3.3e9 x block rows of its largest matrix
 // (chain time ~ 75 us per block row against ~35 TFLOP/s of the half-populated device), i.e. B N^2 <~ 7.7e7.
-inline int dag_pick_workers(double flops, int Pmax, int compute_units, int max_workers)
+// Round 3 (following scheme): several matrices -- 2.0e9 instead of 3.3e9: their strip solves hold workgroups while they
+// follow the factorisation, which a second workgroup per compute unit makes up for earlier (N = 6000, B = 2: 4.29 -> 3.99
+// ms; N = 4096, B = 4: 2.87 -> 2.70 ms; N = 4096, B = 2 stays with one: 1.92 against 2.15 ms).
+inline int dag_pick_workers(double flops, int Pmax, int compute_units, int max_workers, int n_mats = 1)
 {
     if (const char* e = getenv("PSOAP_DAG_WORKERS"))      // experiments
         if (atoi(e) > 0) return atoi(e);
     if (max_workers <= compute_units) return max_workers;
-    return flops <= 3.3e9 * (double)Pmax ? compute_units : max_workers;
+    return flops <= (n_mats > 1 ? 2.0e9 : 3.3e9) * (double)Pmax ? compute_units : max_workers;
 }
 inline double dag_batch_flops(const std::vector<int>& Ps, int Mt = 0)
 {

@@ -429,7 +429,7 @@ extern "C" int psoap_dag_pick_workers(int B, const int* Ps, int Mt, int compute_
     const std::vector<int> v(Ps, Ps + B);
     int Pmax = 0;
     for (int P : v) Pmax = P > Pmax ? P : Pmax;
-    *workers = dag_pick_workers(dag_batch_flops(v, Mt), Pmax, compute_units, max_workers);
+    *workers = dag_pick_workers(dag_batch_flops(v, Mt), Pmax, compute_units, max_workers, B);
     return 0;
 }
 
@@ -710,7 +710,7 @@ static int dag_prepare(psoap_chunk* h)
     // PSOAP_DAG_SCHEME=0|1 pins the split scheme (experiments); default: automatic
     const char* env_scheme = getenv("PSOAP_DAG_SCHEME");
     const std::vector<int> Ps((size_t)sl.B, h->P);
-    const int workers = dag_pick_workers(dag_batch_flops(Ps), h->P, h->n_cus, h->dag_grid);
+    const int workers = dag_pick_workers(dag_batch_flops(Ps), h->P, h->n_cus, h->dag_grid, (int)Ps.size());
     DagPlan plan = dag_build_tasks(Ps, workers, env_scheme ? atoi(env_scheme) : -1);
     if (plan.n_ctrs > h->arrive_cap) FAIL("internal: arrival counter capacity exceeded");
     if (plan.tasks.size() > h->tasks_cap) {
@@ -994,7 +994,7 @@ extern "C" int psoap_group_eval(psoap_group* g)
         const char* env_scheme = getenv("PSOAP_DAG_SCHEME");
         int Pmax = 0;
         for (int P : Ps) Pmax = P > Pmax ? P : Pmax;
-        g->workers = dag_pick_workers(dag_batch_flops(Ps), Pmax, g->hs[0]->n_cus, g->hs[0]->dag_grid);
+        g->workers = dag_pick_workers(dag_batch_flops(Ps), Pmax, g->hs[0]->n_cus, g->hs[0]->dag_grid, (int)Ps.size());
         DagPlan plan = dag_build_tasks(Ps, g->workers, env_scheme ? atoi(env_scheme) : -1);
         if ((size_t)total > g->mats_cap) {
             if (g->dMats) HIP_TRY(hipFree(g->dMats));
