@@ -90,6 +90,7 @@ struct alignas(64) DagCtl {
 // queue g holds tasks[first[g] .. first[g+1]) in ticket order (kernel argument, by value)
 struct DagQueues {
     unsigned int first[DAG_QUEUES + 1];
+    unsigned int follow_first;      // scheme 2: the first block row whose strip solves follow (0, or 2: PSOAP_FOLLOW_ROW0=0)
 };
 
 // One entry of the host-built task list (dag_build_tasks); the ticket is the index.
@@ -550,7 +551,8 @@ PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double*
     potrf_spine_fused(Km, ld, k0, Wm, Rv, acc, prev, Km + (size_t)(k0 - NB) * ld + k0, wait_dep, tl, sm);
     (void)wt0;
 #else
-    potrf_spine_fused(Km, ld, k0, Wm, Rv, acc, prev, Km + (size_t)(k0 - NB) * ld + k0, wait_dep, tl, sm,
+    // (block 0 has no tile above it: strip == nullptr, no update)
+    potrf_spine_fused(Km, ld, k0, Wm, Rv, acc, prev, q > 0 ? Km + (size_t)(k0 - NB) * ld + k0 : nullptr, wait_dep, tl, sm,
                       ps::SpinePub{wt0 + 2 * NB * NB + mb_slot(q, 0, 0), f->step_w, 8 * q},
                       xfollow ? ps::SpineFollow{wt0 + 2 * NB * NB + mb_slot(q - 1, 0, 0), f->xcol[q], 8 * (q - 1), &ctl->error,
                                                 two_panels ? Km + (size_t)(k0 - 2 * NB) * ld + k0 : nullptr}
@@ -795,6 +797,7 @@ struct DagSpecialArgs {
     int* arrive_ctr;
     int xlink;                     // diagonal task: the strip above arrives row block by row block (SpineFollow);
                                    // following strip solve: it delivers its tile that way (dag_pss, xpub)
+    int xfirst;                    // the first block row whose strip solves follow
 };
 
 template <int C, bool AUG>
@@ -852,7 +855,7 @@ __device__ __attribute__((noinline)) void dag_special(const DagSpecialArgs* a)
         dag_store_updated<C, AUG, true>(t, nullptr, 0, k0, j0, a->lw, g, dsum, a->sigma, a->N, scale, a->Npad, a->aug, nullptr);
         dag_negate(t);
     }
-    const int xupd = xlink && q >= 3;      // the row above is a following one that delivers its tiles progressively
+    const int xupd = xlink && q >= si(a->xfirst) + 1;      // the row above is a following one that delivers its tiles progressively
     if (xupd) {
         if (pb - pa > 1) {
             dag_wait_ge(&f->rows_done, pb - 1, ctl, 1u);
@@ -980,7 +983,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
 #ifdef PSOAP_FOLLOW
         // (-DPSOAP_FOLLOW: both out-of-line task kinds go through dag_special, further down, at one call site)
         const bool fast_diag = LAT && preload && ttype == DAG_DIAG && (task.type & DAG_WAITNEXT) &&
-                               (task.pb - task.pa == 1 || ((task.type & DAG_NOSOLVE) && task.pb - task.pa == 2));
+                               (task.pb - task.pa == 1 || task.pb == 0 || ((task.type & DAG_NOSOLVE) && task.pb - task.pa == 2));
         const bool follow = LAT && ttype == DAG_OFF && (task.type & DAG_WAITNEXT);
         if (fast_diag || follow) {
             // scheme 2's strip solves follow the factorisation of block q step by step, on the tile in registers; the
@@ -1002,6 +1005,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
             // second level of following: DAG_NOSOLVE on the diagonal task (it follows the strip solve of the tile above),
             // DAG_FUSED on a strip solve (it delivers its tile row block by row block, and follows the row above likewise)
             args.xlink = fast_diag ? ((task.type & DAG_NOSOLVE) != 0) : ((task.type & DAG_FUSED) != 0);
+            args.xfirst = (int)queues.follow_first;
             dag_special<C, AUG>(&args);
             if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
             continue;
@@ -1185,6 +1189,11 @@ inline int dag_jit_rows()
     const char* e = getenv("PSOAP_DAG_JIT");      // experiments; 0: readiness order
     return e ? atoi(e) : 6;
 }
+inline int dag_follow_first_row()
+{
+    const char* e = getenv("PSOAP_FOLLOW_ROW0");      // experiments; 0: rows 0 and 1 keep the forms of scheme 1
+    return (e && e[0] == '0') ? 2 : 0;
+}
 inline bool dag_xfollow_enabled()
 {
     const char* e = getenv("PSOAP_XFOLLOW");
@@ -1325,14 +1334,46 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
         // block rows step by step -- the strip solves FOLLOW the factorisation (dag_pss: DAG_WAITNEXT on an OFF task),
         // the diagonal task solves nothing itself, and the strip solve of tile (q, q+1) publishes next_done (DAG_NOSOLVE
         // on a following OFF task).  Rows 0 and 1 keep the forms of scheme 1.
-        const bool following = (scheme == 2) && q >= 2;
+        // (dag_follow_first_row(): 0 -- the first block rows follow as well: their diagonal tasks then need a running sum to
+        // start from, which a PART with an empty range provides, it "carries K"; 2: rows 0 and 1 in the forms of scheme 1)
+        const int q_f = dag_follow_first_row();
+        const bool following = (scheme == 2) && q >= q_f;
         // (block row r: its solved tiles are delivered row block by row block (DAG_FUSED on a following OFF task) to the
         // tasks of block row r+1 that read them -- the diagonal task of block r+1 (DAG_NOSOLVE on a DIAG task) and the
         // last panel of the strip solves' updates; PSOAP_XFOLLOW=0 keeps the first level only -- A/B measurements)
-        auto xlink = [&](int r) { return scheme == 2 && r >= 2 && dag_xfollow_enabled(); };
+        auto xlink = [&](int r) { return scheme == 2 && r >= q_f && dag_xfollow_enabled(); };
         auto fused = [&](int b) { return scheme >= 1 && !following && q + 1 < Ps[b]; };
         // 1. DIAG finals of this row
-        if (q <= 1) {
+        if (q <= 1 && following) {
+            // the fused fast diagonal task (the one that publishes its steps) for the first block rows too: a chain of
+            // one PART over no panels -- the covariance tile -- and the final over [0, q)
+            for (int b : mats) {
+                if (q >= Ps[b]) continue;
+                const unsigned int ctr = plan.n_ctrs++;
+                plan.n_slots += plan.n_slots & 1u;
+                const unsigned int slot0 = plan.n_slots;
+                plan.n_slots = slot0 + 1;
+                DagTask t{};
+                t.type = DAG_PART | DAG_CHAIN;
+                t.b = (unsigned short)b;
+                t.q = t.j = (unsigned char)q;
+                t.S = 0;
+                t.pa = t.pb = 0;
+                t.slot = slot0;
+                t.ctr = ctr;
+                plan.tasks.push_back(t);
+                DagTask fin{};
+                fin.type = DAG_DIAG | DAG_CHAIN | DAG_WAITNEXT | ((q == 1 && xlink(0)) ? DAG_NOSOLVE : 0);
+                fin.b = (unsigned short)b;
+                fin.q = fin.j = (unsigned char)q;
+                fin.S = 2;
+                fin.pa = 0;
+                fin.pb = (unsigned char)q;
+                fin.slot = slot0;
+                fin.ctr = ctr;
+                plan.tasks.push_back(fin);
+            }
+        } else if (q <= 1) {
             for (int b : mats)
                 if (q < Ps[b])
                     dag_emit(plan, DAG_DIAG, b, q, q, 0, q, 1, scheme,
@@ -1386,7 +1427,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
                 DagTask fin{};
                 fin.type = DAG_DIAG | flag;
                 if (chain) fin.type |= DAG_WAITNEXT;
-                if (chain && q + 2 < Ps[b] && !(scheme == 2 && q + 1 >= 2)) fin.type |= DAG_FUSED;
+                if (chain && q + 2 < Ps[b] && !(scheme == 2 && q + 1 >= q_f)) fin.type |= DAG_FUSED;
                 // second level of following: the strip solve of tile (q, q+1) follows the factorisation of block q
                 // (q >= 2) and this task follows IT -- DAG_NOSOLVE here, DAG_FUSED on that strip solve (step 3 below)
                 if (xlink(q)) fin.type |= DAG_NOSOLVE;
@@ -1477,6 +1518,7 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
             auto cls = [](const DagTask& t) {
                 const int ty = t.type & DAG_TYPE_MASK;
                 if (ty == DAG_OFF && (t.type & DAG_NOSOLVE) && !(t.type & DAG_WAITNEXT)) return -1;   // update-only: in front of its DIAG
+                if (ty == DAG_PART && t.pb == 0 && t.q == t.j && t.q <= 1) return -2;  // the running sum DIAG(0) / DIAG(1) start from
                 return ty == DAG_DIAG ? 0 : (ty == DAG_OFF ? 1 : 2);      // PART and DAG_SCHUR: whatever is left of a stage
             };
             // (scheme 2: a final that covers two panels -- a following strip solve or the diagonal task that follows
@@ -1528,6 +1570,7 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
         }
     }
     plan.queues.first[DAG_QUEUES] = (unsigned int)plan.tasks.size();
+    plan.queues.follow_first = (unsigned int)dag_follow_first_row();
     return plan;
 }
 

@@ -256,7 +256,7 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
             zc = zn;
             __syncthreads();
         }
-    } else {
+    } else if (strip) {
     stage_glds_one(strip, (size_t)ld, 0, 0, tid, sm);
     __syncthreads();
     {
@@ -492,7 +492,7 @@ __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* 
             }
             __syncthreads();
         }
-    } else {
+    } else if (strip) {
         stage_glds_one(strip, (size_t)ld, 0, 0, tid, sm);
         __syncthreads();
         const int fr = lane & 15, fk = lane >> 4;

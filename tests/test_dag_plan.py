@@ -50,8 +50,8 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
     q_rows = [sum(Ps[g::8]) for g in range(8)]
     q_count = [len(Ps[g::8]) for g in range(8)]
     want_chain = max(q_rows) <= 150 or max(q_count) <= 1
-    # ... and within that, the following scheme (scheme 2) for up to sixteen matrices: from block
-    # row 2 on the strip solves follow the factorisation (DAG_WAITNEXT on OFF finals), the diagonal task solves nothing
+    # ... and within that, the following scheme (scheme 2) for up to sixteen matrices: the strip solves follow the
+    # factorisation (DAG_WAITNEXT on OFF finals), the diagonal task solves nothing
     following = want_chain and B <= 16
     assert np.all(chain[tasks["S"] > 1] == want_chain) if (tasks["S"] > 1).any() else True
     # one queue per XCD: matrix b lives in queue b mod 8, queues are contiguous ranges of the list
@@ -114,12 +114,14 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
         follows = bool(flags[t] & WAITNEXT) and k["type"] == OFF      # on an OFF final the bit means "follow the factorisation"
         wait_next = bool(flags[t] & WAITNEXT) and not follows
         if follows:
-            assert following and q >= 2 and diag_final_ticket[(b, q)] < t      # behind the task whose progress it polls
+            assert following and diag_final_ticket[(b, q)] < t      # behind the task whose progress it polls
+        two_panel_diag = k["type"] == DIAG and bool(flags[t] & NOSOLVE) and q >= 3   # (a following diagonal task: two panels)
         if wait_next:
             assert want_chain and k["type"] == DIAG and int(k["pb"]) == q
-            assert int(k["pb"]) - int(k["pa"]) == (2 if flags[t] & NOSOLVE else 1)    # (a following diagonal task: two panels)
+            assert int(k["pb"]) - int(k["pa"]) == (2 if two_panel_diag else min(q, 1))
+        if wait_next and q >= 1:
             prev = diag_final_ticket[(b, q - 1)]
-            if following and q - 1 >= 2:
+            if following:
                 # the tile right of the diagonal above is solved by its own (following) task, which announces it
                 solver = finals[(b, q - 1, q)]
                 assert solver < t and (flags[solver] & NOSOLVE) and (flags[solver] & WAITNEXT) and not flags[prev] & FUSED
@@ -137,7 +139,7 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
             nxt = diag_final_ticket[(b, q + 1)]
             assert flags[t] & NOSOLVE and flags[nxt] & NOSOLVE and t < nxt
         if xdiag:
-            assert following and q >= 3 and wait_next and chain[t] and k["S"] >= 2
+            assert following and q >= 1 and wait_next and chain[t] and k["S"] >= 2
             src = finals[(b, q - 1, q)]
             assert src < t and flags[src] & FUSED and flags[src] & WAITNEXT
         if flags[t] & FUSED and not xpub:
@@ -148,8 +150,12 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
         if flags[t] & NOSOLVE and not xdiag:
             assert k["type"] == OFF and j == q + 1
             assert bool(flags[diag_final_ticket[(b, q)]] & FUSED) == (not follows)
-        if want_chain and k["type"] == DIAG:
-            assert bool(flags[t] & FUSED) == (q + 1 < Ps[b] and not (following and q >= 2)) and wait_next == (q >= 1)
+        if following and k["type"] == DIAG:
+            # (every diagonal task is the fused fast one that publishes its steps -- it starts from the running sum of a
+            # chain, which for blocks 0 and 1 is a PART over no panels: the covariance tile)
+            assert not flags[t] & FUSED and wait_next and chain[t] and k["S"] >= 2
+        elif want_chain and k["type"] == DIAG:
+            assert bool(flags[t] & FUSED) == (q + 1 < Ps[b]) and wait_next == (q >= 1)
         if not want_chain:
             assert not flags[t] & (NOSOLVE | WAITNEXT | FUSED)
         if k["type"] != PART:
@@ -170,7 +176,7 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
                     assert int(k["slot"]) == got[-1]
                     # (a following strip solve takes the last TWO panels: its chain then needs the row before the row
                     # above only, and the hand-over of the partial tile is off the row-to-row path)
-                    assert int(k["pb"]) - int(k["pa"]) == (2 if follows or (k["type"] == DIAG and flags[t] & NOSOLVE) else 1)
+                    assert int(k["pb"]) - int(k["pa"]) == (2 if follows or two_panel_diag else min(q, 1))
                 else:
                     # gathered: PARTs wait for nothing, the final reads all of them from the first slot
                     assert all(int(tasks[p]["S"]) == 0 for p in parts)
@@ -277,10 +283,9 @@ def test_schur_tiles_of_the_augmented_launch(P, Mt, Ms, scheme):
 
 @pytest.mark.parametrize("P", [3, 16, 32, 47])
 def test_following_scheme_task_flags_and_ticket_order(P):
-    """Scheme 2: from block row 2 on the diagonal task solves nothing (no DAG_FUSED), every strip solve follows it
-    (DAG_WAITNEXT on an OFF final) and therefore sits BEHIND it in the ticket order, and the strip solve of tile
-    (q, q+1) -- flagged DAG_NOSOLVE, here "publishes next_done" -- sits in front of the next diagonal task, which waits
-    for it.  Rows 0 and 1 keep the forms of scheme 1."""
+    """Scheme 2: the diagonal task solves nothing (no DAG_FUSED), every strip solve follows it (DAG_WAITNEXT on an OFF
+    final) and therefore sits BEHIND it in the ticket order, and the strip solve of tile (q, q+1) -- flagged DAG_NOSOLVE,
+    here "publishes next_done" -- sits in front of the next diagonal task, which follows it."""
     from psoap_amd import _lib
     L = _lib.load()
     n, slots, ctrs = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
@@ -296,22 +301,18 @@ def test_following_scheme_task_flags_and_ticket_order(P):
         q, j = int(k["q"]), int(k["j"])
         if ty[t] == DIAG:
             diag_ticket[q] = t
-            assert bool(flags[t] & FUSED) == (q < 2 and q + 1 < P), (q, hex(flags[t]))
-            assert bool(flags[t] & NOSOLVE) == (q >= 3), (q, hex(flags[t]))       # follows the strip solve of tile (q-1, q)
+            assert not flags[t] & FUSED, (q, hex(flags[t]))
+            assert bool(flags[t] & NOSOLVE) == (q >= 1), (q, hex(flags[t]))       # follows the strip solve of tile (q-1, q)
         elif ty[t] == OFF:
             off_tickets.setdefault(q, {})[j] = t
-            if q >= 2:
-                assert flags[t] & WAITNEXT, (q, j)                                    # follows
-                assert bool(flags[t] & NOSOLVE) == (j == q + 1), (q, j)                 # the tile the next diagonal waits for
-                assert flags[t] & FUSED, (q, j)                                        # delivers its tile row block by row block
-            else:
-                assert not (flags[t] & WAITNEXT)
-                assert bool(flags[t] & NOSOLVE) == (j == q + 1 and q + 1 < P)           # update-only, solved by the fused DIAG
+            assert flags[t] & WAITNEXT, (q, j)                                    # follows
+            assert bool(flags[t] & NOSOLVE) == (j == q + 1), (q, j)                 # the tile the next diagonal waits for
+            assert flags[t] & FUSED, (q, j)                                        # delivers its tile row block by row block
     assert sorted(diag_ticket) == list(range(P))
-    for q in range(2, P):
+    for q in range(P):
         for j, t in off_tickets.get(q, {}).items():
             assert diag_ticket[q] < t, (q, j)                  # a follower waits on its leader's progress
         if q + 1 < P:
-            assert off_tickets[q][q + 1] < diag_ticket[q + 1]  # next_done(q) comes from a smaller ticket
+            assert off_tickets[q][q + 1] < diag_ticket[q + 1]  # what DIAG(q+1) follows comes from a smaller ticket
     # every tile exactly once, as in the other schemes
     assert sum(len(v) for v in off_tickets.values()) == P * (P - 1) // 2
