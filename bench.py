@@ -528,6 +528,29 @@ def run_extras(args, h, chunk, gps, lwls, dev, mode):
     require(bool(np.array_equal(mat, mat.T)), "fill_V11_f_g drop-in: matrix not symmetric")
     del mat
 
+    # the drop-in call itself: what an unchanged Worker.lnprob issues per proposal (psoap/sample_parallel.py:193) -- ONE
+    # evaluation through the reference's signature, host arrays in, a float out
+    from psoap_amd import covariance as cov
+    lnlike = {1: cov.lnlike_f, 2: cov.lnlike_f_g, 3: cov.lnlike_f_g_h}[c]
+    call = (None, *[lwls[0][k] for k in range(c)], chunk.fl, chunk.sigma, *gps[0])
+    v0 = lnlike(*call)
+    require(close(v0, float(h.lnlike_batch(lwls[:1], gps[:1])[0])), "drop-in lnlike vs the batched path (one walker)")
+    tds = []
+    for _ in range(15):
+        t0 = time.perf_counter()
+        lnlike(*call)
+        tds.append(time.perf_counter() - t0)
+    t4 = []
+    for _ in range(8):
+        t0 = time.perf_counter()
+        h.lnlike_batch(lwls[:4], gps[:4])
+        t4.append(time.perf_counter() - t0)
+    h.lnlike_batch(lwls, gps)                  # leave the headline batch in the slot
+    ex["dropin_eval"] = {"call": f"covariance.{lnlike.__name__}(V11, *lwls, fl, sigma, *p_GP), N={N}: upload + one evaluation + fetch",
+                         "ms": 1e3 * float(np.median(tds)), "min_ms": 1e3 * float(min(tds)),
+                         "tflops": flops_eval(N) / float(np.median(tds)) / 1e12,
+                         "batch4_ms": 1e3 * float(np.median(t4)), "lnprob": float(v0)}
+
     # the lnprob(p) boundary: orbital parameters in, lnprob out
     model = {1: "SB1", 2: "SB2", 3: "ST3"}[c]
     worker = ChunkWorker(model, chunk.lwl, chunk.fl, chunk.sigma, chunk.epoch_index, chunk.dates, max_batch=B,

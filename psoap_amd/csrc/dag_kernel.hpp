@@ -1521,9 +1521,11 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
                 if (ty == DAG_PART && t.pb == 0 && t.q == t.j && t.q <= 1) return -2;  // the running sum DIAG(0) / DIAG(1) start from
                 return ty == DAG_DIAG ? 0 : (ty == DAG_OFF ? 1 : 2);      // PART and DAG_SCHUR: whatever is left of a stage
             };
-            // (scheme 2: a final that covers two panels -- a following strip solve or the diagonal task that follows
-            // one, from block row 4 on -- starts with the older panel, i.e. a stage early, and it is the row-to-row path:
-            // behind the PARTs of that stage it was picked up a whole round of them late, 110 us at N = 6000, q = 8)
+            // (scheme 2, PSOAP_DAG_EARLY=1: a final that covers two panels -- a following strip solve or the diagonal task that
+            // follows one, from block row 4 on -- starts with the older panel, i.e. could be picked up a stage early.  That
+            // paid while the PARTs were in readiness order (the finals queued behind a whole round of them, 110 us at
+            // N = 6000, q = 8); with the PARTs handed out just in time -- below -- it only makes the finals hold their
+            // workgroups longer: N = 6000: 2.68 -> 2.59 ms for one evaluation, 6.46 -> 6.17 for four WITHOUT it.  Off.)
             // (scheme 2, PARTs: not before block row q - jit is the current one.  In pure readiness order the early stages
             // hold every far row's first PARTs -- ~300 tasks per stage at N = 6000 against ~50 at the end -- and the
             // finals of the next rows queue up behind them: 90 us per block row over the first third of the matrix
@@ -1549,7 +1551,8 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
                     return std::max((int)t.pb, (int)t.q - jit + spread);
                 }
                 const bool follows = (ty == DAG_OFF && (t.type & DAG_WAITNEXT)) || (ty == DAG_DIAG && (t.type & DAG_NOSOLVE));
-                return (follows && t.q >= 4 && t.pb - t.pa >= 2) ? t.pb - 1 : (int)t.pb;   // (q >= 4: what it follows is a stage early too)
+                static const bool early = getenv("PSOAP_DAG_EARLY") && getenv("PSOAP_DAG_EARLY")[0] == '1';   // experiments
+                return (early && follows && t.q >= 4 && t.pb - t.pa >= 2) ? t.pb - 1 : (int)t.pb;   // (q >= 4: what it follows is a stage early too)
             };
             // (the finals of a stage row by row -- only scheme 2 has finals of two rows in one stage, and those of the
             // lower row follow those of the upper one)
@@ -1557,7 +1560,7 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
                              [&](const DagTask& a, const DagTask& b) {
                                  if (stage(a) != stage(b)) return stage(a) < stage(b);
                                  const int ca = cls(a), cb = cls(b);
-                                 if ((ca == 2) != (cb == 2)) return cb == 2;
+                                 if ((ca == 2) != (cb == 2)) return cb == 2;     // (finals behind the PARTs of their stage: 3-6 % slower)
                                  // (tried: within a stage the PARTs that wait for nothing ahead of the ones that need the row
                                  // just finishing -- 3-5 % slower: those are the chains of the nearest rows)
                                  if (a.q != b.q) return a.q < b.q;
