@@ -1526,11 +1526,14 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
             // paid while the PARTs were in readiness order (the finals queued behind a whole round of them, 110 us at
             // N = 6000, q = 8); with the PARTs handed out just in time -- below -- it only makes the finals hold their
             // workgroups longer: N = 6000: 2.68 -> 2.59 ms for one evaluation, 6.46 -> 6.17 for four WITHOUT it.  Off.)
-            // (scheme 2, PARTs: not before block row q - jit is the current one.  In pure readiness order the early stages
+            // (latency schemes, PARTs: not before block row q - jit is the current one.  In pure readiness order the early stages
             // hold every far row's first PARTs -- ~300 tasks per stage at N = 6000 against ~50 at the end -- and the
             // finals of the next rows queue up behind them: 90 us per block row over the first third of the matrix
             // instead of 45.  Just in time, every stage holds about one block row's worth of PARTs.)
-            const int jit = scheme == 2 ? dag_jit_rows() : 0;
+            // (scheme 1 as well -- it is what 17 .. 32 matrices of N <= 4096 and 17 .. 24 of N = 6000 get: 1-5 % there;
+            // PSOAP_DAG_JIT1=0 keeps its PARTs in readiness order)
+            static const bool jit1 = !(getenv("PSOAP_DAG_JIT1") && getenv("PSOAP_DAG_JIT1")[0] == '0');
+            const int jit = (scheme == 2 || (scheme == 1 && jit1)) ? dag_jit_rows() : 0;
             // (the PARTs of the Schur tiles of predict, rows q >= P, keep their place: they are the filler work)
             auto jit_part = [jit, &Ps](const DagTask& t) {
                 return jit > 0 && (t.type & DAG_TYPE_MASK) == DAG_PART && (t.type & DAG_CHAIN) && (int)t.q < Ps[t.b];
