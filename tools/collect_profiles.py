@@ -60,3 +60,16 @@ for a, b in ((f"latency_{tag}.jsonl", f"{tag}_latency_table.jsonl"), (f"bench_{t
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, b))
 print("traffic per launch: %.1f GB (read %.1f, written %.1f)" % ((2 * fetch_kb + write_kb) * 1024 / 1e9, 2 * fetch_kb * 1024 / 1e9, write_kb * 1024 / 1e9))
+# which library was measured: its SHA-256 as taken on the GPU box at the start of the evidence call, next to the record of
+# the build in the tree (sources / compiler / flags: psoap_amd/build.py)
+sha_path = os.path.join(ROOT, "gpurun_out", f"lib_sha256_{tag}.txt")
+if os.path.exists(sha_path):
+    sha = open(sha_path).read().split()[0]
+    rec_path = os.path.join(ROOT, "psoap_amd", "csrc", "libpsoap_gp.so.srchash")
+    rec = json.load(open(rec_path)) if os.path.exists(rec_path) else {}
+    with open(os.path.join(dst, f"{tag}_summary.md"), "a") as f:
+        f.write(f"\nThe library measured: `psoap_amd/csrc/libpsoap_gp.so`, sha256 `{sha}`, as `python -m psoap_amd.build` produces it from the\n"
+                f"committed kernel sources (source hash `{rec.get('sources', '?')}`, `{rec.get('compiler', '?')}`, ladder rung\n"
+                f"{rec.get('fallback_rung', '?')}); GPU tests, soak, bench line, these traces and the latency / scheme tables of `profiles/{tag}_*` come from one\n"
+                f"call on one box (`tools/evidence_round.sh {tag}`).\n")
+
