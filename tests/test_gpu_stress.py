@@ -107,3 +107,24 @@ def test_large_matrix_against_oracle(oracle):
     want = oracle.lnlike(lw[0], ch.fl, ch.sigma, gps[0])
     assert close(both[0], want) and close(one[0], want), (both, one, want)
     assert np.isfinite(both[1])
+
+
+def test_smallest_matrices_one_to_four_block_rows(oracle):
+    """N from 100 to 385 -- one, two, three and four 128-row blocks, with and without padding: the first block rows of the
+    following scheme (a diagonal task that starts from a covariance-only PART and has no tile above it, a second one that
+    follows the first row's strip solve) are all there is."""
+    from psoap_amd.chunk import ChunkHandle
+    for c, ne, npx in ((1, 1, 100), (1, 1, 128), (2, 1, 129), (2, 2, 100), (3, 3, 85), (2, 3, 128), (1, 5, 77)):
+        ch = syn.make_chunk(c, ne, npx, seed=900 + npx)
+        for B in (1, 3, 5):
+            gps = syn.make_walkers(c, B, seed=11)
+            lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, B, seed=12))
+            with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
+                h.set_mode("staged")
+                staged = h.lnlike_batch(lw, gps)
+                h.set_mode("dag")
+                got = h.lnlike_batch(lw, gps)
+                assert np.array_equal(h.lnlike_batch(lw, gps), got)
+            for w in range(B):
+                assert close(got[w], staged[w]), (ch.N, B, w)
+            assert close(got[0], oracle.lnlike(lw[0], ch.fl, ch.sigma, gps[0])), (ch.N, B)
