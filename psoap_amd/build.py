@@ -133,13 +133,26 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 -> psoap_amd/csrc/libpsoap_gp.so, after the assembly checks"""
     if not force and not _stale():
         return LIB_PATH
-    with tempfile.TemporaryDirectory(prefix="psoap_build_") as tmp:
-        so, asm_path, rec = compile_checked(extra_flags(), tmp, verbose)
-        shutil.copy(so, LIB_PATH)
-        shutil.copy(asm_path, ASM_PATH)
-        with open(HASH_PATH, "w") as fh:
-            json.dump(rec, fh, indent=1)
-            fh.write("\n")
+    # (a FIXED scratch directory: hipcc derives unit ids from the paths it is given, and a random temporary directory made
+    # every build of the same sources a different binary -- 759 bytes of the fat binary -- so that the library a profile
+    # names by its SHA-256 could not be rebuilt)
+    tmp = os.path.join(tempfile.gettempdir(), "psoap_gfx950_build")
+    import fcntl
+    with open(tmp + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)           # one build at a time in that directory (ranks, test workers)
+        if not force and not _stale():
+            return LIB_PATH                        # somebody else built it while we waited
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        try:
+            so, asm_path, rec = compile_checked(extra_flags(), tmp, verbose)
+            shutil.copy(so, LIB_PATH)
+            shutil.copy(asm_path, ASM_PATH)
+            with open(HASH_PATH, "w") as fh:
+                json.dump(rec, fh, indent=1)
+                fh.write("\n")
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
     return LIB_PATH
 
 
