@@ -115,6 +115,11 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
         wait_next = bool(flags[t] & WAITNEXT) and not follows
         if follows:
             assert following and diag_final_ticket[(b, q)] < t      # behind the task whose progress it polls
+            if q >= 1:
+                # the last panel of its update follows the two tiles of the row above it reads -- both delivered row block
+                # by row block (FUSED) by following strip solves with smaller tickets
+                for src in (finals[(b, q - 1, q)], finals[(b, q - 1, j)]):
+                    assert src < t and flags[src] & WAITNEXT and flags[src] & FUSED
         two_panel_diag = k["type"] == DIAG and bool(flags[t] & NOSOLVE) and q >= 3   # (a following diagonal task: two panels)
         if wait_next:
             assert want_chain and k["type"] == DIAG and int(k["pb"]) == q
