@@ -1464,7 +1464,8 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
 // more than one matrix; throughput beyond (N = 6000, B = 32: 39.2 vs 39.9 ms; N = 8192, B = 32: 95.0 vs 96.1).
 // (Readiness ordering was also tried for the throughput scheme: 800 -> 776 evals/s, not adopted.)
 constexpr int DAG_LATENCY_QUEUE_ROWS = 150;
-constexpr int DAG_FOLLOW_MAX_MATS = 16;
+constexpr int DAG_FOLLOW_MAX_MATS = 8;
+constexpr int DAG_FOLLOW_SMALL_ROWS = 20;
 inline int dag_auto_scheme(const std::vector<int>& Ps)
 {
     long long rows[DAG_QUEUES] = {};
@@ -1482,9 +1483,12 @@ inline int dag_auto_scheme(const std::vector<int>& Ps)
     const int latency = (max_rows <= DAG_LATENCY_QUEUE_ROWS || max_count <= 1) ? 1 : 0;
 #ifdef PSOAP_FOLLOW
     // following strip solves (scheme 2) where they were measured to win (profiles/r3_follow_table.txt: N = 2000 .. 8192, B =
-    // 1 .. 32): up to sixteen matrices -- single evaluations 15-30 % faster than scheme 1, eight matrices 4-11 %, sixteen
-    // 1-2 %; 0-2 % slower from 24 on
-    if (latency == 1 && Ps.size() <= (size_t)DAG_FOLLOW_MAX_MATS) return 2;
+    // 1 .. 32, against scheme 1 with its PARTs just in time): up to eight matrices everywhere -- single evaluations 12-37 %
+    // faster, eight matrices 1-21 % -- and up to 24 small ones (at most 20 block rows: N = 2000, 12 / 16 / 24 matrices 12 /
+    // 10 / 3 % faster; from N = 4096 on scheme 1 is 1-2 % ahead at 12 and 16)
+    int Pmax = 0;
+    for (int P : Ps) Pmax = P > Pmax ? P : Pmax;
+    if (latency == 1 && (Ps.size() <= (size_t)DAG_FOLLOW_MAX_MATS || (Ps.size() <= 24 && Pmax <= DAG_FOLLOW_SMALL_ROWS))) return 2;
 #endif
     return latency;
 }
