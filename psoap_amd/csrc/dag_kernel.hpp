@@ -62,8 +62,11 @@ struct alignas(64) MatFlags {
     int xcol[256][2]; // per column tile j, per publishing wave of the following strip solve of tile (q, j): 8 q + b + 1
                       // once its half of row block b of the solved tile is in memory -- the tasks of block row q+1 that
                       // read the tile (the diagonal task of block q+1, the strip solves of tiles (q+1, .)) follow it in turn
+    int rvrow[256];   // per column tile j: q + 1 once the strip solve of tile (q, j) has applied its contribution to the
+                      // right-hand side block j and finished (the next row's strip solve of that column waits for it before
+                      // its own: a plain read-modify-write)
 };
-static_assert(sizeof(MatFlags) == 64 + 2048, "one cache line of row state + the per-column progress words");
+static_assert(sizeof(MatFlags) == 64 + 2048 + 1024, "one cache line of row state + the per-column progress words");
 
 // Mailbox of a matrix, right behind its two Wt tiles: the fused diagonal task publishes, step by step, what a strip
 // solve needs of block row b of the diagonal block it is factoring -- the blocks U_bJ (J > b) of U11's row b and
@@ -648,7 +651,7 @@ template <int C, bool AUG>
 __device__ __forceinline__ void dag_pss(Tile& t, double* Km, int ld, int k0, int j0,
                                                   const double* __restrict__ mbq, MatFlags* f, int q, DagCtl* ctl,
                                                   double* Rv, int Npad, lds_double* smem, lds_double* zk, lds_double* colsum,
-                                                  int xpub, int skip_rv)
+                                                  int xpub, int skip_rv, int rv_wait)
 {
     // t: the updated tile (the caller evaluated the covariance into the accumulators: dag_special)
     const SmemArg sm{smem};
@@ -728,6 +731,10 @@ __device__ __forceinline__ void dag_pss(Tile& t, double* Km, int ld, int k0, int
                     Km[(size_t)(k0 + row_of(m, r)) * ld + j0 + tile_col(wc, n, lane)] = t.acc[m][n][r];
     }
     dag_wait_ge(&f->potrf_done, q + 1, ctl, 7u);
+    // (rv_wait -- the row above is a following one: its strip solve of this column has applied ITS contribution to the
+    // right-hand side block and finished; until round 3's last day only the timing said so -- it runs a whole
+    // factorisation ahead)
+    if (rv_wait) dag_wait_ge(&f->rvrow[j0 / NB], q, ctl, 8u);
     if (tid_ < NB) zk[tid_] = Rv[k0 + tid_];
     __syncthreads();
     double part[4] = {0.0, 0.0, 0.0, 0.0};
@@ -876,12 +883,14 @@ __device__ __attribute__((noinline)) void dag_special(const DagSpecialArgs* a)
     double* const Rv = sp(a->Rv);
     const double* const mbq = sp(a->mbq);
     const int Npad = si(a->Npad), ntasks_row = si(a->ntasks_row), pubnext = si(a->pubnext);
-    dag_pss<C, AUG>(t, Km, ld, k0, j0, mbq, f, q, ctl, Rv, Npad, smem, a->zk, a->colsum, xlink, xlink && pubnext);
+    dag_pss<C, AUG>(t, Km, ld, k0, j0, mbq, f, q, ctl, Rv, Npad, smem, a->zk, a->colsum, xlink, xlink && pubnext,
+                    q > si(a->xfirst));
     if (tl && threadIdx.x == 0) tl[6] = __builtin_amdgcn_s_memrealtime();
     dag_drain();
     if (threadIdx.x == 0) {
         dag_release_fence();
         if (pubnext) __hip_atomic_store(&f->next_done, q + 1, PSOAP_RLX_AGENT);   // tile (q, q+1) is final
+        __hip_atomic_store(&f->rvrow[j0 / NB], q + 1, PSOAP_RLX_AGENT);           // ... and the right-hand side block j has its share
         dag_task_done(f, q, ntasks_row);
     }
 }
