@@ -80,7 +80,6 @@ SIGNATURES = {
     "psoap_calibrate_explicit": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                                 ctypes.c_double, _dp, _dp, _dp, _dp, _dp, _dp, ctypes.c_double, _dp, _dp,
                                                 _ip]),
-    "psoap_microbench_exp_check": (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong, _dp, ctypes.POINTER(ctypes.c_longlong)]),
     "psoap_group_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.c_int]),
     "psoap_group_eval": (ctypes.c_int, [_vp]),
     "psoap_group_destroy": (ctypes.c_int, [_vp]),
@@ -102,6 +101,12 @@ SIGNATURES = {
                                           ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong),
                                           ctypes.POINTER(ctypes.c_uint32)]),
     "psoap_dag_pick_workers": (ctypes.c_int, [ctypes.c_int, _ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip]),
+}
+
+# include/psoap_bench.h (libpsoap_bench.so): measurement kernels, loaded by bench.py / tools / one GPU test only
+BENCH_SIGNATURES = {
+    "psoap_bench_last_error": (ctypes.c_char_p, []),
+    "psoap_microbench_exp_check": (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong, _dp, ctypes.POINTER(ctypes.c_longlong)]),
     "psoap_microbench_mfma_f64": (ctypes.c_int, [ctypes.c_int, _dp]),
     "psoap_microbench_tile_engine": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp]),
     "psoap_microbench_potrf": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp]),
@@ -110,6 +115,7 @@ SIGNATURES = {
 }
 
 _lib = None
+_bench = None
 
 
 def load():
@@ -129,6 +135,30 @@ def load():
         fn.argtypes = args
     _lib = L
     return L
+
+
+def load_bench():
+    """Load libpsoap_bench.so (psoap_amd.build.build_bench): the micro-benchmarks behind the measured peaks."""
+    global _bench
+    if _bench is not None:
+        return _bench
+    from .build import BENCH_LIB_PATH
+    path = os.environ.get("PSOAP_BENCH_LIB", BENCH_LIB_PATH)
+    if not os.path.exists(path):
+        raise PsoapError(f"{path} not found: build it with `python -m psoap_amd.build` (hipcc, gfx950)")
+    L = ctypes.CDLL(path)
+    for name, (res, args) in BENCH_SIGNATURES.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _bench = L
+    return L
+
+
+def check_bench(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load_bench().psoap_bench_last_error()
+        raise PsoapError(f"{what}: {msg.decode() if msg else 'error'} (rc={rc})")
 
 
 def check(rc: int, what: str = ""):

@@ -20,7 +20,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libpsoap_gp.so")
 SOURCES = ["psoap_gp.hip"]
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp")) + [os.path.join("..", "..", "include", "psoap_gp.h")]
+# (microbench_kernels.hpp belongs to the measurement library below, not to the product)
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp") and f != "microbench_kernels.hpp") + \
+    [os.path.join("..", "..", "include", "psoap_gp.h")]
+# The measurement library (include/psoap_bench.h): micro-benchmarks and the exp() self-check that bench.py, tools/ and
+# one GPU test load.  Product kernels only in libpsoap_gp.so.
+BENCH_LIB_PATH = os.path.join(CSRC, "libpsoap_bench.so")
+BENCH_SOURCES = ["psoap_bench.hip"]
+BENCH_HEADERS = ["common.hpp", "gemm_core.hpp", "potrf_blocked.hpp", "fill_kernels.hpp", "microbench_kernels.hpp",
+                 os.path.join("..", "..", "include", "psoap_bench.h")]
+BENCH_HASH_PATH = BENCH_LIB_PATH + ".srchash"
 HASH_PATH = LIB_PATH + ".srchash"                      # JSON: what the library beside it was built from
 ASM_PATH = os.path.join(CSRC, "libpsoap_gp.device.s")   # device assembly of that build (kept for the CPU tests)
 
@@ -39,10 +48,10 @@ def hipcc() -> str:
     return os.environ.get("HIPCC", "hipcc")
 
 
-def source_hash() -> str:
+def source_hash(files=None) -> str:
     """SHA-256 over the kernel sources the library is built from (names and contents)."""
     h = hashlib.sha256()
-    for f in SOURCES + HEADERS:
+    for f in (SOURCES + HEADERS if files is None else files):
         p = os.path.join(CSRC, f)
         h.update(os.path.basename(p).encode())
         with open(p, "rb") as fh:
@@ -78,14 +87,30 @@ def build_record() -> dict | None:
 
 
 def _stale() -> bool:
-    """The library is missing or was not built from the sources as they are now, by this compiler, with these extra
-    flags (content hash kept beside it: modification times say nothing after a `git checkout` of a kernel header over
-    an experimental build)."""
+    """The library is missing or was not built from the sources as they are now with these extra flags (content hash
+    kept beside it: modification times say nothing after a `git checkout` of a kernel header over an experimental
+    build).  The compiler: a library whose sources match is REBUILT for another compiler only where that is asked for
+    (PSOAP_REBUILD_ON_COMPILER_CHANGE=1, or `--force`) -- a machine without hipcc, or with a hipcc whose version line
+    differs, loads the shipped library as it is (its SHA-256 is what the profiles cite) and says so once."""
     rec = build_record()
     if not os.path.exists(LIB_PATH) or rec is None:
         return True
-    return (rec.get("sources") != source_hash() or rec.get("compiler") != compiler_id() or
-            rec.get("extra_flags") != extra_flags())
+    if rec.get("sources") != source_hash() or rec.get("extra_flags") != extra_flags():
+        return True
+    cid = compiler_id()
+    if rec.get("compiler") != cid:
+        if cid != "unknown" and os.environ.get("PSOAP_REBUILD_ON_COMPILER_CHANGE") == "1":
+            return True
+        global _warned_compiler
+        if not _warned_compiler:
+            _warned_compiler = True
+            import warnings
+            warnings.warn(f"libpsoap_gp.so was built by {rec.get('compiler')!r}; this machine has {cid!r}: using the "
+                          "library as shipped (PSOAP_REBUILD_ON_COMPILER_CHANGE=1 rebuilds and re-checks it)")
+    return False
+
+
+_warned_compiler = False
 
 
 def compile_once(flags: list[str], out_dir: str) -> tuple[str, str]:
@@ -156,6 +181,52 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def library_sha256(path: str = LIB_PATH) -> str | None:
+    if not os.path.exists(path):
+        return None
+    h = hashlib.sha256()
+    with open(path, "rb") as fh:
+        for blk in iter(lambda: fh.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def provenance() -> dict:
+    """What bench.py prints beside its numbers: which binary ran."""
+    rec = build_record() or {}
+    return {"sha256": library_sha256(), "source_hash": rec.get("sources"), "compiler": rec.get("compiler"),
+            "fallback_rung": rec.get("fallback_rung"), "extra_flags": rec.get("extra_flags"),
+            "sources_match_tree": rec.get("sources") == source_hash()}
+
+
+def build_bench(force: bool = False) -> str:
+    """hipcc -> psoap_amd/csrc/libpsoap_bench.so (measurement kernels; no assembly gate: nothing in it is shipped)"""
+    want = source_hash(BENCH_SOURCES + BENCH_HEADERS)
+    if not force and os.path.exists(BENCH_LIB_PATH) and os.path.exists(BENCH_HASH_PATH):
+        try:
+            with open(BENCH_HASH_PATH) as fh:
+                if json.load(fh).get("sources") == want:
+                    return BENCH_LIB_PATH
+        except ValueError:
+            pass
+    tmp = os.path.join(tempfile.gettempdir(), "psoap_gfx950_build_bench")
+    import fcntl
+    with open(tmp + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        try:
+            so = os.path.join(tmp, "libpsoap_bench.so")
+            subprocess.check_call([hipcc(), *BASE_FLAGS, *[os.path.join(CSRC, f) for f in BENCH_SOURCES], "-o", so], cwd=tmp)
+            shutil.copy(so, BENCH_LIB_PATH)
+            with open(BENCH_HASH_PATH, "w") as fh:
+                json.dump({"sources": want, "compiler": compiler_id(), "flags": BASE_FLAGS}, fh, indent=1)
+                fh.write("\n")
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return BENCH_LIB_PATH
+
+
 def device_asm() -> str:
     """Device assembly of the installed library (rebuilding first if it is stale)."""
     build()
@@ -169,3 +240,4 @@ if __name__ == "__main__":
     import sys
     print(build(force="--force" in sys.argv, verbose=True))
     print(json.dumps(build_record(), indent=1))
+    print(build_bench(force="--force" in sys.argv))

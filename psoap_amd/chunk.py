@@ -217,7 +217,9 @@ class ChunkGroup:
 
 
 def microbench(device: int | None = None) -> dict:
-    L = _lib.load()
+    """Measured ceilings of the device (libpsoap_bench.so, include/psoap_bench.h): never part of the product path."""
+    L = _lib.load_bench()
+    check = _lib.check_bench
     dev = _lib.default_device() if device is None else device
     tf = ctypes.c_double()
     w = ctypes.c_double()

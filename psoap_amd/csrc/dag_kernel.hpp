@@ -499,9 +499,11 @@ __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, in
 // Being a non-kernel function it names NO __shared__ variable: the kernel hands it the base of the dynamic LDS
 // array (`smem`) and its two LDS vectors as address_space(3) pointers, and the spine's progress flag lives in
 // that array (pb::OFF_FLAG) -- see gemm_core.hpp (SmemArg) and DESIGN.md 3.4 for why.
-//   -DPSOAP_DIAG_INLINE     compiles the routine into the LAT kernels instead (2-5 % slower in the latency regime);
-//   -DPSOAP_DIAG_LDS_TABLE  the round-2 form: the routine names psoap_smem itself, i.e. reaches LDS through the
-//                           compiler's per-kernel table (tools/lat_variants.py builds both for comparison).
+//   -DPSOAP_DIAG_INLINE     compiles the routine into the LAT kernels instead (2-5 % slower in the latency regime; the
+//                           build's fallback rung, psoap_amd/build.py).
+// (The code-shape variants of the round-3 compiler-defect study -- poll in front of the call, table-lookup callee, round-2
+// staging forms, s_nop padding, ... -- are no longer in this file: tools/lat_variants.py applies them as a patch,
+// tools/lat_variants.patch, to a scratch copy of the sources.)
 // The LDS address of a __shared__ object as a value the optimiser cannot see through: with the address visible at
 // the (only) call sites, interprocedural constant propagation puts the object's name right back into the callee.
 __device__ __forceinline__ lds_double* dag_opaque_lds(double* shared_obj)
@@ -515,7 +517,7 @@ __device__ __forceinline__ lds_double* dag_opaque_lds(double* shared_obj)
 #else
 #define PSOAP_DIAG_FN __device__ __attribute__((noinline))
 #endif
-#if (defined(PSOAP_DIAG_INLINE) || defined(PSOAP_DIAG_LDS_TABLE)) && !defined(PSOAP_FOLLOW)
+#if defined(PSOAP_DIAG_INLINE) && !defined(PSOAP_FOLLOW)
 #define PSOAP_DIAG_SMEM(smem) SmemKernel()
 #else
 #define PSOAP_DIAG_SMEM(smem) SmemArg{smem}
@@ -526,17 +528,11 @@ PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double*
                                                         lds_double* smem, lds_double* zk, lds_double* colsum,
                                                         unsigned long long* tl, bool xfollow = false, bool two_panels = false)
 {
-#ifdef PSOAP_PAD_CALLEE
-    // variant matrix (tools/lat_variants.py): code placement only
-    asm volatile(".rept %0\n\ts_nop 0\n\t.endr" ::"n"(PSOAP_PAD_CALLEE));
-#endif
     const auto sm = PSOAP_DIAG_SMEM(smem);
     // the wait for the tile's PART chain (it ran ahead: normally no wait at all) happens in here, not in front of the
     // call: a one-lane poll right before a call is where hipcc's register allocator parked the values that live
     // across the call UNDER THE POLL'S EXEC MASK (tools/check_exec_restore.py)
-#ifndef PSOAP_WAIT_BEFORE_CALL
     dag_wait_ge(chain_ctr, chain_len, ctl, 4u);
-#endif
     __builtin_amdgcn_s_setprio(3);
     // (xfollow: no wait for the finished tile above -- its row blocks are awaited one by one inside the update)
     // (two_panels: the final also applies tile (q-2, q), final with the whole of block row q-2)
@@ -545,9 +541,6 @@ PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double*
         else if (two_panels) dag_wait_ge(&f->rows_done, q - 1, ctl, 1u);
         if (tl && threadIdx.x == 0) tl[4] = __builtin_amdgcn_s_memrealtime();
     };
-#ifdef PSOAP_NO_SPINE
-    potrf_blocked<0, true>(Km, ld, k0, Wm, Rv, acc, prev, Km + (size_t)(k0 - NB) * ld + k0, wait_dep, tl);
-#else
     // (the mailbox sits behind the matrix's two Wt tiles: Wm is tile q & 1 of them)
     double* wt0 = Wm - (size_t)(q & 1) * NB * NB;
 #ifndef PSOAP_FOLLOW
@@ -560,7 +553,6 @@ PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double*
                       xfollow ? ps::SpineFollow{wt0 + 2 * NB * NB + mb_slot(q - 1, 0, 0), f->xcol[q], 8 * (q - 1), &ctl->error,
                                                 two_panels ? Km + (size_t)(k0 - 2 * NB) * ld + k0 : nullptr}
                               : ps::SpineFollow{nullptr, nullptr, 0, nullptr, nullptr});
-#endif
 #endif
     dag_drain();
     if (tl && threadIdx.x == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
@@ -935,9 +927,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
     // 38.9 -> 38.7 ms per 32-walker step; the balanced solve alone brings a thread-id reload into the K-loop stages.
     // Both kinds of kernel use these forms (round 2 kept the LAT kernels on the plain ones only because any change to
     // them could bring the fault of DESIGN.md 3.4 back; measured in round 3: within 1 % either way, profiles/r3_ab_forms.txt)
-#ifdef PSOAP_PAD_KERNEL
-    asm volatile(".rept %0\n\ts_nop 0\n\t.endr" ::"n"(PSOAP_PAD_KERNEL));
-#endif
     const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     unsigned int dry = 0;                       // bit g: queue g is exhausted (wave-uniform)
     int probe = 0;
@@ -1021,9 +1010,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         }
 #else
         if (LAT && preload && ttype == DAG_DIAG && (task.type & DAG_WAITNEXT) && task.pb - task.pa == 1) {
-#ifdef PSOAP_WAIT_BEFORE_CALL
-            dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);   // round-2 placement, kept for tools/lat_variants.py only
-#endif
             dag_diag_fast(Km, ld, k0, Wm, Rv, mat.acc, prev, Npad, f, ctl, q, ntasks_row, (task.type & DAG_FUSED) != 0,
                           &arrive[task.ctr], n_wait, dag_opaque_lds(psoap_smem), dag_opaque_lds(vec1), dag_opaque_lds(vec2),
                           tlog ? tlog + ticket * 8 : nullptr);
@@ -1037,14 +1023,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
             dag_sub_partials(t, prev, 1);
             n_prev = 0;
         }
-#ifdef PSOAP_LAT_PLAIN
-        // round-2 forms of the LAT kernels (thread-id staging, plain strip solve): tools/lat_variants.py only -- with
-        // -DPSOAP_WAIT_BEFORE_CALL this is the code shape on which hipcc produces the defect of DESIGN.md 3.4
-        if constexpr (LAT)
-            dag_update(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl, ttype == DAG_DIAG && (task.type & DAG_WAITNEXT) != 0,
-                       tlog ? tlog + ticket * 8 : nullptr);
-        else
-#endif
         // (DAG_WAITNEXT on a DIAG task: its last panel needs only the tile right of the diagonal above; on an OFF task
         // the bit means "follow the factorisation" and the last panel needs the whole block row above, as always)
         dag_update<true>(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl, ttype == DAG_DIAG && (task.type & DAG_WAITNEXT) != 0,
@@ -1124,10 +1102,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         } else {
             dag_wait_ge(&f->potrf_done, q + 1, ctl, 3u + 16u * (unsigned int)q + 4096u * (unsigned int)b);
             if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 2] = __builtin_amdgcn_s_memrealtime();
-#ifdef PSOAP_LAT_PLAIN
-            if constexpr (LAT) dag_trsm(t, Km, ld, k0, j0, Wm, Rv, Npad, vec1, vec2);
-            else
-#endif
             dag_trsm<true>(t, Km, ld, k0, j0, Wm, Rv, Npad, vec1, vec2);
             dag_drain();
             if (threadIdx.x == 0) {

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "fill_kernels.hpp"
 #include "gemm_core.hpp"
 #include "potrf_blocked.hpp"
 

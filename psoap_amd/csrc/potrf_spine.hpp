@@ -23,13 +23,6 @@
 #include "potrf_blocked.hpp"
 
 // variant matrix (tools/lat_variants.py): the routine's global accesses as global_* instead of flat_* instructions
-#ifdef PSOAP_SPINE_GLOBAL
-#define PSOAP_SG(p) ((__attribute__((address_space(1))) double*)(p))
-#define PSOAP_SGC(p) ((const __attribute__((address_space(1))) double*)(p))
-#else
-#define PSOAP_SG(p) (p)
-#define PSOAP_SGC(p) (p)
-#endif
 
 namespace psoap {
 namespace ps {
@@ -175,7 +168,7 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
                 d4 v = {0.0, 0.0, 0.0, 0.0};
                 if (J > I && J < 8) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = PSOAP_SGC(part)[(size_t)(16 * I + q + 4 * r) * NB + 16 * J + c];
+                    for (int r = 0; r < 4; ++r) v[r] = part[(size_t)(16 * I + q + 4 * r) * NB + 16 * J + c];
                 }
                 blk[3 * I + s] = v;
             }
@@ -187,7 +180,7 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
         for (int s = 0; s < 3; ++s)
             if (owned(W, I, s) && col0(W, I) + 3 * s == 8) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) blk[3 * I + s][r] = (c == 0) ? PSOAP_SG(Rv)[k0 + 16 * I + q + 4 * r] : 0.0;
+                for (int r = 0; r < 4; ++r) blk[3 * I + s][r] = (c == 0) ? Rv[k0 + 16 * I + q + 4 * r] : 0.0;
             }
     // ---- T -= strip^T strip on the upper blocks this wave owns (K = 128 in eight LDS stages)
     if (xf.xstep) {
@@ -347,26 +340,6 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
                     }
             }
         }
-#ifdef PSOAP_SPINE_INLOOP_OUT
-        // ---- outputs of block row bb, final since phase B (measured slower than writing everything after the
-        // loop, even with a barrier that does not wait for the stores: kept for reference only)
-#pragma unroll
-        for (int I = 0; I < 8; ++I) {
-            if (I != bb) continue;
-#pragma unroll
-            for (int s = 0; s < 3; ++s)
-                if (owned(W, I, s)) {
-                    const int J = col0(W, I) + 3 * s;
-                    if (J < I) {
-                        pb::emit_w(blk[3 * I + s], I, J, lane, W, Wm, sm);
-                    } else if (J < 8) {
-                        const d4& v = blk[3 * I + s];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) PSOAP_SG(Km)[(size_t)(k0 + 16 * I + q + 4 * r) * ld + k0 + 16 * J + c] = v[r];
-                    }
-                }
-        }
-#endif
         // this wave's blocks of rows < bb are in the mailbox by now; younger than those: row bb's blocks (phase B above) and,
         // in wave 1, the four stores of W_(bb-1) at the end of the previous step
         if (pub.mb && bb > 0) pub_flag(pub, W, bb, lane, 4 * pub_count(W, bb) + (W == 1 ? 4 : 0));
@@ -375,7 +348,6 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
     }
     if (pub.mb) pub_flag(pub, W, 8, lane);
     double zz = 0.0;
-#ifndef PSOAP_SPINE_INLOOP_OUT
     // ---- outputs of this wave: its blocks of W (strictly lower), of U11 (strictly upper) and of z
 #pragma unroll
     for (int I = 0; I < 8; ++I)
@@ -388,19 +360,18 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
                 } else if (J < 8) {
                     const d4& v = blk[3 * I + s];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) PSOAP_SG(Km)[(size_t)(k0 + 16 * I + q + 4 * r) * ld + k0 + 16 * J + c] = v[r];
+                    for (int r = 0; r < 4; ++r) Km[(size_t)(k0 + 16 * I + q + 4 * r) * ld + k0 + 16 * J + c] = v[r];
                 } else {
                     // z (column 0 of the rhs block) back into r, and its share of z^T z
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (c == 0) {
                             const double z = blk[3 * I + s][r];
-                            PSOAP_SG(Rv)[k0 + 16 * I + q + 4 * r] = z;
+                            Rv[k0 + 16 * I + q + 4 * r] = z;
                             zz = fma(z, z, zz);
                         }
                 }
             }
-#endif
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) zz += __shfl_xor(zz, off, 64);
     if (lane == 0) sm[pb::OFF_RED + W] = zz;
@@ -443,7 +414,7 @@ __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* 
 #pragma unroll
     for (int I = 0; I < 8; ++I)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) d[I][r] = PSOAP_SGC(part)[(size_t)(16 * I + q + 4 * r) * NB + 16 * I + c];
+        for (int r = 0; r < 4; ++r) d[I][r] = part[(size_t)(16 * I + q + 4 * r) * NB + 16 * I + c];
     wait_dep();
     if (xf.xstep) {
         // the same stages as the workers', requested as the strip solve above delivers them (worker<W>)
@@ -547,7 +518,7 @@ __device__ __forceinline__ void spine(double* Km, int ld, int k0, const double* 
 #pragma unroll
     for (int I = 0; I < 8; ++I)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) PSOAP_SG(Km)[(size_t)(k0 + 16 * I + q + 4 * r) * ld + k0 + 16 * I + c] = d[I][r];
+        for (int r = 0; r < 4; ++r) Km[(size_t)(k0 + 16 * I + q + 4 * r) * ld + k0 + 16 * I + c] = d[I][r];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) logsum += __shfl_xor(logsum, off, 64);
     if (lane == 0) {

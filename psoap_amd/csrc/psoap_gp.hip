@@ -15,7 +15,6 @@
 #include "chol_kernels.hpp"
 #include "dag_kernel.hpp"
 #include "fill_kernels.hpp"
-#include "microbench_kernels.hpp"
 #include "orbit_kernels.hpp"
 #include "predict_kernels.hpp"
 #include "calibrate_kernels.hpp"
@@ -1413,43 +1412,4 @@ extern "C" int psoap_calibrate_explicit(int device, int M, int N, int order, dou
     int rc = calibrate_run(in, fl_cor, X, &status, g_err);
     if (status_out) *status_out = status;
     return rc;
-}
-
-// ---- micro-benchmarks -----------------------------------------------------------------------
-extern "C" int psoap_microbench_mfma_f64(int device, double* tflops)
-{
-    HIP_TRY(hipSetDevice(device));
-    return microbench_mfma(tflops, g_err);
-}
-
-extern "C" int psoap_microbench_tile_engine(int device, int shared_operands, double* tflops)
-{
-    HIP_TRY(hipSetDevice(device));
-    return microbench_tile_engine(shared_operands, tflops, g_err);
-}
-
-extern "C" int psoap_microbench_potrf(int device, int ablate, double* usec)
-{
-    HIP_TRY(hipSetDevice(device));
-    return microbench_potrf(ablate, usec, g_err);
-}
-
-extern "C" int psoap_microbench_exp_check(int device, long long n, const double* x, long long* mismatches)
-{
-    if (n < 4 || !x || !mismatches) FAIL("psoap_microbench_exp_check: bad arguments");
-    HIP_TRY(hipSetDevice(device));
-    return microbench_exp_check(n, x, mismatches, g_err);
-}
-
-extern "C" int psoap_microbench_mix(int device, int mode, int iters_mfma, int iters_valu, double* out3)
-{
-    if (!out3 || iters_mfma < 0 || iters_valu < 0) FAIL("psoap_microbench_mix: bad arguments");
-    HIP_TRY(hipSetDevice(device));
-    return microbench_mix(mode, iters_mfma, iters_valu, out3, g_err);
-}
-
-extern "C" int psoap_microbench_hbm(int device, double* write_gbs, double* copy_gbs)
-{
-    HIP_TRY(hipSetDevice(device));
-    return microbench_hbm(write_gbs, copy_gbs, g_err);
 }

@@ -10,8 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    text = open(os.path.join(ROOT, "include", "psoap_gp.h")).read()
+def _header_symbols(name="psoap_gp.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(psoap_[a-z0-9_]+)\s*\(", text)))
 
@@ -27,6 +27,19 @@ def test_library_exports_every_declared_symbol():
     # the ctypes table binds exactly the declared set
     assert sorted(_lib.SIGNATURES) == syms
     assert _lib.load().psoap_version() == 1
+
+
+def test_bench_library_exports_every_declared_symbol_and_the_product_has_no_measurement_kernels():
+    """include/psoap_bench.h <-> libpsoap_bench.so; the product library holds product entry points only."""
+    from psoap_amd import build, _lib
+    L = ctypes.CDLL(build.build_bench())
+    syms = _header_symbols("psoap_bench.h")
+    assert len(syms) >= 7 and sorted(_lib.BENCH_SIGNATURES) == syms
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/psoap_bench.h but not exported"
+    P = ctypes.CDLL(build.build())
+    assert not any(hasattr(P, s) for s in syms)
+    assert not any("microbench" in s for s in _header_symbols())
 
 
 def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):

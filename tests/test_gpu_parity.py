@@ -311,7 +311,7 @@ def test_batched_exp_is_bit_identical_to_library_exp():
     ])
     x = np.ascontiguousarray(x[: len(x) - len(x) % 4])
     bad = ctypes.c_longlong(-1)
-    _lib.check(_lib.load().psoap_microbench_exp_check(_lib.default_device(), len(x), _lib.dptr(x), ctypes.byref(bad)),
+    _lib.check_bench(_lib.load_bench().psoap_microbench_exp_check(_lib.default_device(), len(x), _lib.dptr(x), ctypes.byref(bad)),
                "psoap_microbench_exp_check")
     assert bad.value == 0
 

@@ -4,12 +4,12 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from psoap_amd import _lib
-L = _lib.load()
+L = _lib.load_bench()
 IM, IE = 4000, 2500
 def run(mode):
     out = np.zeros(3)
     rc = L.psoap_microbench_mix(0, mode, IM, IE, out.ctypes.data_as(_lib._dp))
-    _lib.check(rc, "psoap_microbench_mix")
+    _lib.check_bench(rc, "psoap_microbench_mix")
     return out
 for name, mode in (("MFMA alone", 1), ("exp alone", 2), ("MFMA + exp", 3), ("FMA chains alone", 6), ("MFMA + FMA chains", 7),
                    ("fp32 FMA chains alone", 8), ("MFMA + fp32 FMA chains", 9), ("int32 chains alone", 16), ("MFMA + int32 chains", 17),
@@ -20,5 +20,5 @@ for name, mode in (("MFMA alone", 1), ("exp alone", 2), ("MFMA + exp", 3), ("FMA
 
 out = np.zeros(1)
 for name, v in (("tile engine, 2 workgroups per CU", 8), ("tile engine, 1 workgroup per CU", 8 + 64)):
-    _lib.check(L.psoap_microbench_tile_engine(0, v, out.ctypes.data_as(_lib._dp)), "tile engine")
+    _lib.check_bench(L.psoap_microbench_tile_engine(0, v, out.ctypes.data_as(_lib._dp)), "tile engine")
     print(f"{name}: {out[0]:.1f} TFLOP/s")
