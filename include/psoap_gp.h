@@ -240,6 +240,47 @@ int psoap_chunk_set_mode(psoap_chunk *h, int mode);
 /* Debug aid for the persistent kernel: the first call allocates a per-task timestamp log, later
  * calls copy it out (4 x 100 MHz stamps per task, indexed by ticket). */
 int psoap_chunk_dag_tasklog(psoap_chunk *h, unsigned long long *out, long long max_tasks);
+/* ---- Streamed evaluation (round 4): consecutive ensemble steps through ONE resident launch ----------------
+ * Replaces: the back-to-back iterations of the sampler's loop, /root/reference/psoap/sample_parallel.py:434-438 (every
+ * iteration calls lnprob -> Worker.lnprob -> covariance.lnlike[...] at :193, and the master gathers at :378-387).
+ * A plain psoap_batch_eval is one launch of the persistent kernel per step, which ramps up and drains every time;
+ * a stream keeps the launch resident and lets the MATRICES come and go: `lanes` matrix workspaces of the handle
+ * (lanes <= max_batch, <= 64) each run the same single-matrix task list, a dispatcher workgroup inside the launch pulls
+ * submitted proposals from pinned host memory and opens lanes, and the workgroup that finishes a matrix writes its
+ * lnprob straight into pinned host memory.  A proposal's result does not depend on what else is in flight: it is
+ * bit-identical for every batch size, submission order and number of GPUs.
+ * Typical use -- two half-ensembles in flight (neither half's proposals depend on the other's accept / reject):
+ *     open; tA = submit(A0); tB = submit(B0); loop { fetch(tA); tA = submit(A_next); fetch(tB); tB = submit(B_next); }
+ * While a stream is open the handle's batch entry points (psoap_batch_*, psoap_lnlike*) are refused -- the matrix
+ * workspaces belong to the resident launch -- and other launches on the device wait until it leaves (it does so by
+ * itself once nothing has been in flight for PSOAP_STREAM_IDLE_MS, default 20 ms, and comes back on the next submit). */
+/* c: number of components of every submission; scheme: -1 automatic (by lanes and N), 0 throughput, 1 latency, 2 following */
+int psoap_stream_open(psoap_chunk *h, int c, int lanes, int scheme);
+/* n proposals -- lwl (n, c, N), gp (n, 2c) as psoap_batch_upload -- into n free lanes; tickets[n] identify them.
+ * Fails when fewer than n lanes are free. */
+int psoap_stream_submit(psoap_chunk *h, int n, const double *lwl, const double *gp, double mu_GP, long long *tickets);
+/* blocks until the n results are there (any order of tickets); frees their lanes.  -inf for a negative hyper-parameter
+ * (covariance.py:317) or a matrix that is not positive definite. */
+int psoap_stream_fetch(psoap_chunk *h, int n, const long long *tickets, double *out);
+/* blocks until one of the n tickets has its result: *which = its index (then psoap_stream_fetch of that one returns at
+ * once) -- independent chains resubmit each walker the moment it completes instead of waiting for a whole group */
+int psoap_stream_wait_any(psoap_chunk *h, int n, const long long *tickets, int *which);
+/* *ready = 1 when the result of `ticket` has arrived (never blocks) */
+int psoap_stream_ready(psoap_chunk *h, long long ticket, int *ready);
+/* the resident launch leaves as soon as what is in flight is done (instead of after the idle time-out) and the call
+ * returns when it has; the stream stays open and the next submit relaunches.  Call before a device-wide synchronise. */
+int psoap_stream_pause(psoap_chunk *h);
+/* waits for what is in flight, ends the resident launch, frees the stream */
+int psoap_stream_close(psoap_chunk *h);
+/* counters: launches of the resident kernel so far (> 1 after an idle time-out), submissions, completed results, the
+ * scheme of the lanes' task list and its length; any pointer may be NULL */
+int psoap_stream_stats(psoap_chunk *h, long long *launches, long long *submitted, long long *completed, int *scheme,
+                       long long *tasks_per_matrix);
+/* Debug aids: per-task time stamps of the last `cap` submissions (allocate with out == NULL before the first submit;
+ * read with nothing in flight), and the task list every lane runs (record format of psoap_chunk_dag_tasks). */
+int psoap_stream_tasklog(psoap_chunk *h, int cap, unsigned long long *out, long long max_words);
+int psoap_stream_tasks(psoap_chunk *h, void *out, long long max_tasks, long long *n_tasks);
+
 /* Debug aid: the persistent kernel's task list (16-byte records: type, q, j, S, b(u16), pa, pb,
  * slot(u32), ctr(u32)) in ticket order; *n_tasks receives the list length. */
 int psoap_chunk_dag_tasks(psoap_chunk *h, void *out, long long max_tasks, long long *n_tasks);

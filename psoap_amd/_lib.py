@@ -84,6 +84,17 @@ SIGNATURES = {
     "psoap_group_eval": (ctypes.c_int, [_vp]),
     "psoap_group_destroy": (ctypes.c_int, [_vp]),
     "psoap_group_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
+    "psoap_stream_open": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "psoap_stream_submit": (ctypes.c_int, [_vp, ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.POINTER(ctypes.c_longlong)]),
+    "psoap_stream_fetch": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), _dp]),
+    "psoap_stream_wait_any": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), _ip]),
+    "psoap_stream_ready": (ctypes.c_int, [_vp, ctypes.c_longlong, _ip]),
+    "psoap_stream_close": (ctypes.c_int, [_vp]),
+    "psoap_stream_pause": (ctypes.c_int, [_vp]),
+    "psoap_stream_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong),
+                                          ctypes.POINTER(ctypes.c_longlong), _ip, ctypes.POINTER(ctypes.c_longlong)]),
+    "psoap_stream_tasklog": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_longlong]),
+    "psoap_stream_tasks": (ctypes.c_int, [_vp, _vp, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
     "psoap_chunk_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),
     "psoap_chunk_get_timings": (ctypes.c_int, [_vp, ctypes.POINTER(Timings)]),
     "psoap_chunk_set_stream_groups": (ctypes.c_int, [_vp, ctypes.c_int]),

@@ -126,6 +126,65 @@ class ChunkHandle:
     def sync(self):
         check(self._L.psoap_chunk_sync(self._h), "psoap_chunk_sync")
 
+    # -- streamed evaluation (include/psoap_gp.h: psoap_stream_*) ----------------------------------------
+    def stream_open(self, c: int, lanes: int | None = None, scheme: int = -1):
+        """Keep ONE launch of the persistent kernel resident: ``stream_submit`` hands proposals to free lanes,
+        ``stream_fetch`` returns their lnprob while the other lanes keep the device busy (the back-to-back iterations
+        of /root/reference/psoap/sample_parallel.py:434-438).  Batch calls are refused until ``stream_close``."""
+        lanes = self.max_batch if lanes is None else int(lanes)
+        check(self._L.psoap_stream_open(self._h, int(c), lanes, int(scheme)), "psoap_stream_open")
+        self._stream_c = int(c)
+        self.stream_lanes = lanes
+
+    def stream_submit(self, lwls, gps, mu_GP: float = 1.0) -> np.ndarray:
+        """``lwls`` (n, c, N), ``gps`` (n, 2c) -> tickets (n,) int64"""
+        lwls = as_f64(lwls)
+        if lwls.ndim != 3 or lwls.shape[1:] != (self._stream_c, self.N):
+            raise ValueError(f"lwls must have shape (n, {self._stream_c}, {self.N})")
+        n = lwls.shape[0]
+        gps = as_f64(gps, (n, 2 * self._stream_c))
+        tickets = np.empty(n, dtype=np.int64)
+        check(self._L.psoap_stream_submit(self._h, n, dptr(lwls), dptr(gps), float(mu_GP),
+                                          tickets.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))), "psoap_stream_submit")
+        return tickets
+
+    def stream_fetch(self, tickets) -> np.ndarray:
+        tickets = np.ascontiguousarray(tickets, dtype=np.int64)
+        out = np.empty(tickets.shape[0])
+        check(self._L.psoap_stream_fetch(self._h, tickets.shape[0],
+                                         tickets.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), dptr(out)),
+              "psoap_stream_fetch")
+        return out
+
+    def stream_wait_any(self, tickets) -> int:
+        """index of a ticket whose result has arrived (blocks until one has)"""
+        tickets = np.ascontiguousarray(tickets, dtype=np.int64)
+        w = ctypes.c_int(-1)
+        check(self._L.psoap_stream_wait_any(self._h, tickets.shape[0],
+                                            tickets.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), ctypes.byref(w)),
+              "psoap_stream_wait_any")
+        return int(w.value)
+
+    def stream_ready(self, ticket: int) -> bool:
+        r = ctypes.c_int(0)
+        check(self._L.psoap_stream_ready(self._h, int(ticket), ctypes.byref(r)), "psoap_stream_ready")
+        return bool(r.value)
+
+    def stream_stats(self) -> dict:
+        a, b, c_, t = (ctypes.c_longlong(0) for _ in range(4))
+        sch = ctypes.c_int(0)
+        check(self._L.psoap_stream_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c_), ctypes.byref(sch),
+                                         ctypes.byref(t)), "psoap_stream_stats")
+        return {"launches": a.value, "submitted": b.value, "completed": c_.value, "scheme": sch.value,
+                "tasks_per_matrix": t.value}
+
+    def stream_pause(self):
+        """The resident launch leaves now (after what is in flight) and the device is free; the next submit relaunches."""
+        check(self._L.psoap_stream_pause(self._h), "psoap_stream_pause")
+
+    def stream_close(self):
+        check(self._L.psoap_stream_close(self._h), "psoap_stream_close")
+
     def predict(self, mode: int, lwls, lwls_predict, mu_c, gp, want_sigma=True):
         """``predict_*`` on this chunk's resident ``fl`` / ``sigma`` (include/psoap_gp.h: psoap_chunk_predict;
         mode 0 components, 1 sum, 2 predict_f).  The workspace stays with the handle.
@@ -171,6 +230,89 @@ class ChunkHandle:
         for k, name in enumerate(K_NAMES):
             out[name] = {"ms": t.ms[k], "launches": int(t.launches[k]), "flops": t.flops[k], "bytes": t.bytes[k]}
         return out
+
+
+class StreamPipeline:
+    """``groups`` sub-ensembles of one walker ensemble in flight through a stream (``ChunkHandle.stream_open``): step k of
+    group g is fetched and its successor submitted while the other groups keep the device busy -- neither group's
+    proposals depend on another group's accept / reject (red / black halves of an ensemble; independent chains), so
+    the iteration order of /root/reference/psoap/sample_parallel.py:434-438 is kept per group.
+
+        pipe = StreamPipeline(h, c, walkers=32, groups=2)
+        pipe.start(lwls, gps)                    # all groups submitted (group g delayed by g / groups of a period)
+        for k in range(steps):
+            lnp = pipe.step(next_lwls, next_gps) # per group: fetch, then submit the same rows of the next proposals
+        last = pipe.drain()
+
+    ``step`` returns the lnprob of the proposals submitted one call earlier, in walker order."""
+
+    def __init__(self, handle: ChunkHandle, c: int, walkers: int, groups: int = 2, scheme: int = -1):
+        if walkers % groups:
+            raise ValueError("walkers must be a multiple of groups")
+        self.h, self.c, self.walkers, self.groups = handle, int(c), int(walkers), int(groups)
+        self.rows = [slice(g * walkers // groups, (g + 1) * walkers // groups) for g in range(groups)]
+        handle.stream_open(c, walkers, scheme)
+        self.tickets = [None] * groups
+        self.period = None             # seconds per ensemble step, measured by calibrate()
+
+    def calibrate(self, lwls, gps, mu_GP: float = 1.0, steps: int = 2) -> float:
+        """Seconds per ensemble step in the steady state (a few untimed steps): what the start-up stagger is set from."""
+        import time
+        self.start(lwls, gps, mu_GP, stagger=0.0)
+        self.step(lwls, gps, mu_GP)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(lwls, gps, mu_GP)
+        self.period = (time.perf_counter() - t0) / steps
+        self.drain()
+        return self.period
+
+    def start(self, lwls, gps, mu_GP: float = 1.0, stagger: float | None = None):
+        """Submit every group, group g a little later than group g - 1, so that the groups end up ``1 / groups`` of a
+        period apart and their first block rows and tails never coincide.  While only k groups are in flight they have
+        the whole device and advance ``groups / k`` times as fast as in the steady state: the k-th interval is
+        ``k * period / groups**2`` long (two groups: the second a QUARTER of a period after the first, which is then
+        half way through).  ``stagger``: that unit, ``period / groups**2``, in seconds (default from ``calibrate``)."""
+        import time
+        if stagger is None:
+            stagger = (self.period or 0.0) / self.groups ** 2
+        t0 = time.perf_counter()
+        for g, r in enumerate(self.rows):
+            while time.perf_counter() - t0 < 0.5 * g * (g + 1) * stagger:
+                pass
+            self.tickets[g] = self.h.stream_submit(lwls[r], gps[r], mu_GP)
+
+    def step(self, lwls, gps, mu_GP: float = 1.0) -> np.ndarray:
+        out = np.empty(self.walkers)
+        for g, r in enumerate(self.rows):
+            out[r] = self.h.stream_fetch(self.tickets[g])
+            self.tickets[g] = self.h.stream_submit(lwls[r], gps[r], mu_GP)
+        return out
+
+    def step_any_order(self, lwls, gps, mu_GP: float = 1.0) -> np.ndarray:
+        """The same step with the groups taken in the order in which they COMPLETE (``groups == walkers``: every chain
+        resubmitted the moment its result is there -- independent chains): no lane waits for the slowest matrix of a
+        group.  Every group is fetched and resubmitted exactly once per call."""
+        out = np.empty(self.walkers)
+        left = list(range(self.groups))
+        while left:
+            # (a group is complete when its last ticket is: wait on one ticket per group)
+            k = self.h.stream_wait_any([self.tickets[g][-1] for g in left]) if len(left) > 1 else 0
+            g = left.pop(k)
+            r = self.rows[g]
+            out[r] = self.h.stream_fetch(self.tickets[g])
+            self.tickets[g] = self.h.stream_submit(lwls[r], gps[r], mu_GP)
+        return out
+
+    def drain(self) -> np.ndarray:
+        out = np.empty(self.walkers)
+        for g, r in enumerate(self.rows):
+            out[r] = self.h.stream_fetch(self.tickets[g])
+            self.tickets[g] = None
+        return out
+
+    def close(self):
+        self.h.stream_close()
 
 
 class ChunkGroup:

@@ -95,6 +95,15 @@ struct DagQueues {
     unsigned int first[DAG_QUEUES + 1];
     unsigned int follow_first;      // scheme 2: the first block row whose strip solves follow (0, or 2: PSOAP_FOLLOW_ROW0=0)
 };
+// Scheme 0 (the kernels without the latency paths, LAT = false; round 4): updates wait for the TILES they read -- the
+// per-column progress words MatFlags::rvrow -- instead of whole block rows (dag_update).  Compile-time: a run-time switch
+// around a one-lane poll is the code shape on which hipcc parks values under the poll's exec mask (the
+// build's assembly scan caught exactly that in the first version).  -DPSOAP_NO_TILE_DEPS: whole rows as in rounds 1-3 (A/B).
+#ifdef PSOAP_NO_TILE_DEPS
+constexpr bool DAG_TILE_DEPS = false;
+#else
+constexpr bool DAG_TILE_DEPS = true;
+#endif
 
 // One entry of the host-built task list (dag_build_tasks); the ticket is the index.
 //   PART : partial left-looking update of tile (q, j) over finished block rows [pa, pb); the
@@ -159,6 +168,31 @@ __device__ __forceinline__ void dag_wait_ge(int* flag, int target, DagCtl* ctl, 
     __syncthreads();
 }
 
+// the same for two words (the two column tiles an update reads): both >= target
+__device__ __forceinline__ void dag_wait_ge2(int* fa, int* fb, int target, DagCtl* ctl, unsigned int code = 0)
+{
+    if (threadIdx.x == 0) {
+        long long spins = 0;
+        for (;;) {
+            int v = dag_peek(fa);
+            if (v >= target && fb != fa) v = dag_peek(fb);
+            if (v >= target) break;
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > DAG_MAX_SPINS) {
+                if (__hip_atomic_fetch_or(&ctl->error, 1u, PSOAP_RLX_AGENT) == 0u) {
+                    __hip_atomic_store(&ctl->pad[0], code, PSOAP_RLX_AGENT);
+                    __hip_atomic_store(&ctl->pad[1], (unsigned int)target, PSOAP_RLX_AGENT);
+                    __hip_atomic_store(&ctl->pad[2], (unsigned int)v, PSOAP_RLX_AGENT);
+                }
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
 // producer side, part 1 (all threads): drain own stores, meet at the barrier
 __device__ __forceinline__ void dag_drain()
 {
@@ -192,21 +226,41 @@ __device__ __forceinline__ void dag_task_done(MatFlags* f, int q, int ntasks_row
 
 // left-looking update over finished block rows [pa, pb) with look-ahead: all but the last panel
 // need rows_done >= pb-1, the last one rows_done >= pb
-template <bool SW = false, class SM = SmemKernel, bool ROWMAP = false>
+// (wa, wb -- tile-level dependencies, scheme 0 since round 4: the progress words of the two column tiles the update reads
+// (MatFlags::rvrow of block columns k0 / 128 and j0 / 128: r + 1 once tile (r, column) is final) instead of the count of
+// completed block rows.  A task then never waits for the stragglers of the row above, only for its own two operands --
+// with whole rows, every task of a row taken soon after the row above stalls until that row's last task is through: 7.5 %
+// of all worker time in a streamed run, where few matrices share a queue and the rows follow each other closely.)
+template <bool SW = false, class SM = SmemKernel, bool ROWMAP = false, bool TD = false>
 __device__ __forceinline__ void dag_update(Tile& t, double* Km, int ld, int k0, int j0, int pa, int pb, MatFlags* f,
-                                           DagCtl* ctl, bool wait_next, unsigned long long* tl, int wave_s = -1, SM sm = SM())
+                                           DagCtl* ctl, bool wait_next, unsigned long long* tl, int wave_s = -1, SM sm = SM(),
+                                           int* wa = nullptr, int* wb = nullptr)
 {
     if (pb <= pa) return;
     const bool diag = (k0 == j0);
+    // (task log: the time spent in the two waits below is added up in bits 40.. of word 7 -- tools/stream_timeline.py)
+    unsigned long long w0 = 0;
+    if (tl && threadIdx.x == 0) w0 = __builtin_amdgcn_s_memrealtime();
     if (pb - pa > 1) {
-        dag_wait_ge(&f->rows_done, pb - 1, ctl, 1u);
+        if constexpr (TD) dag_wait_ge2(wa, wb, pb - 1, ctl, 1u);
+        else dag_wait_ge(&f->rows_done, pb - 1, ctl, 1u);
+        if (tl && threadIdx.x == 0) {
+            const unsigned long long w1 = __builtin_amdgcn_s_memrealtime();
+            tl[7] += (w1 - w0) << 40;
+        }
         const size_t r0 = (size_t)pa * NB;
         tile_gemm_tn<SW, SM, ROWMAP>(t, Km + r0 * ld + k0, (size_t)ld, Km + r0 * ld + j0, (size_t)ld, (pb - 1 - pa) * NB, diag, 0x7fffffff, wave_s, sm);
     }
     // the last panel: the whole block row above, or (diagonal tile of the latency scheme) only its tile
     // right of the diagonal -- U(pb-1, pb), all this tile reads of that row
-    dag_wait_ge(wait_next ? &f->next_done : &f->rows_done, pb, ctl, 2u);
-    if (tl && threadIdx.x == 0) tl[4] = __builtin_amdgcn_s_memrealtime();
+    if (tl && threadIdx.x == 0) w0 = __builtin_amdgcn_s_memrealtime();
+    if constexpr (TD) dag_wait_ge2(wa, wb, pb, ctl, 2u);
+    else dag_wait_ge(wait_next ? &f->next_done : &f->rows_done, pb, ctl, 2u);
+    if (tl && threadIdx.x == 0) {
+        const unsigned long long w1 = __builtin_amdgcn_s_memrealtime();
+        tl[4] = w1;
+        tl[7] += (w1 - w0) << 40;
+    }
     const size_t r1 = (size_t)(pb - 1) * NB;
     tile_gemm_tn<SW, SM, ROWMAP>(t, Km + r1 * ld + k0, (size_t)ld, Km + r1 * ld + j0, (size_t)ld, NB, diag, 0x7fffffff, wave_s, sm);
 }
@@ -888,19 +942,394 @@ __device__ __attribute__((noinline)) void dag_special(const DagSpecialArgs* a)
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// Streamed evaluation (round 4): consecutive ensemble steps through ONE resident launch.
+//
+// A persistent launch ramps up (first block rows: short K-loops, both workgroups of a compute unit in their epilogues at
+// the same time) and drains (the last tasks are all handed out, their holders wait on the row-to-row chain); a second
+// launch cannot fill either (its workgroups get compute units only when those of the first exit).  In
+// streamed mode the launch stays resident and the MATRICES come and go instead:
+//   * the device keeps `n_lanes` matrix workspaces ("lanes": storage, flags, arrival counters, split-K slots).  Every lane
+//     runs the SAME single-matrix task list (dag_build_tasks({P}, workers / lanes)) with a ticket counter of its own, so a
+//     task only ever waits for smaller tickets of its own lane, which running workgroups hold: no deadlock, and a
+//     matrix's order of summation does not depend on what else is in flight -- a proposal's lnprob is bit-identical for
+//     every batch size, submission order and world size;
+//   * the host writes a proposal into pinned memory and publishes a ring entry; workgroup 0 of the launch, the DISPATCHER,
+//     takes no tasks: it polls the ring, pulls the proposal over PCIe into the lane's device arrays (no copy engine, no
+//     blit kernel -- neither can run beside a resident grid that owns every register file), forms r = fl - mu, clears the
+//     lane's flags and counters and opens the lane (ticket counter = 0);
+//   * workers serve the lanes of their own XCD round-robin (lane l belongs to XCD l mod 8: the tiles of one block row
+//     share an L2), steal from the others when those have nothing to hand out, and sleep on one word when nothing does;
+//   * the workgroup that finishes a matrix's last diagonal block writes lnprob and the submission number straight into
+//     pinned host memory: psoap_stream_fetch returns while the other lanes keep the device busy.
+// The launch ends when the host closes the stream or nothing was in flight for `idle_ticks`; what was published but not
+// opened survives in the ring and the next launch carries on (psoap_gp.hip relaunches on demand).  Every wait is bounded
+// and reports through DagCtl::error, mirrored into StreamHost::error.
+struct alignas(64) StreamLane {
+    unsigned int next;              // next ticket of the matrix in this lane; >= n_tasks: nothing to hand out
+    unsigned int pad0;
+    unsigned long long seq;         // submission number of that matrix
+    unsigned int pad[12];
+};
+constexpr unsigned short STREAM_BURST_END = 0x8000;   // DagTask::b of a lane's task list (the matrix index is the lane):
+                                                      // the last ticket of a burst -- the next one starts a block row
+struct alignas(64) StreamCursor {
+    unsigned int lane;              // the lane the workgroups of this XCD draw from now
+    unsigned int pad[15];
+};
+struct alignas(64) StreamDev {
+    unsigned int stop;              // dispatcher -> workers: leave when nothing is left to hand out
+    unsigned int opens;             // bumped at every lane opening (and at stop): idle workers sleep on it
+    unsigned int pad0[14];
+    StreamCursor cur[DAG_QUEUES];   // per XCD.  The lanes of an XCD are served a BURST at a time -- one block row of one
+                                    // matrix, its diagonal task first -- in turn: handed out ticket by ticket in turn, a
+                                    // row's tasks would start spread over a whole round of the lanes, the row would end a
+                                    // task's length before the next one's tickets come up, and every task of that next row
+                                    // would wait for it (measured: 6 % slower than one launch per step)
+    unsigned long long opened;      // submissions opened so far (the dispatcher's cursor; survives relaunches)
+    unsigned long long pad1[7];
+    unsigned long long completed;   // matrices finished (added to by the finishing workgroups)
+    unsigned long long pad2[7];
+};
+constexpr int STREAM_RING = 256;    // ring of submissions; at most `n_lanes` (<= 64) are ever outstanding
+constexpr int STREAM_MAX_LANES = 64;
+struct StreamEntry {
+    int lane;
+    int pad;
+    double mu;
+};
+struct StreamResult {
+    double lnp;
+    unsigned long long seq1;        // submission number + 1 once lnp is valid
+};
+struct StreamHost {                 // pinned, host-coherent memory
+    unsigned long long head;        // host -> device: entries [0, head) are published
+    unsigned int close;             // host -> device: leave as soon as everything published is done
+    unsigned int pad0[13];
+    unsigned int error;             // device -> host: a bounded wait gave up (results invalid) ...
+    unsigned int err_code, err_target, err_seen;   // ... and which
+    unsigned int exits;             // device -> host: launches that have ended
+    unsigned int pad1[11];
+    StreamEntry entry[STREAM_RING];
+    StreamResult result[STREAM_RING];
+};
+struct StreamArgs {                 // kernel argument, by value
+    StreamLane* lanes;
+    StreamDev* dev;
+    StreamHost* host;
+    const double* h_lw;             // pinned proposals, lane-major: C x N ln-wavelengths ...
+    const double* h_gp;             // ... and 2 C hyper-parameters per lane
+    const double* fl;               // the chunk's flux vector (device)
+    unsigned int n_lanes, n_tasks, ctrs_per_lane, slots_per_lane;
+    int C, N;
+    unsigned int gate;              // 1: a lane whose next block row is not ready yet is passed over (scheme 0: tile-level
+                                    // dependencies; stream_next_lane)
+    unsigned int pad1;
+    unsigned long long idle_ticks;  // 100 MHz ticks without anything in flight after which the launch ends
+    unsigned int tlog_cap;          // submissions the task log holds (ring)
+    unsigned int pad;
+};
+
+#define PSOAP_RLX_SYSTEM __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
+
+// lnp = -0.5 (z^T z + 2 sum log U_ii)   (covariance.py:329-331); -inf when not positive definite -- the expression of
+// k_finalize (chol_kernels.hpp), kept in one place so that both paths round alike
+__device__ __forceinline__ double stream_lnp(double logdet_half, double quad, bool bad)
+{
+    return bad ? -INFINITY : -0.5 * (quad + 2.0 * logdet_half);
+}
+
+// Worker side: wave 0 finds the next task -- a ticket of the lane its XCD's cursor points at; when that lane has none, of
+// the next lane of the XCD that has (the cursor moves there), else of another XCD's current lane (stealing); sleeps on
+// StreamDev::opens when no lane has any.  Returns through LDS.
+__device__ __forceinline__ void stream_take(const StreamArgs& st, int home, DagCtl* ctl, unsigned int* s_ticket, int* s_lane)
+{
+    if (threadIdx.x < 64) {
+        const int l = hw_lane();
+        int got = -1;
+        unsigned int ticket = 0;
+        int xcd = home;                 // whose cursor to follow
+        bool try_cur = true;
+        long long spins = 0;
+        for (;;) {
+            if (try_cur) {
+                unsigned int t = 0xffffffffu, L = 0;
+                if (l == 0) {
+                    L = __hip_atomic_fetch_add(&st.dev->cur[xcd].lane, 0u, PSOAP_RLX_AGENT);
+                    t = __hip_atomic_fetch_add(&st.lanes[L].next, 1u, PSOAP_RLX_AGENT);
+                }
+                t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+                L = (unsigned int)__builtin_amdgcn_readfirstlane((int)L);
+                if (t < st.n_tasks) {
+                    got = (int)L;
+                    ticket = t;
+                    break;
+                }
+            }
+            // what the wake-up word holds BEFORE the scan: an opening between scan and sleep is then not missed
+            unsigned int seen = 0;
+            if (l == 0) seen = __hip_atomic_fetch_add(&st.dev->opens, 0u, PSOAP_RLX_AGENT);
+            seen = (unsigned int)__builtin_amdgcn_readfirstlane((int)seen);
+            unsigned int v = 0xffffffffu;
+            if (l < (int)st.n_lanes) v = __hip_atomic_fetch_add(&st.lanes[l].next, 0u, PSOAP_RLX_AGENT);
+            const unsigned long long m = __ballot(v < st.n_tasks);
+            if (m != 0ull) {
+                const unsigned long long mine = m & (0x0101010101010101ull << home);
+                if (mine) {
+                    // the cursor's lane ran dry (its matrix is handed out): on to the next lane of this XCD that has tickets
+                    unsigned int L = 0;
+                    if (l == 0) L = __hip_atomic_fetch_add(&st.dev->cur[home].lane, 0u, PSOAP_RLX_AGENT);
+                    L = (unsigned int)__builtin_amdgcn_readfirstlane((int)L);
+                    const int start = ((int)L + 8) & 63;
+                    const unsigned long long rot = start ? ((mine >> start) | (mine << (64 - start))) : mine;
+                    const int pick = (__builtin_ctzll(rot) + start) & 63;
+                    if (l == 0) __hip_atomic_store(&st.dev->cur[home].lane, (unsigned int)pick, PSOAP_RLX_AGENT);
+                    xcd = home;
+                } else {
+                    // steal: another XCD's current lane (its burst order is kept), the XCDs tried in turn from a start
+                    // that differs from worker to worker
+                    const int start = (int)((blockIdx.x * 5u + (unsigned int)spins) & 63u);
+                    const unsigned long long rot = start ? ((m >> start) | (m << (64 - start))) : m;
+                    const int pick = (__builtin_ctzll(rot) + start) & 63;
+                    xcd = pick & 7;
+                    unsigned int L = 0;
+                    if (l == 0) L = __hip_atomic_fetch_add(&st.dev->cur[xcd].lane, 0u, PSOAP_RLX_AGENT);
+                    L = (unsigned int)__builtin_amdgcn_readfirstlane((int)L);
+                    if (!((m >> (L & 63u)) & 1ull) && l == 0)
+                        __hip_atomic_store(&st.dev->cur[xcd].lane, (unsigned int)pick, PSOAP_RLX_AGENT);
+                    ++spins;
+                }
+                try_cur = true;
+                continue;
+            }
+            // nothing to hand out: leave when told to, else sleep until a lane opens
+            int leave = 0;
+            for (;;) {
+                unsigned int o = 0, stop = 0, err = 0;
+                if (l == 0) {
+                    stop = __hip_atomic_fetch_add(&st.dev->stop, 0u, PSOAP_RLX_AGENT);
+                    o = __hip_atomic_fetch_add(&st.dev->opens, 0u, PSOAP_RLX_AGENT);
+                    err = __hip_atomic_fetch_or(&ctl->error, 0u, PSOAP_RLX_AGENT);
+                }
+                stop = (unsigned int)__builtin_amdgcn_readfirstlane((int)stop);
+                o = (unsigned int)__builtin_amdgcn_readfirstlane((int)o);
+                err = (unsigned int)__builtin_amdgcn_readfirstlane((int)err);
+                if (stop != 0u || err != 0u) {
+                    leave = 1;
+                    break;
+                }
+                if (o != seen) break;
+                __builtin_amdgcn_s_sleep(127);
+                __builtin_amdgcn_s_sleep(127);
+                if (++spins > 64 * DAG_MAX_SPINS) {      // (the dispatcher ends the launch long before: belt and braces)
+                    leave = 1;
+                    break;
+                }
+            }
+            if (leave) break;
+            xcd = home;
+            try_cur = true;
+        }
+        if (l == 0) {
+            *s_ticket = ticket;
+            *s_lane = got;
+            if (got >= 0) {
+                // the lane's arrays were (re)written by the dispatcher before it opened the lane
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// The ticket just taken from `lane` ended a burst (thread 0): the XCD's workgroups draw from its next lane now -- the next
+// one in turn whose coming block row is READY: its diagonal task (the burst's first ticket) finds the tile above the
+// diagonal final (MatFlags::rvrow, tile-level dependencies) and the row two above complete.  Tickets are handed out in
+// order and cannot be given back: a burst handed out early commits some forty workgroups to tasks that wait for the row
+// above (measured before: 5.5 % of all worker time in such waits, a third of it in diagonal tasks) while the other
+// lanes' rows become ready and find nobody.  When no lane of the XCD is ready the turn decides, as before.  (A lane
+// without tickets is skipped by whoever finds it so: stream_take.)
+__device__ __forceinline__ void stream_next_lane(const StreamArgs& st, int lane, const DagTask* __restrict__ tasks, MatFlags* flags)
+{
+    const int nl = (int)st.n_lanes;
+    const int per = (nl + 7 - (lane & 7)) / 8;            // lanes of this XCD
+    int fallback = -1, pick = -1;
+    int cand = lane;
+    for (int k = 0; k < per; ++k) {
+        cand = cand + 8 < nl ? cand + 8 : (cand & 7);
+        if (!st.gate) {
+            pick = cand;
+            break;
+        }
+        const unsigned int t = __hip_atomic_fetch_add(&st.lanes[cand].next, 0u, PSOAP_RLX_AGENT);
+        if (t >= st.n_tasks) continue;                    // nothing to hand out there
+        if (fallback < 0) fallback = cand;
+        const int q = tasks[t].q;
+        bool ready = true;
+        if ((tasks[t].type & DAG_TYPE_MASK) == DAG_DIAG && q >= 1) {
+            MatFlags* f = flags + cand;
+            ready = dag_peek(&f->rvrow[q]) >= q && (q < 2 || dag_peek(&f->rows_done) >= q - 1);
+        }
+        if (ready) {
+            pick = cand;
+            break;
+        }
+    }
+    if (pick < 0) pick = fallback >= 0 ? fallback : (lane + 8 < nl ? lane + 8 : (lane & 7));
+    __hip_atomic_store(&st.dev->cur[lane & 7].lane, (unsigned int)pick, PSOAP_RLX_AGENT);
+}
+
+// The matrix of `lane` is complete (thread 0 of the workgroup that finished its last diagonal block, after its release):
+// lnprob and the submission number go straight to pinned host memory.
+__device__ __forceinline__ void stream_complete(const StreamArgs& st, int lane, MatAcc* acc)
+{
+    const double lh = __hip_atomic_load(&acc->logdet_half, PSOAP_RLX_AGENT);
+    const double qd = __hip_atomic_load(&acc->quad, PSOAP_RLX_AGENT);
+    const double info = __hip_atomic_load(&acc->info, PSOAP_RLX_AGENT);
+    const unsigned long long seq = __hip_atomic_load(&st.lanes[lane].seq, PSOAP_RLX_AGENT);
+    StreamResult* res = &st.host->result[seq % STREAM_RING];
+    __hip_atomic_store(&res->lnp, stream_lnp(lh, qd, info != 0.0), PSOAP_RLX_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&res->seq1, seq + 1ull, PSOAP_RLX_SYSTEM);
+    __hip_atomic_fetch_add(&st.dev->completed, 1ull, PSOAP_RLX_AGENT);
+}
+
+// Workgroup 0 of a streamed launch (all 256 threads): open lanes as the host publishes submissions, end the launch.
+__device__ __forceinline__ void stream_dispatch(const StreamArgs& st, const DagMat* __restrict__ mats, MatFlags* flags,
+                                                int* arrive, DagCtl* ctl, unsigned long long* box /* LDS, 4 words */)
+{
+    const int tid = threadIdx.x;
+    unsigned long long opened = __hip_atomic_load(&st.dev->opened, PSOAP_RLX_AGENT);
+    unsigned long long last_busy = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        if (tid == 0) {
+            box[0] = __hip_atomic_load(&st.host->head, PSOAP_RLX_SYSTEM);
+            box[1] = (unsigned long long)__hip_atomic_load(&st.host->close, PSOAP_RLX_SYSTEM);
+            box[2] = __hip_atomic_fetch_add(&st.dev->completed, 0ull, PSOAP_RLX_AGENT);
+            box[3] = (unsigned long long)__hip_atomic_fetch_or(&ctl->error, 0u, PSOAP_RLX_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        const unsigned long long head = box[0], closing = box[1], completed = box[2], err = box[3];
+        __syncthreads();
+        if (err != 0ull) {
+            if (tid == 0) {
+                __hip_atomic_store(&st.host->err_code, __hip_atomic_load(&ctl->pad[0], PSOAP_RLX_AGENT), PSOAP_RLX_SYSTEM);
+                __hip_atomic_store(&st.host->err_target, __hip_atomic_load(&ctl->pad[1], PSOAP_RLX_AGENT), PSOAP_RLX_SYSTEM);
+                __hip_atomic_store(&st.host->err_seen, __hip_atomic_load(&ctl->pad[2], PSOAP_RLX_AGENT), PSOAP_RLX_SYSTEM);
+                __hip_atomic_store(&st.host->error, (unsigned int)err, PSOAP_RLX_SYSTEM);
+            }
+            break;
+        }
+        if (opened < head) {
+            // everything published so far in one go: the proposals of all its lanes first (one pass of PCIe pulls), ONE
+            // drain and release (the write-back of this XCD's L2 is what a release costs), then the lanes open together
+            const unsigned int nb = (unsigned int)(head - opened < (unsigned long long)st.n_lanes ? head - opened : st.n_lanes);
+            bool bad = false;
+            for (unsigned int k = 0; k < nb; ++k) {
+                const StreamEntry* e = &st.host->entry[(opened + k) % STREAM_RING];
+                const int lane = __hip_atomic_load(&e->lane, PSOAP_RLX_SYSTEM);
+                const double mu = __hip_atomic_load(&e->mu, PSOAP_RLX_SYSTEM);
+                if (lane < 0 || lane >= (int)st.n_lanes) {         // a corrupt entry: refuse, loudly
+                    bad = true;
+                    break;
+                }
+                const DagMat mat = mats[lane];
+                // the proposal: pinned host memory -> the lane's device arrays (uncached system-scope loads, sixteen in
+                // flight per thread: one after the other, a lane's 96 KB took 48 PCIe round trips)
+                {
+                    const size_t n = (size_t)st.C * st.N;
+                    const double* src = st.h_lw + (size_t)lane * n;
+                    double* dst = const_cast<double*>(mat.lw);
+                    size_t i = tid;
+                    for (; i + 15 * GEMM_THREADS < n; i += 16 * GEMM_THREADS) {
+                        double v[16];
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) v[u] = __hip_atomic_load(&src[i + (size_t)u * GEMM_THREADS], PSOAP_RLX_SYSTEM);
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) dst[i + (size_t)u * GEMM_THREADS] = v[u];
+                    }
+                    for (; i < n; i += GEMM_THREADS) dst[i] = __hip_atomic_load(&src[i], PSOAP_RLX_SYSTEM);
+                    if (tid < 2 * st.C)
+                        const_cast<double*>(mat.gp)[tid] = __hip_atomic_load(&st.h_gp[(size_t)lane * 2 * st.C + tid], PSOAP_RLX_SYSTEM);
+                }
+                // r = fl - mu (covariance.py:331), padded with zeros; accumulators, flags and arrival counters cleared
+                for (int i = tid; i < mat.Npad; i += GEMM_THREADS) mat.R[i] = (i < mat.N) ? (st.fl[i] - mu) : 0.0;
+                if (tid == 0) *mat.acc = MatAcc{0.0, 0.0, 0.0, 0.0};
+                int* fz = reinterpret_cast<int*>(flags + lane);
+                for (int i = tid; i < (int)(sizeof(MatFlags) / sizeof(int)); i += GEMM_THREADS) fz[i] = 0;
+                int* az = arrive + (size_t)lane * st.ctrs_per_lane;
+                for (int i = tid; i < (int)st.ctrs_per_lane; i += GEMM_THREADS) az[i] = 0;
+            }
+            if (bad) {
+                if (tid == 0) {
+                    __hip_atomic_fetch_or(&ctl->error, 2u, PSOAP_RLX_AGENT);
+                    __hip_atomic_store(&ctl->pad[0], 100u, PSOAP_RLX_AGENT);
+                }
+                __syncthreads();
+                continue;
+            }
+            dag_drain();
+            if (tid == 0) {
+                dag_release_fence();
+                for (unsigned int k = 0; k < nb; ++k) {
+                    const int lane = __hip_atomic_load(&st.host->entry[(opened + k) % STREAM_RING].lane, PSOAP_RLX_SYSTEM);
+                    __hip_atomic_store(&st.lanes[lane].seq, opened + k, PSOAP_RLX_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (unsigned int k = 0; k < nb; ++k) {
+                    const int lane = __hip_atomic_load(&st.host->entry[(opened + k) % STREAM_RING].lane, PSOAP_RLX_SYSTEM);
+                    __hip_atomic_store(&st.lanes[lane].next, 0u, PSOAP_RLX_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&st.dev->opened, opened + nb, PSOAP_RLX_AGENT);
+                __hip_atomic_fetch_add(&st.dev->opens, 1u, PSOAP_RLX_AGENT);
+            }
+            opened += nb;
+            last_busy = __builtin_amdgcn_s_memrealtime();
+            continue;
+        }
+        if (completed < opened) {
+            last_busy = __builtin_amdgcn_s_memrealtime();
+        } else if (closing != 0ull || __builtin_amdgcn_s_memrealtime() - last_busy > st.idle_ticks) {
+            break;      // everything published is done, and the host has closed the stream or gone quiet
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (tid == 0) {
+        __hip_atomic_store(&st.dev->stop, 1u, PSOAP_RLX_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(&st.dev->opens, 1u, PSOAP_RLX_AGENT);
+        __hip_atomic_fetch_add(&st.host->exits, 1u, PSOAP_RLX_SYSTEM);
+    }
+}
+
 // LAT: the instantiation launched for task lists of the latency scheme; only it contains the fused diagonal
 // fast path (dag_diag_fast).  With that path compiled into the one kernel, hipcc keeps a spilled value in the
 // MFMA loops of every task (a scratch load per 64-MFMA stage: 32-walker batch 39.5 -> 43.7 ms); the
 // throughput scheme never runs it, so it gets a kernel without it.
-template <int C, bool AUG = false, bool LAT = false>
+// STREAM: the resident form (above): tickets come from the lanes' own counters, matrix index = lane, workgroup 0
+// dispatches.  The task bodies are the same code.
+template <int C, bool AUG = false, bool LAT = false, bool STREAM = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __restrict__ mats,
                                                              const DagTask* __restrict__ tasks, DagQueues queues,
                                                              MatFlags* flags, int* arrive, double* wspace,
-                                                             DagCtl* ctl, unsigned long long* tlog, DagAug aug)
+                                                             DagCtl* ctl, unsigned long long* tlog, DagAug aug,
+                                                             StreamArgs st)
 {
     __shared__ double vec1[NB];   // z_k (OFF)
     __shared__ double vec2[NB];   // column sums (OFF)
     __shared__ unsigned int s_ticket;
+    __shared__ int s_lane;
+    if constexpr (STREAM) {
+        if (blockIdx.x == 0) {
+            stream_dispatch(st, mats, flags, arrive, ctl, reinterpret_cast<unsigned long long*>(vec1));
+            return;
+        }
+    }
     constexpr size_t SLOT = (size_t)NB * NB;   // doubles per workspace slot
     // the XCD this workgroup runs on: its queue first (L2 locality), the others when it runs dry.
     // Stealing starts at a queue picked uniformly among the NON-EMPTY ones (by workgroup index): with
@@ -932,27 +1361,55 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
     int probe = 0;
     for (;;) {
         Tile t;
-        if (dry == (1u << DAG_QUEUES) - 1u) return;
-        const int g = (probe == 0) ? home : (steal0 + probe - 1) % DAG_QUEUES;
-        if (dry & (1u << g)) {
-            ++probe;
-            continue;
+        unsigned int ticket;
+        int b;
+        if constexpr (STREAM) {
+            stream_take(st, home, ctl, &s_ticket, &s_lane);
+            ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)s_ticket);
+            b = __builtin_amdgcn_readfirstlane(s_lane);
+            __syncthreads();  // both are rewritten by the next stream_take
+            if (b < 0) return;
+            // the lane's proposal arrays change from matrix to matrix: nothing of the previous one may survive in the
+            // scalar cache (uniform loads -- the hyper-parameters -- go through it; the vector caches were invalidated by
+            // the acquire in stream_take)
+            asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            if (dry == (1u << DAG_QUEUES) - 1u) return;
+            const int g = (probe == 0) ? home : (steal0 + probe - 1) % DAG_QUEUES;
+            if (dry & (1u << g)) {
+                ++probe;
+                continue;
+            }
+            if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&ctl->queue[g].next, 1u, PSOAP_RLX_AGENT);
+            __syncthreads();
+            // wave-uniform by construction: keep it (and everything decoded from it) in scalar registers
+            const unsigned int local = __builtin_amdgcn_readfirstlane(s_ticket);
+            __syncthreads();  // s_ticket is rewritten at the top of the next iteration
+            if (local >= queues.first[g + 1] - queues.first[g]) {
+                dry |= 1u << g;
+                ++probe;
+                continue;
+            }
+            ticket = queues.first[g] + local;
         }
-        if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&ctl->queue[g].next, 1u, PSOAP_RLX_AGENT);
-        __syncthreads();
-        // wave-uniform by construction: keep it (and everything decoded from it) in scalar registers
-        const unsigned int local = __builtin_amdgcn_readfirstlane(s_ticket);
-        __syncthreads();  // s_ticket is rewritten at the top of the next iteration
-        if (local >= queues.first[g + 1] - queues.first[g]) {
-            dry |= 1u << g;
-            ++probe;
-            continue;
-        }
-        const unsigned int ticket = queues.first[g] + local;
         if (__hip_atomic_fetch_or(&ctl->error, 0u, PSOAP_RLX_AGENT) != 0u) return;
         const DagTask task = tasks[ticket];
-        const int b = task.b, q = task.q, j = task.j;
+        if constexpr (!STREAM) b = task.b;
+        if constexpr (STREAM) {
+            if ((task.b & STREAM_BURST_END) && threadIdx.x == 0) stream_next_lane(st, b, tasks, flags);
+        }
+        const int q = task.q, j = task.j;
         const DagMat mat = mats[b];
+        // STREAM: arrival counters, split-K slots and task-log rows of this lane
+        int* const arrive_l = STREAM ? arrive + (size_t)b * st.ctrs_per_lane : arrive;
+        double* const wspace_l = STREAM ? wspace + (size_t)b * st.slots_per_lane * ((size_t)NB * NB) : wspace;
+        unsigned long long* tlog_l = tlog;
+        if constexpr (STREAM) {
+            if (tlog) {
+                const unsigned long long sq = __hip_atomic_load(&st.lanes[b].seq, PSOAP_RLX_AGENT);
+                tlog_l = tlog + (size_t)(sq % st.tlog_cap) * st.n_tasks * 8;
+            }
+        }
         double* Km = mat.K;
         double* Rv = mat.R;
         double* Wm = mat.Wt + (size_t)(q & 1) * NB * NB;
@@ -961,10 +1418,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         const int k0 = q * NB, j0 = j * NB;
         const int ntasks_row = (AUG ? aug.Pt : mat.P) - q;
 
-        if (tlog && threadIdx.x == 0) {
-            tlog[ticket * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+        if (tlog_l && threadIdx.x == 0) {
+            tlog_l[ticket * 8 + 0] = __builtin_amdgcn_s_memrealtime();
             // where it ran: the XCD and HW_REG_HW_ID (wave slot, SIMD, CU, SH, SE) -- tools/dag_cu_overlap.py
-            tlog[ticket * 8 + 7] = ((unsigned long long)(unsigned int)home << 32) |
+            tlog_l[ticket * 8 + 7] = ((unsigned long long)(unsigned int)home << 32) |
                                    (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));
         }
         const int ttype = task.type & DAG_TYPE_MASK;
@@ -976,7 +1433,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         const int n_wait = is_part ? (chain ? (int)task.S : 0) : (int)task.S - 1;
         int n_prev = is_part ? (n_wait > 0 ? 1 : 0) : (chain ? (n_wait > 0 ? 1 : 0) : n_wait);
         // chained PART: the predecessor's tile sits in the other slot of the even/odd pair
-        const double* prev = wspace + (size_t)(is_part ? task.slot ^ 1u : task.slot) * SLOT;
+        const double* prev = wspace_l + (size_t)(is_part ? task.slot ^ 1u : task.slot) * SLOT;
         const bool preload = !is_part && chain && n_wait > 0;
 #ifdef PSOAP_FOLLOW
         // (-DPSOAP_FOLLOW: both out-of-line task kinds go through dag_special, further down, at one call site)
@@ -990,46 +1447,55 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
             args.mode = fast_diag ? 0 : 1;
             args.Km = Km; args.ld = ld; args.k0 = k0; args.j0 = j0; args.Wm = Wm; args.Rv = Rv; args.acc = mat.acc;
             args.prev = prev; args.Npad = Npad; args.f = f; args.ctl = ctl; args.q = q; args.ntasks_row = ntasks_row;
-            args.fused = (task.type & DAG_FUSED) != 0; args.chain_ctr = &arrive[task.ctr]; args.chain_len = n_wait;
+            args.fused = (task.type & DAG_FUSED) != 0; args.chain_ctr = &arrive_l[task.ctr]; args.chain_len = n_wait;
             args.smem = dag_opaque_lds(psoap_smem); args.zk = dag_opaque_lds(vec1); args.colsum = dag_opaque_lds(vec2);
-            args.tl = tlog ? tlog + ticket * 8 : nullptr;
+            args.tl = tlog_l ? tlog_l + ticket * 8 : nullptr;
             args.mbq = mat.Wt + 2 * NB * NB + mb_slot(q, 0, 0);
             args.lw = mat.lw; args.gp = mat.gp; args.sigma = mat.sigma; args.N = N;
             args.pubnext = (task.type & DAG_NOSOLVE) != 0;
             args.scale = (chain ? task.S <= 1 : true) ? 1.0 : 0.0;
             args.aug = aug;
             args.pa = task.pa; args.pb = task.pb; args.n_wait = n_wait; args.preload = preload ? 1 : 0; args.n_prev = n_prev;
-            args.arrive_ctr = &arrive[task.ctr];
+            args.arrive_ctr = &arrive_l[task.ctr];
             // second level of following: DAG_NOSOLVE on the diagonal task (it follows the strip solve of the tile above),
             // DAG_FUSED on a strip solve (it delivers its tile row block by row block, and follows the row above likewise)
             args.xlink = fast_diag ? ((task.type & DAG_NOSOLVE) != 0) : ((task.type & DAG_FUSED) != 0);
             args.xfirst = (int)queues.follow_first;
             dag_special<C, AUG>(&args);
-            if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+            if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+            if constexpr (STREAM) {
+                // (the last diagonal block: nothing of this matrix is left -- thread 0 published the task's completion)
+                if (fast_diag && q == mat.P - 1 && threadIdx.x == 0) stream_complete(st, b, mat.acc);
+            }
             continue;
         }
 #else
         if (LAT && preload && ttype == DAG_DIAG && (task.type & DAG_WAITNEXT) && task.pb - task.pa == 1) {
             dag_diag_fast(Km, ld, k0, Wm, Rv, mat.acc, prev, Npad, f, ctl, q, ntasks_row, (task.type & DAG_FUSED) != 0,
-                          &arrive[task.ctr], n_wait, dag_opaque_lds(psoap_smem), dag_opaque_lds(vec1), dag_opaque_lds(vec2),
-                          tlog ? tlog + ticket * 8 : nullptr);
+                          &arrive_l[task.ctr], n_wait, dag_opaque_lds(psoap_smem), dag_opaque_lds(vec1), dag_opaque_lds(vec2),
+                          tlog_l ? tlog_l + ticket * 8 : nullptr);
+            if constexpr (STREAM) {
+                if (q == mat.P - 1 && threadIdx.x == 0) stream_complete(st, b, mat.acc);
+            }
             continue;
         }
 #endif
         t.zero();
         if (preload) {
             // the chain ran ahead (its PARTs need older block rows): normally no wait at all
-            dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);
+            dag_wait_ge(&arrive_l[task.ctr], n_wait, ctl, 4u);
             dag_sub_partials(t, prev, 1);
             n_prev = 0;
         }
         // (DAG_WAITNEXT on a DIAG task: its last panel needs only the tile right of the diagonal above; on an OFF task
         // the bit means "follow the factorisation" and the last panel needs the whole block row above, as always)
-        dag_update<true>(t, Km, ld, k0, j0, task.pa, task.pb, f, ctl, ttype == DAG_DIAG && (task.type & DAG_WAITNEXT) != 0,
-                         tlog ? tlog + ticket * 8 : nullptr, wave_s);
-        if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 5] = __builtin_amdgcn_s_memrealtime();
-        if (!preload && n_wait > 0) dag_wait_ge(&arrive[task.ctr], n_wait, ctl, 4u);
-        if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+        // (scheme 0: tile-level dependencies; never in the LAT kernels, whose task lists carry their own protocols)
+        dag_update<true, SmemKernel, false, !LAT && DAG_TILE_DEPS>(
+            t, Km, ld, k0, j0, task.pa, task.pb, f, ctl, ttype == DAG_DIAG && (task.type & DAG_WAITNEXT) != 0,
+            tlog_l ? tlog_l + ticket * 8 : nullptr, wave_s, SmemKernel(), &f->rvrow[q], &f->rvrow[j]);
+        if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+        if (!preload && n_wait > 0) dag_wait_ge(&arrive_l[task.ctr], n_wait, ctl, 4u);
+        if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 6] = __builtin_amdgcn_s_memrealtime();
         dag_sub_partials(t, prev, n_prev);
         {
             GpDev g;
@@ -1039,7 +1505,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
 #pragma clang fp contract(off)
                 for (int c = 1; c < C; ++c) dsum = dsum + g.a2[c];
             }
-            double* dest = is_part ? (wspace + (size_t)task.slot * SLOT) : (Km + (size_t)k0 * ld + j0);
+            double* dest = is_part ? (wspace_l + (size_t)task.slot * SLOT) : (Km + (size_t)k0 * ld + j0);
             size_t ldd = is_part ? (size_t)NB : (size_t)ld;
             double* mirror = nullptr;
             if (AUG && ttype == DAG_SCHUR) {
@@ -1059,21 +1525,25 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
             dag_drain();
             if (threadIdx.x == 0) {
                 dag_release_fence();
-                __hip_atomic_fetch_add(&arrive[task.ctr], 1, PSOAP_RLX_AGENT);
+                __hip_atomic_fetch_add(&arrive_l[task.ctr], 1, PSOAP_RLX_AGENT);
             }
-            if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+            if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
             continue;
         }
         if (AUG && ttype == DAG_SCHUR) continue;     // nobody inside the launch reads Sigma: no drain, no counter
         dag_drain();  // the tile is re-read below in another layout by other waves of this block
-        if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+        if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 1] = __builtin_amdgcn_s_memrealtime();
         if (ttype == DAG_DIAG) {
             // the diagonal task is the row-to-row critical path: let its waves win the issue arbitration
             // against the co-resident workgroup (N = 2000, B = 32: -4 % with the deferred W output)
             __builtin_amdgcn_s_setprio(3);
+            // (tile-level dependencies: block q - 2's strip solves read the W buffer this factorisation writes, and the row
+            // counters alternate by parity -- all of row q - 2 has to be through; it has been for a whole row's time)
+            // (no branch around the poll: rows_done >= 0 always holds)
+            if constexpr (!LAT && DAG_TILE_DEPS) dag_wait_ge(&f->rows_done, q >= 2 ? q - 1 : 0, ctl, 9u);
             potrf_blocked(Km, ld, k0, Wm, Rv, mat.acc);
             dag_drain();
-            if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+            if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 2] = __builtin_amdgcn_s_memrealtime();
             if (threadIdx.x == 0) {
                 dag_release_fence();
                 __hip_atomic_store(&f->potrf_done, q + 1, PSOAP_RLX_AGENT);
@@ -1092,6 +1562,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
                 }
             } else if (threadIdx.x == 0) {
                 dag_task_done(f, q, ntasks_row);
+                if constexpr (STREAM) {
+                    if (q == mat.P - 1) stream_complete(st, b, mat.acc);
+                }
             }
             __builtin_amdgcn_s_setprio(0);
         } else if (task.type & DAG_NOSOLVE) {
@@ -1101,15 +1574,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
             }
         } else {
             dag_wait_ge(&f->potrf_done, q + 1, ctl, 3u + 16u * (unsigned int)q + 4096u * (unsigned int)b);
-            if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+            if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 2] = __builtin_amdgcn_s_memrealtime();
             dag_trsm<true>(t, Km, ld, k0, j0, Wm, Rv, Npad, vec1, vec2);
             dag_drain();
             if (threadIdx.x == 0) {
                 dag_release_fence();
+                // tile (q, j) is final and its share of the right-hand side block j applied
+                if constexpr (!LAT && DAG_TILE_DEPS) __hip_atomic_store(&f->rvrow[j], q + 1, PSOAP_RLX_AGENT);
                 dag_task_done(f, q, ntasks_row);
             }
         }
-        if (tlog && threadIdx.x == 0) tlog[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+        if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

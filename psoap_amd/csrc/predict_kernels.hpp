@@ -534,7 +534,7 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
 #define PSOAP_LAUNCH_AUG(CC, LAT)                                                                                 \
     hipLaunchKernelGGL((k_chol_dag<CC, true, LAT>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, ws.Mat.p,  \
                        ws.Tasks.p, plan.queues, fl_, reinterpret_cast<int*>(ws.Dag.p + arrive_off), ws.Ws.p, ctl_,  \
-                       (unsigned long long*)nullptr, aug)
+                       (unsigned long long*)nullptr, aug, StreamArgs{})
         const bool lat = plan.scheme >= 1;
         if (c == 1) { if (lat) PSOAP_LAUNCH_AUG(1, true); else PSOAP_LAUNCH_AUG(1, false); }
         else if (c == 2) { if (lat) PSOAP_LAUNCH_AUG(2, true); else PSOAP_LAUNCH_AUG(2, false); }

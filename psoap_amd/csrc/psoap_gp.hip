@@ -74,6 +74,35 @@ struct BatchSlot {
 
 namespace psoap { struct PredictWs; }
 
+// Streamed evaluation (dag_kernel.hpp, "Streamed evaluation"): one resident launch of the persistent kernel, matrices
+// come and go through `lanes` workspaces of the handle.  Host side: lane allocation, the submission ring in pinned
+// memory, launch / relaunch, result polling.
+struct StreamState {
+    bool open = false;
+    int C = 0, lanes = 0, scheme = 0;
+    unsigned int n_tasks = 0, ctrs_per_lane = 0, slots_per_lane = 0;
+    DagQueues queues{};
+    DagTask* dTasks = nullptr;
+    StreamLane* dLanes = nullptr;
+    StreamDev* dDev = nullptr;
+    StreamHost* hHost = nullptr;       // pinned, host-coherent
+    double* hLw = nullptr;             // pinned proposals, lane-major
+    double* hGp = nullptr;
+    double* dWs = nullptr;             // lanes x slots_per_lane partial tiles
+    char* dDag = nullptr;              // DagCtl, MatFlags[lanes], arrival counters[lanes x ctrs_per_lane]
+    size_t arrive_off = 0;
+    DagMat* dMats = nullptr;
+    unsigned long long* dTlog = nullptr;
+    unsigned int tlog_cap = 0;
+    hipEvent_t evExit = nullptr;
+    bool launched = false;
+    unsigned long long head = 0;                 // submissions published
+    std::vector<long long> lane_ticket;          // ticket held by each lane, -1: free
+    std::vector<char> neg;                       // per ring entry: a hyper-parameter was negative -> -inf
+    long long launches = 0;
+    double idle_ms = 20.0;
+};
+
 struct psoap_chunk {
     int device = 0;
     int N = 0, Npad = 0, ld = 0, P = 0;
@@ -141,6 +170,8 @@ struct psoap_chunk {
     psoap_timings last = {};
     // predict workspace (grow-only; psoap_chunk_predict)
     psoap::PredictWs* pws = nullptr;
+    // streamed evaluation (psoap_stream_*)
+    StreamState stream;
 };
 
 static int set_dev(const psoap_chunk* h) { HIP_TRY(hipSetDevice(h->device)); return 0; }
@@ -176,6 +207,12 @@ static int configure_kernels(int device)
     PSOAP_SET_LDS(k_chol_dag<1, false, true>);
     PSOAP_SET_LDS(k_chol_dag<2, false, true>);
     PSOAP_SET_LDS(k_chol_dag<3, false, true>);
+    PSOAP_SET_LDS(k_chol_dag<1, false, false, true>);
+    PSOAP_SET_LDS(k_chol_dag<2, false, false, true>);
+    PSOAP_SET_LDS(k_chol_dag<3, false, false, true>);
+    PSOAP_SET_LDS(k_chol_dag<1, false, true, true>);
+    PSOAP_SET_LDS(k_chol_dag<2, false, true, true>);
+    PSOAP_SET_LDS(k_chol_dag<3, false, true, true>);
 #undef PSOAP_SET_LDS
     HIP_TRY(predict_configure_kernels());
     if (done.size() <= (size_t)device) done.resize((size_t)device + 1, 0);
@@ -277,10 +314,13 @@ extern "C" int psoap_chunk_create(psoap_chunk** out, int device, int N, const do
 
 
 
+extern "C" int psoap_stream_close(psoap_chunk* h);
+
 extern "C" int psoap_chunk_destroy(psoap_chunk* h)
 {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
+    if (h->stream.open) (void)psoap_stream_close(h);
     (void)hipDeviceSynchronize();
     (void)hipFree(h->dFl); (void)hipFree(h->dSigma); (void)hipFree(h->dGrid); (void)hipFree(h->dEpoch);
     (void)hipFree(h->dK); (void)hipFree(h->dWt); (void)hipFree(h->dR); (void)hipFree(h->dAcc);
@@ -463,6 +503,7 @@ extern "C" int psoap_chunk_set_profiling(psoap_chunk* h, int enabled)
 // previous user of the pinned staging buffers are done, and record the batch's host-side state.
 static int upload_begin(psoap_chunk* h, int B, int c, const double* gp, double mu_GP, BatchSlot** out)
 {
+    if (h->stream.open) FAIL("the handle has an open stream (psoap_stream_close first): its workspaces belong to the resident launch");
     if (B < 1 || B > h->max_batch) FAIL("batch size outside [1, max_batch]");
     if (c < 1 || c > 3) FAIL("number of components must be 1, 2 or 3");
     const int target = (h->pend >= 0) ? h->pend : (h->act < 0 ? 0 : (h->act ^ 1));
@@ -765,7 +806,7 @@ static int eval_dag(psoap_chunk* h)
 #define PSOAP_LAUNCH_DAG(CC, LAT)                                                                                \
     hipLaunchKernelGGL((k_chol_dag<CC, false, LAT>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, sl.dMats, \
                        h->dTasks, h->plan_queues, fl_, reinterpret_cast<int*>(h->dDag + h->arrive_off), h->dWs,   \
-                       ctl_, h->dTlog, DagAug{P, 0, 0, nullptr})
+                       ctl_, h->dTlog, DagAug{P, 0, 0, nullptr}, StreamArgs{})
         const bool lat = h->plan_scheme >= 1;
         if (C == 1) { if (lat) PSOAP_LAUNCH_DAG(1, true); else PSOAP_LAUNCH_DAG(1, false); }
         else if (C == 2) { if (lat) PSOAP_LAUNCH_DAG(2, true); else PSOAP_LAUNCH_DAG(2, false); }
@@ -1062,7 +1103,7 @@ extern "C" int psoap_group_eval(psoap_group* g)
 #define PSOAP_LAUNCH_GROUP(CC, LAT)                                                                             \
     hipLaunchKernelGGL((k_chol_dag<CC, false, LAT>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, g->dMats, \
                        g->dTasks, g->queues, fl_, reinterpret_cast<int*>(g->dDag + g->arrive_off), g->dWs, ctl_,  \
-                       (unsigned long long*)nullptr, DagAug{0, 0, 0, nullptr})
+                       (unsigned long long*)nullptr, DagAug{0, 0, 0, nullptr}, StreamArgs{})
         const bool lat = g->scheme >= 1;
         if (C == 1) { if (lat) PSOAP_LAUNCH_GROUP(1, true); else PSOAP_LAUNCH_GROUP(1, false); }
         else if (C == 2) { if (lat) PSOAP_LAUNCH_GROUP(2, true); else PSOAP_LAUNCH_GROUP(2, false); }
@@ -1092,6 +1133,400 @@ extern "C" int psoap_group_stats(psoap_group* g, long long* plan_builds, long lo
     if (plan_builds) *plan_builds = g->plan_builds;
     if (record_refreshes) *record_refreshes = g->record_refreshes;
     return 0;
+}
+
+
+// ---- streamed evaluation ---------------------------------------------------------------------------
+// The reference issues one iteration after another (psoap/sample_parallel.py:434-438: the sampler's loop; :193 the
+// likelihood call inside it).  psoap_stream_* keeps ONE launch of the persistent kernel resident across those
+// iterations: submit() hands proposals to free lanes, fetch() returns their lnprob; see dag_kernel.hpp.
+static int stream_launch(psoap_chunk* h)
+{
+    StreamState& st = h->stream;
+    hipStream_t s = h->streams[0];
+    HIP_TRY(hipMemsetAsync(st.dDev, 0, 64, s));      // stop, opens (no workgroup of an earlier launch is left: same stream)
+    StreamArgs a{};
+    a.lanes = st.dLanes;
+    a.dev = st.dDev;
+    a.host = st.hHost;
+    a.h_lw = st.hLw;
+    a.h_gp = st.hGp;
+    a.fl = h->dFl;
+    a.n_lanes = (unsigned int)st.lanes;
+    a.n_tasks = st.n_tasks;
+    a.ctrs_per_lane = st.ctrs_per_lane;
+    a.slots_per_lane = st.slots_per_lane;
+    a.C = st.C;
+    a.N = h->N;
+    a.idle_ticks = (unsigned long long)(st.idle_ms * 1e5);      // s_memrealtime: 100 MHz
+    {
+        const char* e = getenv("PSOAP_STREAM_GATE");            // experiments; 0: lanes strictly in turn
+        a.gate = (st.scheme == 0 && DAG_TILE_DEPS && !(e && e[0] == '0')) ? 1u : 0u;
+    }
+    a.tlog_cap = st.tlog_cap;
+    MatFlags* fl_ = reinterpret_cast<MatFlags*>(st.dDag + sizeof(DagCtl));
+    DagCtl* ctl_ = reinterpret_cast<DagCtl*>(st.dDag);
+    const int grid = h->dag_grid;
+#define PSOAP_LAUNCH_STREAM(CC, LAT)                                                                              \
+    hipLaunchKernelGGL((k_chol_dag<CC, false, LAT, true>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s,      \
+                       st.dMats, st.dTasks, st.queues, fl_, reinterpret_cast<int*>(st.dDag + st.arrive_off), st.dWs, \
+                       ctl_, st.dTlog, DagAug{h->P, 0, 0, nullptr}, a)
+    const bool lat = st.scheme >= 1;
+    if (st.C == 1) { if (lat) PSOAP_LAUNCH_STREAM(1, true); else PSOAP_LAUNCH_STREAM(1, false); }
+    else if (st.C == 2) { if (lat) PSOAP_LAUNCH_STREAM(2, true); else PSOAP_LAUNCH_STREAM(2, false); }
+    else { if (lat) PSOAP_LAUNCH_STREAM(3, true); else PSOAP_LAUNCH_STREAM(3, false); }
+#undef PSOAP_LAUNCH_STREAM
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(st.evExit, s));
+    st.launched = true;
+    ++st.launches;
+    return 0;
+}
+
+// the resident launch is there, or comes back (it leaves by itself when nothing was in flight for idle_ms)
+static int stream_ensure_running(psoap_chunk* h)
+{
+    StreamState& st = h->stream;
+    if (st.launched) {
+        const hipError_t q = hipEventQuery(st.evExit);
+        if (q == hipErrorNotReady) return 0;
+        if (q != hipSuccess) {
+            g_err = std::string("stream: the resident launch failed: ") + hipGetErrorString(q);
+            return 1;
+        }
+    }
+    return stream_launch(h);
+}
+
+static int stream_free(psoap_chunk* h)
+{
+    StreamState& st = h->stream;
+    (void)hipFree(st.dTasks); (void)hipFree(st.dLanes); (void)hipFree(st.dDev); (void)hipFree(st.dWs);
+    (void)hipFree(st.dDag); (void)hipFree(st.dMats); (void)hipFree(st.dTlog);
+    (void)hipHostFree(st.hHost); (void)hipHostFree(st.hLw); (void)hipHostFree(st.hGp);
+    if (st.evExit) (void)hipEventDestroy(st.evExit);
+    st = StreamState();
+    return 0;
+}
+
+static int stream_open_impl(psoap_chunk* h, int c, int lanes, int scheme)
+{
+    StreamState& st = h->stream;
+    st.C = c;
+    st.lanes = lanes;
+    const std::vector<int> all((size_t)lanes, h->P);
+    if (scheme < 0) {
+        const char* e = getenv("PSOAP_STREAM_SCHEME");
+        scheme = e ? atoi(e) : dag_auto_scheme(all);
+    }
+    // every lane runs the task list of ONE matrix, cut as if `lanes` matrices shared the workers (one workgroup dispatches)
+    const int share = (h->dag_grid - 1) / lanes > 0 ? (h->dag_grid - 1) / lanes : 1;
+    DagPlan plan = dag_build_tasks(std::vector<int>(1, h->P), share, scheme);
+    // bursts: the lanes of an XCD are served one block row at a time, the row's diagonal task first -- a burst ends with
+    // the ticket in front of a diagonal final (PSOAP_STREAM_BURSTS=0: ticket by ticket in turn, experiments)
+    {
+        const char* e = getenv("PSOAP_STREAM_BURSTS");
+        const bool bursts = !(e && e[0] == '0');
+        for (size_t i = 0; i < plan.tasks.size(); ++i) {
+            const bool last = i + 1 == plan.tasks.size();
+            const bool next_diag = !last && (plan.tasks[i + 1].type & DAG_TYPE_MASK) == DAG_DIAG;
+            plan.tasks[i].b = (unsigned short)((!bursts || last || next_diag) ? STREAM_BURST_END : 0);
+        }
+    }
+    st.scheme = plan.scheme;
+    st.queues = plan.queues;
+    st.n_tasks = (unsigned int)plan.tasks.size();
+    st.ctrs_per_lane = plan.n_ctrs + 4;
+    st.slots_per_lane = plan.n_slots + 1;
+    if (const char* e = getenv("PSOAP_STREAM_IDLE_MS")) st.idle_ms = atof(e) > 0.0 ? atof(e) : st.idle_ms;
+    HIP_TRY(hipMalloc(&st.dTasks, sizeof(DagTask) * plan.tasks.size()));
+    HIP_TRY(hipMemcpy(st.dTasks, plan.tasks.data(), sizeof(DagTask) * plan.tasks.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&st.dLanes, sizeof(StreamLane) * lanes));
+    {
+        // next >= n_tasks: nothing to hand out.  (Not 0xffffffff: a worker's failed fetch-add would wrap it to 0.)
+        std::vector<StreamLane> init((size_t)lanes);
+        memset(init.data(), 0, sizeof(StreamLane) * lanes);
+        for (StreamLane& ln : init) ln.next = 0x40000000u;
+        HIP_TRY(hipMemcpy(st.dLanes, init.data(), sizeof(StreamLane) * lanes, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc(&st.dDev, sizeof(StreamDev)));
+    {
+        StreamDev init;
+        memset(&init, 0, sizeof init);
+        for (int x = 0; x < DAG_QUEUES; ++x) init.cur[x].lane = (unsigned int)(x % lanes);   // XCD x starts at its first lane
+        HIP_TRY(hipMemcpy(st.dDev, &init, sizeof init, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipHostMalloc(&st.hHost, sizeof(StreamHost), hipHostMallocCoherent));
+    memset(st.hHost, 0, sizeof(StreamHost));
+    HIP_TRY(hipHostMalloc(&st.hLw, sizeof(double) * (size_t)lanes * c * h->N, hipHostMallocCoherent));
+    HIP_TRY(hipHostMalloc(&st.hGp, sizeof(double) * (size_t)lanes * 2 * c, hipHostMallocCoherent));
+    HIP_TRY(hipMalloc(&st.dWs, sizeof(double) * NB * NB * (size_t)st.slots_per_lane * lanes));
+    st.arrive_off = sizeof(DagCtl) + sizeof(MatFlags) * (size_t)lanes;
+    const size_t dag_bytes = st.arrive_off + sizeof(int) * (size_t)st.ctrs_per_lane * lanes;
+    HIP_TRY(hipMalloc(&st.dDag, dag_bytes));
+    HIP_TRY(hipMemset(st.dDag, 0, dag_bytes));
+    HIP_TRY(hipMalloc(&st.dMats, sizeof(DagMat) * lanes));
+    std::vector<DagMat> mats((size_t)lanes);
+    for (int b = 0; b < lanes; ++b) {
+        DagMat m{};
+        m.K = h->dK + (size_t)b * h->mat_stride;
+        m.R = h->dR + (size_t)b * h->Npad;
+        m.Wt = h->dWt + (size_t)b * WT_STRIDE;
+        m.lw = h->slot[0].dLwl + (size_t)b * c * h->N;       // the lane's device copy of its proposal (the dispatcher fills it)
+        m.gp = h->slot[0].dGp + (size_t)b * 2 * c;
+        m.sigma = h->dSigma;
+        m.acc = h->dAcc + b;
+        m.N = h->N;
+        m.Npad = h->Npad;
+        m.P = h->P;
+        m.ld = h->ld;
+        mats[b] = m;
+    }
+    HIP_TRY(hipMemcpy(st.dMats, mats.data(), sizeof(DagMat) * lanes, hipMemcpyHostToDevice));
+    HIP_TRY(hipEventCreateWithFlags(&st.evExit, hipEventDisableTiming));
+    st.lane_ticket.assign((size_t)lanes, -1);
+    st.neg.assign(STREAM_RING, 0);
+    st.head = 0;
+    st.open = true;
+    return 0;
+}
+
+extern "C" int psoap_stream_open(psoap_chunk* h, int c, int lanes, int scheme)
+{
+    if (!h) FAIL("psoap_stream_open: null handle");
+    if (c < 1 || c > 3) FAIL("psoap_stream_open: number of components must be 1, 2 or 3");
+    if (lanes < 1 || lanes > h->max_batch || lanes > STREAM_MAX_LANES)
+        FAIL("psoap_stream_open: 1 <= lanes <= min(max_batch, 64)");
+    if (scheme < -1 || scheme > 2) FAIL("psoap_stream_open: scheme must be -1 (automatic), 0, 1 or 2");
+    if (h->P > 255) FAIL("psoap_stream_open: N too large for the persistent kernel (N <= 32640)");
+    if (h->stream.open) FAIL("psoap_stream_open: the handle already has an open stream");
+    if (int rc = enter_device(h->device)) return rc;
+    if (int rc = psoap_chunk_sync(h)) return rc;         // batch evaluations of this handle use the same workspaces
+    // the lanes' proposal arrays are those of proposal slot 0: whatever batch was uploaded is gone
+    h->pend = -1;
+    h->act = -1;
+    h->slot[0].B = h->slot[1].B = 0;
+    if (int rc = stream_open_impl(h, c, lanes, scheme)) {
+        const std::string keep = g_err;
+        (void)stream_free(h);
+        g_err = keep;
+        return rc;
+    }
+    return 0;
+}
+
+extern "C" int psoap_stream_submit(psoap_chunk* h, int n, const double* lwl, const double* gp, double mu_GP,
+                                   long long* tickets)
+{
+    if (!h || !lwl || !gp || !tickets || n < 1) FAIL("psoap_stream_submit: bad arguments");
+    StreamState& st = h->stream;
+    if (!st.open) FAIL("psoap_stream_submit: no open stream (psoap_stream_open)");
+    if (set_dev(h)) return 1;
+    if (st.hHost->error != 0u) FAIL("psoap_stream_submit: the stream has failed (a dependency wait timed out); close it");
+    int free_lanes = 0;
+    for (long long t : st.lane_ticket) free_lanes += (t < 0);
+    if (n > free_lanes) FAIL("psoap_stream_submit: not enough free lanes (fetch outstanding results first)");
+    const int c = st.C;
+    const size_t nl = (size_t)c * h->N;
+    int lane = 0;
+    for (int k = 0; k < n; ++k) {
+        while (st.lane_ticket[lane] >= 0) ++lane;
+        const unsigned long long seq = st.head + (unsigned long long)k;
+        memcpy(st.hLw + (size_t)lane * nl, lwl + (size_t)k * nl, sizeof(double) * nl);
+        memcpy(st.hGp + (size_t)lane * 2 * c, gp + (size_t)k * 2 * c, sizeof(double) * 2 * c);
+        char neg = 0;
+        for (int i = 0; i < 2 * c; ++i)
+            if (gp[(size_t)k * 2 * c + i] < 0.0) neg = 1;      // covariance.py:317,339,362
+        st.neg[seq % STREAM_RING] = neg;
+        StreamEntry& e = st.hHost->entry[seq % STREAM_RING];
+        e.lane = lane;
+        e.mu = mu_GP;
+        st.hHost->result[seq % STREAM_RING].seq1 = 0ull;
+        st.lane_ticket[lane] = (long long)seq;
+        tickets[k] = (long long)seq;
+    }
+    // publish: everything above is visible before the new head (the device reads head, then the entries and proposals)
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    st.head += (unsigned long long)n;
+    __atomic_store_n(&st.hHost->head, st.head, __ATOMIC_RELEASE);
+    return stream_ensure_running(h);
+}
+
+// 1: the result of `ticket` is there, 0: not yet (never blocks)
+extern "C" int psoap_stream_ready(psoap_chunk* h, long long ticket, int* ready)
+{
+    if (!h || !ready || !h->stream.open) FAIL("psoap_stream_ready: bad arguments / no open stream");
+    const StreamState& st = h->stream;
+    if (ticket < 0 || (unsigned long long)ticket >= st.head) FAIL("psoap_stream_ready: unknown ticket");
+    *ready = __atomic_load_n(&st.hHost->result[(unsigned long long)ticket % STREAM_RING].seq1, __ATOMIC_ACQUIRE) ==
+             (unsigned long long)ticket + 1ull;
+    return 0;
+}
+
+// blocks until ONE of the n tickets has its result; *which = its index in `tickets` (the lowest ready one)
+extern "C" int psoap_stream_wait_any(psoap_chunk* h, int n, const long long* tickets, int* which)
+{
+    if (!h || !tickets || !which || n < 1) FAIL("psoap_stream_wait_any: bad arguments");
+    StreamState& st = h->stream;
+    if (!st.open) FAIL("psoap_stream_wait_any: no open stream");
+    if (set_dev(h)) return 1;
+    for (int k = 0; k < n; ++k)
+        if (tickets[k] < 0 || (unsigned long long)tickets[k] >= st.head) FAIL("psoap_stream_wait_any: unknown ticket");
+    long long spins = 0;
+    for (;;) {
+        for (int k = 0; k < n; ++k) {
+            const unsigned long long t = (unsigned long long)tickets[k];
+            if (__atomic_load_n(&st.hHost->result[t % STREAM_RING].seq1, __ATOMIC_ACQUIRE) == t + 1ull) {
+                *which = k;
+                return 0;
+            }
+        }
+        if ((++spins & 255) == 0) {
+            if (__atomic_load_n(&st.hHost->error, __ATOMIC_ACQUIRE) != 0u)
+                FAIL("psoap_stream_wait_any: a dependency wait in the resident kernel timed out (results invalid)");
+            if (int rc = stream_ensure_running(h)) return rc;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+
+extern "C" int psoap_stream_fetch(psoap_chunk* h, int n, const long long* tickets, double* out)
+{
+    if (!h || !tickets || !out || n < 1) FAIL("psoap_stream_fetch: bad arguments");
+    StreamState& st = h->stream;
+    if (!st.open) FAIL("psoap_stream_fetch: no open stream");
+    if (set_dev(h)) return 1;
+    for (int k = 0; k < n; ++k) {
+        const long long t = tickets[k];
+        if (t < 0 || (unsigned long long)t >= st.head) FAIL("psoap_stream_fetch: unknown ticket");
+        const size_t idx = (size_t)((unsigned long long)t % STREAM_RING);
+        int lane = -1;
+        for (int l = 0; l < st.lanes; ++l)
+            if (st.lane_ticket[l] == t) lane = l;
+        if (lane < 0) FAIL("psoap_stream_fetch: the ticket was fetched before (or is too old)");
+        long long spins = 0;
+        while (__atomic_load_n(&st.hHost->result[idx].seq1, __ATOMIC_ACQUIRE) != (unsigned long long)t + 1ull) {
+            if ((++spins & 1023) == 0) {
+                if (__atomic_load_n(&st.hHost->error, __ATOMIC_ACQUIRE) != 0u) {
+                    char buf[256];
+                    snprintf(buf, sizeof buf,
+                             "psoap_stream_fetch: a dependency wait in the resident kernel timed out (results invalid); "
+                             "first failing wait: code=%u target=%u seen=%u", st.hHost->err_code, st.hHost->err_target,
+                             st.hHost->err_seen);
+                    FAIL(buf);
+                }
+                // the launch may have ended (idle time-out) between this ticket's submission and its opening
+                if (int rc = stream_ensure_running(h)) return rc;
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        out[k] = st.neg[idx] ? -INFINITY : st.hHost->result[idx].lnp;
+        st.lane_ticket[lane] = -1;
+    }
+    return 0;
+}
+
+extern "C" int psoap_stream_stats(psoap_chunk* h, long long* launches, long long* submitted, long long* completed,
+                                  int* scheme, long long* tasks_per_matrix)
+{
+    if (!h || !h->stream.open) FAIL("psoap_stream_stats: no open stream");
+    if (set_dev(h)) return 1;
+    const StreamState& st = h->stream;
+    if (launches) *launches = st.launches;
+    if (submitted) *submitted = (long long)st.head;
+    if (completed) {
+        long long done = 0;
+        for (unsigned long long t = st.head > STREAM_RING ? st.head - STREAM_RING : 0; t < st.head; ++t)
+            done += st.hHost->result[t % STREAM_RING].seq1 == t + 1ull;
+        *completed = (st.head > STREAM_RING ? (long long)(st.head - STREAM_RING) : 0) + done;
+    }
+    if (scheme) *scheme = st.scheme;
+    if (tasks_per_matrix) *tasks_per_matrix = (long long)st.n_tasks;
+    return 0;
+}
+
+// Debug: per-task timestamps of the last `cap` submissions (8 x 100 MHz stamps per task, rows of n_tasks per
+// submission, submission s in row s mod cap).  First call (out == NULL) allocates -- before the first submit.
+extern "C" int psoap_stream_tasklog(psoap_chunk* h, int cap, unsigned long long* out, long long max_words)
+{
+    if (!h || !h->stream.open || cap < 1) FAIL("psoap_stream_tasklog: bad arguments / no open stream");
+    StreamState& st = h->stream;
+    if (set_dev(h)) return 1;
+    const size_t words = (size_t)cap * st.n_tasks * 8;
+    if (!out) {
+        if (st.launched) FAIL("psoap_stream_tasklog: allocate before the first submission");
+        if (st.dTlog) HIP_TRY(hipFree(st.dTlog));
+        st.dTlog = nullptr;
+        HIP_TRY(hipMalloc(&st.dTlog, sizeof(unsigned long long) * words));
+        HIP_TRY(hipMemset(st.dTlog, 0, sizeof(unsigned long long) * words));
+        st.tlog_cap = (unsigned int)cap;
+        return 0;
+    }
+    if (!st.dTlog || (unsigned int)cap != st.tlog_cap) FAIL("psoap_stream_tasklog: no log of that capacity");
+    // (the copy waits for the resident launch to leave: call it with nothing in flight)
+    HIP_TRY(hipStreamSynchronize(h->streams[0]));
+    const size_t n = (size_t)max_words < words ? (size_t)max_words : words;
+    HIP_TRY(hipMemcpy(out, st.dTlog, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// Debug: the task list every lane runs (16-byte DagTask records, ticket order)
+extern "C" int psoap_stream_tasks(psoap_chunk* h, void* out, long long max_tasks, long long* n_tasks)
+{
+    if (!h || !h->stream.open || !n_tasks) FAIL("psoap_stream_tasks: bad arguments / no open stream");
+    if (set_dev(h)) return 1;
+    const StreamState& st = h->stream;
+    *n_tasks = st.n_tasks;
+    if (out) {
+        HIP_TRY(hipStreamSynchronize(h->streams[0]));
+        const long long n = max_tasks < (long long)st.n_tasks ? max_tasks : (long long)st.n_tasks;
+        HIP_TRY(hipMemcpy(out, st.dTasks, sizeof(DagTask) * n, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+// The resident launch leaves NOW (once what is in flight is done) instead of after the idle time-out, and the call
+// returns when it has: the device is free for other work (another handle's launch, a device-wide synchronise).  The
+// stream stays open; the next submit brings the launch back.
+extern "C" int psoap_stream_pause(psoap_chunk* h)
+{
+    if (!h) FAIL("psoap_stream_pause: null handle");
+    StreamState& st = h->stream;
+    if (!st.open) FAIL("psoap_stream_pause: no open stream");
+    if (set_dev(h)) return 1;
+    if (!st.launched) return 0;
+    __atomic_store_n(&st.hHost->close, 1u, __ATOMIC_RELEASE);
+    const hipError_t e = hipStreamSynchronize(h->streams[0]);
+    __atomic_store_n(&st.hHost->close, 0u, __ATOMIC_RELEASE);
+    if (e != hipSuccess) {
+        g_err = std::string("psoap_stream_pause: ") + hipGetErrorString(e);
+        return 1;
+    }
+    return 0;
+}
+
+extern "C" int psoap_stream_close(psoap_chunk* h)
+{
+    if (!h) FAIL("psoap_stream_close: null handle");
+    StreamState& st = h->stream;
+    if (!st.open) return 0;
+    if (set_dev(h)) return 1;
+    int rc = 0;
+    // what is in flight completes; what was published but never opened needs a launch to be consumed
+    bool pending = false;
+    for (long long t : st.lane_ticket)
+        if (t >= 0 && __atomic_load_n(&st.hHost->result[(unsigned long long)t % STREAM_RING].seq1, __ATOMIC_ACQUIRE) !=
+                          (unsigned long long)t + 1ull)
+            pending = true;
+    __atomic_store_n(&st.hHost->close, 1u, __ATOMIC_RELEASE);
+    if (pending && st.hHost->error == 0u) rc = stream_ensure_running(h);
+    if (hipStreamSynchronize(h->streams[0]) != hipSuccess) rc = rc ? rc : 1;
+    (void)stream_free(h);
+    return rc;
 }
 
 extern "C" int psoap_batch_fetch(psoap_chunk* h, double* out)

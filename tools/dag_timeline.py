@@ -25,6 +25,7 @@ with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
     log = np.zeros(ntask * 8, dtype=np.uint64)
     h._L.psoap_chunk_dag_tasklog(h._h, log.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), ntask)
 tasks["type"] &= 0x0F   # strip the chain flag
+waits = (log.reshape(ntask, 8)[:, 7] >> np.uint64(40)).astype(np.float64) / 100.0     # us in the updates' dependency waits
 log = log.reshape(ntask, 8).astype(np.float64) / 100.0   # us
 base = log[:, 0].min()
 log -= base
@@ -35,6 +36,7 @@ d01 = log[:, 1] - log[:, 0]; d12 = log[:, 2] - log[:, 1]; d23 = log[:, 3] - log[
 busy = (log[:, 3] - log[:, 0]).sum()
 print(f"N={ch.N} B={B} tasks={ntask} (PART {part.sum()}, DIAG {diag.sum()}, OFF {off.sum()}) span={span/1e3:.2f} ms  "
       f"sum(task time)={busy/1e3:.1f} ms  -> avg concurrency {busy/span:.1f}")
+print(f"measured dependency waits inside updates: {waits.sum()/1e3:.1f} ms ({100*waits.sum()/busy:.1f} % of all task time)")
 print(f"PART: total {(log[part,3]-log[part,0]).sum()/1e3:8.1f} ms")
 print(f"OFF : update+store {d01[off].sum()/1e3:8.1f} ms | wait potrf {d12[off].sum()/1e3:8.1f} ms | trsm+publish {d23[off].sum()/1e3:8.1f} ms")
 print(f"DIAG: update+store {d01[diag].sum()/1e3:8.1f} ms | potrf      {d12[diag].sum()/1e3:8.1f} ms | publish      {d23[diag].sum()/1e3:8.1f} ms")
