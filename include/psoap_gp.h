@@ -276,6 +276,11 @@ int psoap_stream_close(psoap_chunk *h);
  * scheme of the lanes' task list and its length; any pointer may be NULL */
 int psoap_stream_stats(psoap_chunk *h, long long *launches, long long *submitted, long long *completed, int *scheme,
                        long long *tasks_per_matrix);
+/* Pure host function (touches no device): the task list every lane of a stream of `lanes` lanes runs for matrices of
+ * P block rows on `workers` workgroups (record format of psoap_chunk_dag_tasks; the field `b` carries the burst marks:
+ * 0x8000 = the last ticket of a burst, i.e. of a block row).  scheme -1: automatic; *scheme_out the one taken. */
+int psoap_stream_plan(int P, int lanes, int workers, int scheme, void *out, long long max_tasks, long long *n_tasks,
+                      long long *n_slots, long long *n_ctrs, int *scheme_out);
 /* Debug aids: per-task time stamps of the last `cap` submissions (allocate with out == NULL before the first submit;
  * read with nothing in flight), and the task list every lane runs (record format of psoap_chunk_dag_tasks). */
 int psoap_stream_tasklog(psoap_chunk *h, int cap, unsigned long long *out, long long max_words);

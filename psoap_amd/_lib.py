@@ -93,6 +93,9 @@ SIGNATURES = {
     "psoap_stream_pause": (ctypes.c_int, [_vp]),
     "psoap_stream_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong),
                                           ctypes.POINTER(ctypes.c_longlong), _ip, ctypes.POINTER(ctypes.c_longlong)]),
+    "psoap_stream_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_longlong,
+                                         ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong),
+                                         ctypes.POINTER(ctypes.c_longlong), _ip]),
     "psoap_stream_tasklog": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.c_longlong]),
     "psoap_stream_tasks": (ctypes.c_int, [_vp, _vp, ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong)]),
     "psoap_chunk_set_profiling": (ctypes.c_int, [_vp, ctypes.c_int]),

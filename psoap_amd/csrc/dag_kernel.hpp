@@ -58,7 +58,9 @@ struct alignas(64) MatFlags {
     int off1_ready;   // q + 1 once tile (q, q+1) holds its fully updated value, ready for the strip solve
     int step_w[4];    // per wave of the fused diagonal task: 8 q + b + 1 once its share of step b of block q (the row
                       // of U11 and W_bb^T the strip solves need) is in the matrix's mailbox (dag_pss)
-    int pad[6];
+    int cnt3;         // scheme 0 (round 4): the counter of block rows q = 2 (mod 3) -- with tile-level dependencies DIAG(q)
+                      // runs as soon as tile (q-1, q) is final, up to three block rows are being counted at a time
+    int pad[5];
     int xcol[256][2]; // per column tile j, per publishing wave of the following strip solve of tile (q, j): 8 q + b + 1
                       // once its half of row block b of the solved tile is in memory -- the tasks of block row q+1 that
                       // read the tile (the diagonal task of block q+1, the strip solves of tiles (q+1, .)) follow it in turn
@@ -75,7 +77,8 @@ static_assert(sizeof(MatFlags) == 64 + 2048 + 1024, "one cache line of row state
 //   column).   Blocks in the accumulator-linear form.
 using ps::MB_BLOCKS;
 constexpr size_t MB_DOUBLES = (size_t)2 * 8 * MB_BLOCKS * 256;
-constexpr size_t WT_STRIDE = (size_t)2 * NB * NB + MB_DOUBLES;     // doubles per matrix: two Wt tiles + the mailbox
+constexpr size_t WT_THIRD = (size_t)2 * NB * NB + MB_DOUBLES;      // scheme 0: a third Wt tile, behind the mailbox (block q in tile q mod 3)
+constexpr size_t WT_STRIDE = WT_THIRD + (size_t)NB * NB;           // doubles per matrix: two Wt tiles + the mailbox + the third tile
 __host__ __device__ inline size_t mb_slot(int q, int b, int J) { return ((size_t)((q & 1) * 8 + b) * MB_BLOCKS + J) * 256; }
 
 constexpr int DAG_QUEUES = 8;   // one ticket queue per XCD (MI355X: 8 XCDs, each with its own 4 MiB L2)
@@ -208,9 +211,11 @@ __device__ __forceinline__ void dag_release_fence()
 }
 
 // a task of block row q of this matrix is complete (thread 0, after dag_release_fence)
+// (M3: three counters in turn -- scheme 0, whose diagonal tasks run up to two block rows ahead of the strip solves)
+template <bool M3 = false>
 __device__ __forceinline__ void dag_task_done(MatFlags* f, int q, int ntasks_row, int n = 1)
 {
-    int* cnt = &f->cnt[q & 1];
+    int* cnt = M3 ? (q % 3 == 2 ? &f->cnt3 : &f->cnt[q % 3]) : &f->cnt[q & 1];
     const int old = __hip_atomic_fetch_add(cnt, n, PSOAP_RLX_AGENT);
     if (old + n == ntasks_row) {
         // last finisher of the row: order after every other task's release, then publish the row
@@ -969,7 +974,8 @@ struct alignas(64) StreamLane {
     unsigned int next;              // next ticket of the matrix in this lane; >= n_tasks: nothing to hand out
     unsigned int pad0;
     unsigned long long seq;         // submission number of that matrix
-    unsigned int pad[12];
+    unsigned long long stamp;       // when the lane's last burst was handed out (s_memrealtime; 0: none yet)
+    unsigned int pad[10];
 };
 constexpr unsigned short STREAM_BURST_END = 0x8000;   // DagTask::b of a lane's task list (the matrix index is the lane):
                                                       // the last ticket of a burst -- the next one starts a block row
@@ -1022,8 +1028,8 @@ struct StreamArgs {                 // kernel argument, by value
     const double* fl;               // the chunk's flux vector (device)
     unsigned int n_lanes, n_tasks, ctrs_per_lane, slots_per_lane;
     int C, N;
-    unsigned int gate;              // 1: a lane whose next block row is not ready yet is passed over (scheme 0: tile-level
-                                    // dependencies; stream_next_lane)
+    unsigned int gate;              // scheme 0: 100 MHz ticks that have to lie between two bursts (block rows) of one lane
+                                    // (stream_next_lane); 0: the lanes of an XCD strictly in turn
     unsigned int pad1;
     unsigned long long idle_ticks;  // 100 MHz ticks without anything in flight after which the launch ends
     unsigned int tlog_cap;          // submissions the task log holds (ring)
@@ -1144,16 +1150,19 @@ __device__ __forceinline__ void stream_take(const StreamArgs& st, int home, DagC
 }
 
 // The ticket just taken from `lane` ended a burst (thread 0): the XCD's workgroups draw from its next lane now -- the next
-// one in turn whose coming block row is READY: its diagonal task (the burst's first ticket) finds the tile above the
-// diagonal final (MatFlags::rvrow, tile-level dependencies) and the row two above complete.  Tickets are handed out in
-// order and cannot be given back: a burst handed out early commits some forty workgroups to tasks that wait for the row
-// above (measured before: 5.5 % of all worker time in such waits, a third of it in diagonal tasks) while the other
-// lanes' rows become ready and find nobody.  When no lane of the XCD is ready the turn decides, as before.  (A lane
-// without tickets is skipped by whoever finds it so: stream_take.)
-__device__ __forceinline__ void stream_next_lane(const StreamArgs& st, int lane, const DagTask* __restrict__ tasks, MatFlags* flags)
+// one in turn whose previous burst lies at least `gate` ticks back.  Tickets are handed out in order and cannot be given
+// back.  A strip solve needs the row above only for the LAST panel of its update and potrf of its own row at the end, so
+// a block row may be handed out long before the row above is through -- but not right behind it: then its tasks reach
+// their last panel before the tiles above them are final and some forty workgroups wait (measured with the lanes strictly
+// in turn: 5.5 % of all worker time in such waits whenever half the lanes were between two matrices).  About 250 us of
+// spacing is what the tail of a task (last panel, covariance, potrf, strip solve) takes.  When no lane of the XCD is
+// that far, the turn decides.  (A lane without tickets is skipped by whoever finds it so: stream_take.)
+__device__ __forceinline__ void stream_next_lane(const StreamArgs& st, int lane)
 {
     const int nl = (int)st.n_lanes;
     const int per = (nl + 7 - (lane & 7)) / 8;            // lanes of this XCD
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    __hip_atomic_store(&st.lanes[lane].stamp, now, PSOAP_RLX_AGENT);
     int fallback = -1, pick = -1;
     int cand = lane;
     for (int k = 0; k < per; ++k) {
@@ -1162,16 +1171,10 @@ __device__ __forceinline__ void stream_next_lane(const StreamArgs& st, int lane,
             pick = cand;
             break;
         }
-        const unsigned int t = __hip_atomic_fetch_add(&st.lanes[cand].next, 0u, PSOAP_RLX_AGENT);
-        if (t >= st.n_tasks) continue;                    // nothing to hand out there
+        if (__hip_atomic_fetch_add(&st.lanes[cand].next, 0u, PSOAP_RLX_AGENT) >= st.n_tasks) continue;   // nothing to hand out
         if (fallback < 0) fallback = cand;
-        const int q = tasks[t].q;
-        bool ready = true;
-        if ((tasks[t].type & DAG_TYPE_MASK) == DAG_DIAG && q >= 1) {
-            MatFlags* f = flags + cand;
-            ready = dag_peek(&f->rvrow[q]) >= q && (q < 2 || dag_peek(&f->rows_done) >= q - 1);
-        }
-        if (ready) {
+        const unsigned long long last = cand == lane ? now : __hip_atomic_load(&st.lanes[cand].stamp, PSOAP_RLX_AGENT);
+        if (now - last >= (unsigned long long)st.gate) {
             pick = cand;
             break;
         }
@@ -1278,6 +1281,7 @@ __device__ __forceinline__ void stream_dispatch(const StreamArgs& st, const DagM
                 for (unsigned int k = 0; k < nb; ++k) {
                     const int lane = __hip_atomic_load(&st.host->entry[(opened + k) % STREAM_RING].lane, PSOAP_RLX_SYSTEM);
                     __hip_atomic_store(&st.lanes[lane].seq, opened + k, PSOAP_RLX_AGENT);
+                    __hip_atomic_store(&st.lanes[lane].stamp, 0ull, PSOAP_RLX_AGENT);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 for (unsigned int k = 0; k < nb; ++k) {
@@ -1359,11 +1363,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
     const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     unsigned int dry = 0;                       // bit g: queue g is exhausted (wave-uniform)
     int probe = 0;
+    // Scheme 0 (round 4): the strip solve of tile (q, q+1) CONTINUES into the diagonal task of block q+1 (DAG_FUSED on that
+    // OFF final; the DIAG record is the next entry of the list, flagged DAG_NOSOLVE = "owned": whoever draws its ticket
+    // skips it).  The tile above the diagonal is all DIAG(q+1) waits for, so it starts the moment it can, never holds a
+    // workgroup waiting (257 us per diagonal task before, 1.9 % of all worker time of a streamed run) and potrf(q+1) is
+    // out long before the strip solves of row q+1 ask for it.
+    constexpr bool CONT = !LAT && DAG_TILE_DEPS;
+    bool cont = false;
+    unsigned int ticket = 0;
+    int b = 0;
     for (;;) {
         Tile t;
-        unsigned int ticket;
-        int b;
-        if constexpr (STREAM) {
+        const bool owned_run = CONT && cont;
+        cont = false;
+        if (owned_run) {
+            ticket += 1u;           // the record behind the strip solve just finished: its diagonal task (same matrix)
+        } else if constexpr (STREAM) {
             stream_take(st, home, ctl, &s_ticket, &s_lane);
             ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)s_ticket);
             b = __builtin_amdgcn_readfirstlane(s_lane);
@@ -1396,7 +1411,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         const DagTask task = tasks[ticket];
         if constexpr (!STREAM) b = task.b;
         if constexpr (STREAM) {
-            if ((task.b & STREAM_BURST_END) && threadIdx.x == 0) stream_next_lane(st, b, tasks, flags);
+            // (the burst ends with the TICKET, whoever runs the task)
+            if (!owned_run && (task.b & STREAM_BURST_END) && threadIdx.x == 0) stream_next_lane(st, b);
+        }
+        if constexpr (CONT) {
+            if (!owned_run && (task.type & DAG_TYPE_MASK) == DAG_DIAG && (task.type & DAG_NOSOLVE)) continue;   // owned
         }
         const int q = task.q, j = task.j;
         const DagMat mat = mats[b];
@@ -1412,7 +1431,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         }
         double* Km = mat.K;
         double* Rv = mat.R;
-        double* Wm = mat.Wt + (size_t)(q & 1) * NB * NB;
+        // (scheme 0: three Wt tiles in turn, the third one behind the mailbox)
+        double* Wm = CONT ? (q % 3 == 2 ? mat.Wt + WT_THIRD : mat.Wt + (size_t)(q % 3) * NB * NB)
+                          : mat.Wt + (size_t)(q & 1) * NB * NB;
         const int ld = mat.ld, N = mat.N, Npad = mat.Npad;
         MatFlags* f = flags + b;
         const int k0 = q * NB, j0 = j * NB;
@@ -1537,10 +1558,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
             // the diagonal task is the row-to-row critical path: let its waves win the issue arbitration
             // against the co-resident workgroup (N = 2000, B = 32: -4 % with the deferred W output)
             __builtin_amdgcn_s_setprio(3);
-            // (tile-level dependencies: block q - 2's strip solves read the W buffer this factorisation writes, and the row
-            // counters alternate by parity -- all of row q - 2 has to be through; it has been for a whole row's time)
+            // (tile-level dependencies: block q - 3's strip solves read the W tile this factorisation writes, and the row
+            // counters take turns likewise -- all of row q - 3 has to be through; it has been for two rows' time)
             // (no branch around the poll: rows_done >= 0 always holds)
-            if constexpr (!LAT && DAG_TILE_DEPS) dag_wait_ge(&f->rows_done, q >= 2 ? q - 1 : 0, ctl, 9u);
+            if constexpr (CONT) dag_wait_ge(&f->rows_done, q >= 3 ? q - 2 : 0, ctl, 9u);
             potrf_blocked(Km, ld, k0, Wm, Rv, mat.acc);
             dag_drain();
             if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 2] = __builtin_amdgcn_s_memrealtime();
@@ -1561,7 +1582,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
                     dag_task_done(f, q, ntasks_row, 2);
                 }
             } else if (threadIdx.x == 0) {
-                dag_task_done(f, q, ntasks_row);
+                dag_task_done<CONT>(f, q, ntasks_row);
                 if constexpr (STREAM) {
                     if (q == mat.P - 1) stream_complete(st, b, mat.acc);
                 }
@@ -1579,10 +1600,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
             dag_drain();
             if (threadIdx.x == 0) {
                 dag_release_fence();
+                // (counted BEFORE the tile is announced: whatever reads the tile belongs to a later row, so a row is
+                // complete -- rows_done -- in row order)
+                dag_task_done<CONT>(f, q, ntasks_row);
                 // tile (q, j) is final and its share of the right-hand side block j applied
-                if constexpr (!LAT && DAG_TILE_DEPS) __hip_atomic_store(&f->rvrow[j], q + 1, PSOAP_RLX_AGENT);
-                dag_task_done(f, q, ntasks_row);
+                if constexpr (CONT) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(&f->rvrow[j], q + 1, PSOAP_RLX_AGENT);
+                }
             }
+            if constexpr (CONT) cont = (task.type & DAG_FUSED) != 0;
         }
         if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
     }
@@ -1770,6 +1797,12 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
         uniform = uniform && Ps[b] == Ps[mats[0]];
     }
     std::vector<std::vector<DagTask>> early_final(P);   // DIAG finals whose PARTs were emitted a row early
+    // scheme 0 (round 4): the final of DIAG(q+1) sits right BEHIND the final of tile (q, q+1) and is run by the workgroup
+    // that ran that one (DAG_FUSED on the OFF final: "continue with the next record"; DAG_NOSOLVE on the DIAG final:
+    // "owned", skipped by whoever draws its ticket) -- see k_chol_dag
+    const bool cont0 = (scheme == 0) && DAG_TILE_DEPS;
+    std::vector<DagTask> owned_final(Ps.size());          // per matrix: the DIAG(q+1) final to emit behind tile (q, q+1)
+    std::vector<char> has_owned(Ps.size(), 0);
     for (int q = 0; q < P; ++q) {
         // tiles of this block row in the queue; uniform batches use the nominal matrix count so that the
         // split factors do not depend on the slot a matrix sits in
@@ -1833,9 +1866,15 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
             }
         } else if (q <= 1) {
             for (int b : mats)
-                if (q < Ps[b])
+                if (q < Ps[b]) {
+                    if (cont0 && q == 1) {
+                        // DIAG(1): one final over [0, 1), emitted behind tile (0, 1) -- row 0 has come by already: here
+                        // only for a matrix whose row 0 had no such tile (never: q < Ps[b] means P >= 2)
+                        continue;
+                    }
                     dag_emit(plan, DAG_DIAG, b, q, q, 0, q, 1, scheme,
                              (unsigned char)((fused(b) ? DAG_FUSED : 0) | (scheme >= 1 && q == 1 ? DAG_WAITNEXT : 0)));
+                }
         } else {
             for (const DagTask& t : early_final[q]) plan.tasks.push_back(t);
         }
@@ -1896,17 +1935,33 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
                 fin.pb = (unsigned char)(q + 1);
                 fin.slot = chain ? slot0 + (unsigned int)((n_parts - 1) & 1) : slot0;
                 fin.ctr = ctr;
-                early_final[q + 1].push_back(fin);
+                if (cont0) {
+                    fin.type |= DAG_NOSOLVE;          // owned by the strip solve of tile (q, q+1): step 3
+                    owned_final[b] = fin;
+                    has_owned[b] = 1;
+                } else {
+                    early_final[q + 1].push_back(fin);
+                }
             }
         }
         // 3. off-diagonal tiles of this row
         for (int b : mats)
-            for (int j = q + 1; j < Ps[b] + Mt && q < Ps[b]; ++j)
+            for (int j = q + 1; j < Ps[b] + Mt && q < Ps[b]; ++j) {
+                const bool owner = cont0 && j == q + 1 && q + 1 < Ps[b];     // its workgroup goes on with DIAG(q+1)
                 dag_emit(plan, DAG_OFF, b, q, j, 0, q, S_off, scheme,
                          following ? (unsigned char)(DAG_WAITNEXT | (xlink(q) ? DAG_FUSED : 0) |
                                                      ((j == q + 1 && q + 1 < Ps[b]) ? DAG_NOSOLVE : 0))
-                                   : (unsigned char)((j == q + 1 && fused(b)) ? DAG_NOSOLVE : 0),
+                                   : (unsigned char)(((j == q + 1 && fused(b)) ? DAG_NOSOLVE : 0) | (owner ? DAG_FUSED : 0)),
                          following ? dag_final_panels() : 1);
+                if (owner) {
+                    if (q == 0) {
+                        dag_emit(plan, DAG_DIAG, b, 1, 1, 0, 1, 1, scheme, DAG_NOSOLVE);   // DIAG(1): one final over [0, 1)
+                    } else {
+                        plan.tasks.push_back(owned_final[b]);
+                        has_owned[b] = 0;
+                    }
+                }
+            }
     }
     if (Ms > 0)
         for (int b : mats) dag_emit_schur(plan, b, Ps[b], Ms);
@@ -2070,6 +2125,29 @@ inline double dag_batch_flops(const std::vector<int>& Ps, int Mt = 0)
         f += n * n * n / 3.0 + n * n * r;
     }
     return f;
+}
+
+// The task list every lane of a stream runs (one matrix), cut as if `lanes` matrices shared `workers` workgroups, with its
+// bursts marked (DagTask::b, which the lanes do not need: the matrix index is the lane).  A burst is what the workgroups of
+// an XCD draw from one lane before they move on to the next: one block row -- scheme 0: the tasks emitted for row q (the
+// PARTs that pre-accumulate DIAG(q+1), the row's strip solves with their PARTs, the owned DIAG(q+1)); schemes 1, 2:
+// whatever precedes a diagonal final.  bursts == false: every ticket ends one (the lanes ticket by ticket in turn).
+inline DagPlan dag_build_lane_plan(int P, int lanes, int workers, int scheme, bool bursts = true)
+{
+    const int share = workers / lanes > 0 ? workers / lanes : 1;
+    DagPlan plan = dag_build_tasks(std::vector<int>(1, P), share, scheme);
+    const bool rows = plan.scheme == 0 && DAG_TILE_DEPS;
+    auto section = [](const DagTask& t) { return (t.q == t.j && t.q > 0) ? (int)t.q - 1 : (int)t.q; };
+    for (size_t i = 0; i < plan.tasks.size(); ++i) {
+        const bool last = i + 1 == plan.tasks.size();
+        bool end = !bursts || last;
+        if (!end) {
+            const DagTask& nx = plan.tasks[i + 1];
+            end = rows ? section(nx) != section(plan.tasks[i]) : (nx.type & DAG_TYPE_MASK) == DAG_DIAG;
+        }
+        plan.tasks[i].b = (unsigned short)(end ? STREAM_BURST_END : 0);
+    }
+    return plan;
 }
 
 // uniform batch: B matrices of P block rows each

@@ -490,6 +490,7 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         PR_TRY(hipMemcpyAsync(ws.Colx, h_colx, sizeof(double) * (size_t)c * Rq_pad, hipMemcpyHostToDevice, st));
         PR_TRY(hipMemsetAsync(ws.Dag, 0, dag_bytes, st));
         PR_TRY(hipMemsetAsync(dW, 0, sizeof(double) * 2 * NB * NB, st));  // the strictly upper part of W stays zero
+        PR_TRY(hipMemsetAsync(dW + WT_THIRD, 0, sizeof(double) * NB * NB, st));   // (scheme 0's third tile)
         hipLaunchKernelGGL(k_init_rhs, dim3((Npad + 255) / 256, 1), dim3(256), 0, st, dR, Npad, N, dFl, offset, dAcc);
         const int grid = (int)(plan.tasks.size() < (size_t)workers ? plan.tasks.size() : (size_t)workers);
         DagAug aug{P + Mt, Rq, Rq_pad, ws.Colx, nullptr, nullptr, nullptr, 0};

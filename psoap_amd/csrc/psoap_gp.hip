@@ -421,6 +421,26 @@ extern "C" int psoap_dag_plan(int B, int P, int workers, void* out, long long ma
     return 0;
 }
 
+// Pure host function: the task list every lane of a stream of `lanes` lanes runs for matrices of P block rows
+// (dag_build_lane_plan); DagTask::b carries the burst marks (0x8000: the last ticket of a burst).
+extern "C" int psoap_stream_plan(int P, int lanes, int workers, int scheme, void* out, long long max_tasks,
+                                 long long* n_tasks, long long* n_slots, long long* n_ctrs, int* scheme_out)
+{
+    if (P < 1 || P > 255 || lanes < 1 || lanes > STREAM_MAX_LANES || workers < 1 || scheme < -1 || scheme > 2 || !n_tasks)
+        FAIL("psoap_stream_plan: bad arguments");
+    if (scheme < 0) scheme = dag_auto_scheme(std::vector<int>((size_t)lanes, P));
+    DagPlan plan = dag_build_lane_plan(P, lanes, workers, scheme);
+    *n_tasks = (long long)plan.tasks.size();
+    if (n_slots) *n_slots = plan.n_slots;
+    if (n_ctrs) *n_ctrs = plan.n_ctrs;
+    if (scheme_out) *scheme_out = plan.scheme;
+    if (out) {
+        const long long n = max_tasks < *n_tasks ? max_tasks : *n_tasks;
+        memcpy(out, plan.tasks.data(), sizeof(DagTask) * n);
+    }
+    return 0;
+}
+
 // One matrix with Mt appended column tiles (predict) and, when Ms > 0, the Ms x Ms tiles of their Schur complement as
 // tasks of the same launch (DAG_SCHUR).  scheme: -1 automatic, 0 throughput, 1 latency.
 extern "C" int psoap_dag_plan_aug(int P, int Mt, int Ms, int workers, int scheme, void* out, long long max_tasks,
@@ -1160,8 +1180,10 @@ static int stream_launch(psoap_chunk* h)
     a.N = h->N;
     a.idle_ticks = (unsigned long long)(st.idle_ms * 1e5);      // s_memrealtime: 100 MHz
     {
-        const char* e = getenv("PSOAP_STREAM_GATE");            // experiments; 0: lanes strictly in turn
-        a.gate = (st.scheme == 0 && DAG_TILE_DEPS && !(e && e[0] == '0')) ? 1u : 0u;
+        // ticks (10 ns) between two block rows of one lane; PSOAP_STREAM_GATE_US overrides (0: lanes strictly in turn)
+        const char* e = getenv("PSOAP_STREAM_GATE_US");
+        const double us = e ? atof(e) : 250.0;
+        a.gate = (st.scheme == 0 && DAG_TILE_DEPS && us > 0.0) ? (unsigned int)(us * 100.0) : 0u;
     }
     a.tlog_cap = st.tlog_cap;
     MatFlags* fl_ = reinterpret_cast<MatFlags*>(st.dDag + sizeof(DagCtl));
@@ -1220,19 +1242,9 @@ static int stream_open_impl(psoap_chunk* h, int c, int lanes, int scheme)
         scheme = e ? atoi(e) : dag_auto_scheme(all);
     }
     // every lane runs the task list of ONE matrix, cut as if `lanes` matrices shared the workers (one workgroup dispatches)
-    const int share = (h->dag_grid - 1) / lanes > 0 ? (h->dag_grid - 1) / lanes : 1;
-    DagPlan plan = dag_build_tasks(std::vector<int>(1, h->P), share, scheme);
-    // bursts: the lanes of an XCD are served one block row at a time, the row's diagonal task first -- a burst ends with
-    // the ticket in front of a diagonal final (PSOAP_STREAM_BURSTS=0: ticket by ticket in turn, experiments)
-    {
-        const char* e = getenv("PSOAP_STREAM_BURSTS");
-        const bool bursts = !(e && e[0] == '0');
-        for (size_t i = 0; i < plan.tasks.size(); ++i) {
-            const bool last = i + 1 == plan.tasks.size();
-            const bool next_diag = !last && (plan.tasks[i + 1].type & DAG_TYPE_MASK) == DAG_DIAG;
-            plan.tasks[i].b = (unsigned short)((!bursts || last || next_diag) ? STREAM_BURST_END : 0);
-        }
-    }
+    // (PSOAP_STREAM_BURSTS=0: the lanes ticket by ticket in turn instead of a block row at a time -- experiments)
+    const char* eb = getenv("PSOAP_STREAM_BURSTS");
+    DagPlan plan = dag_build_lane_plan(h->P, lanes, h->dag_grid - 1, scheme, !(eb && eb[0] == '0'));
     st.scheme = plan.scheme;
     st.queues = plan.queues;
     st.n_tasks = (unsigned int)plan.tasks.size();

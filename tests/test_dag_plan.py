@@ -132,13 +132,30 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
                 assert solver < t and (flags[solver] & NOSOLVE) and (flags[solver] & WAITNEXT) and not flags[prev] & FUSED
             else:
                 assert prev < t and flags[prev] & FUSED
-        for m in range(int(k["pb"]) - (1 if wait_next else 0)):
-            assert row_final_last_ticket[(b, m)] < t
+        if want_chain:
+            for m in range(int(k["pb"]) - (1 if wait_next else 0)):
+                assert row_final_last_ticket[(b, m)] < t
+        else:
+            # scheme 0 (round 4), tile-level dependencies: an update over [pa, pb) reads the tiles (m, q) and (m, j), m < pb,
+            # whose finals are earlier; an OWNED diagonal final (NOSOLVE) sits right behind the final of the tile above
+            # its diagonal (FUSED) and is run by that task's workgroup; before it writes its W tile (three in turn), block
+            # row q - 3 is through
+            for m in range(int(k["pb"])):
+                assert finals[(b, m, q)] < t and finals[(b, m, j)] < t
+            if k["type"] == DIAG and q >= 1:
+                assert flags[t] & NOSOLVE and not flags[t] & (WAITNEXT | FUSED)
+                assert finals[(b, q - 1, q)] == t - 1 and flags[t - 1] & FUSED and int(k["pb"]) == q
+                for m in range(q - 2):
+                    assert row_final_last_ticket[(b, m)] < t
+            elif k["type"] == DIAG:
+                assert not flags[t] & (NOSOLVE | WAITNEXT | FUSED)
+            if flags[t] & FUSED:
+                assert k["type"] == OFF and j == q + 1 and q + 1 < Ps[b] and diag_final_ticket[(b, q + 1)] == t + 1
         # the second level of the following scheme: the strip solve of tile (q, q+1), q >= 2, delivers its tile row block
         # by row block (FUSED on a following OFF final) to the diagonal task of block q+1 (NOSOLVE on a DIAG final), which
         # must be one the out-of-line fast path takes: chained, a one-panel final with a running sum to start from
         xpub = follows and bool(flags[t] & FUSED)
-        xdiag = k["type"] == DIAG and bool(flags[t] & NOSOLVE)
+        xdiag = want_chain and k["type"] == DIAG and bool(flags[t] & NOSOLVE)
         assert xpub == follows           # every following strip solve delivers its tile progressively
         if xpub and j == q + 1 and q + 1 < Ps[b]:
             nxt = diag_final_ticket[(b, q + 1)]
@@ -147,12 +164,12 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
             assert following and q >= 1 and wait_next and chain[t] and k["S"] >= 2
             src = finals[(b, q - 1, q)]
             assert src < t and flags[src] & FUSED and flags[src] & WAITNEXT
-        if flags[t] & FUSED and not xpub:
+        if flags[t] & FUSED and not xpub and want_chain:
             # DIAG(q) also solves tile (q, q+1): its update-only task comes earlier in the list
             assert k["type"] == DIAG and q + 1 < Ps[b]
             upd = finals[(b, q, q + 1)]
             assert upd < t and flags[upd] & NOSOLVE
-        if flags[t] & NOSOLVE and not xdiag:
+        if flags[t] & NOSOLVE and not xdiag and want_chain:
             assert k["type"] == OFF and j == q + 1
             assert bool(flags[diag_final_ticket[(b, q)]] & FUSED) == (not follows)
         if following and k["type"] == DIAG:
@@ -162,7 +179,7 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
         elif want_chain and k["type"] == DIAG:
             assert bool(flags[t] & FUSED) == (q + 1 < Ps[b]) and wait_next == (q >= 1)
         if not want_chain:
-            assert not flags[t] & (NOSOLVE | WAITNEXT | FUSED)
+            assert not flags[t] & WAITNEXT
         if k["type"] != PART:
             if k["S"] > 1:
                 parts = part_done_ticket[int(k["ctr"])]
@@ -188,7 +205,7 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
                     assert got == list(range(got[0], got[0] + len(parts)))                 # consecutive slots
                     assert int(k["slot"]) == got[0]
             if k["type"] == OFF and not flags[t] & NOSOLVE:
-                assert diag_final_ticket[(b, q)] < t
+                assert diag_final_ticket[(b, q)] < t       # potrf(q): a smaller ticket (scheme 0: the record behind tile (q-1, q))
 
 
 def test_sparse_rows_are_split_and_diagonal_is_preaccumulated():
