@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
 """Headline benchmark: GP lnprob evaluations per second, SB2 chunk at N = 6000.
 
-One "step" = one ensemble step of the hot path on every rank: the proposals of the NEXT step
-(32 walkers x 2 components x 6000 ln-wavelengths = 3 MB) are copied from host memory to the GPU
-while the rank's SB2 chunk (20 epochs x 300 px, N = 6000; BASELINE.json configs[2]/[3]) is
-evaluated for the current 32 walkers (fill -> +sigma^2 -> Cholesky -> solve -> logdet -> lnprob),
-the 32 lnprobs come back to the host, and the per-(walker, chunk) lnprobs are gathered over RCCL
-and summed in fixed chunk order (the gather-and-sum of psoap/sample_parallel.py:378-387).
-So `value` INCLUDES the per-step H2D of c*N doubles per proposal and the D2H of the results
-(BASELINE.md section 4); the proposals-resident rate is reported beside it.
+One "step" = one ensemble step of the hot path on every rank: the rank's SB2 chunk (20 epochs x 300 px,
+N = 6000; BASELINE.json configs[2]/[3]) is evaluated for 32 walkers (fill -> +sigma^2 -> Cholesky -> solve ->
+logdet -> lnprob), the proposals (32 walkers x 2 components x 6000 ln-wavelengths = 3 MB) come from host
+memory over PCIe and the 32 lnprobs go back to it, and the per-(walker, chunk) lnprobs are gathered over
+RCCL and summed in fixed chunk order (the gather-and-sum of psoap/sample_parallel.py:378-387).
+So `value` INCLUDES the per-step H2D of c*N doubles per proposal and the D2H of the results (BASELINE.md
+section 4).
+
+Round 4, default `--mode stream`: the K timed steps run through ONE resident launch of the persistent kernel
+(psoap_stream_*: include/psoap_gp.h), the ensemble as two half-ensembles in flight -- the proposals of a half
+depend on that half's previous results only, as in a red / black ensemble move or with independent chains, so a
+half is fetched and its successor submitted while the other half keeps the device busy (the back-to-back
+iterations of psoap/sample_parallel.py:434-438).  The timed region starts with nothing in flight and no launch
+resident, and ends when the last result is back and the launch has left.  `--mode dag` is rounds 1-3's path,
+one launch of the kernel per step (next step's proposals uploaded under it); its rate is reported beside the
+headline in the same run (`launch_per_step`).
 Chunks are independent, so per-GPU work is fixed as N grows ("weak"); at 8 GPUs a step is exactly
 the 32-walker x 8-chunk ensemble of configs[3].  The same run also times configs[3] AS NAMED -- the fixed
 8-chunk x 32-walker ensemble, chunk k on rank k mod G, 256 evaluations per step at every G -- and reports
@@ -218,7 +226,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--walkers", type=int, default=N_WALKERS)
     ap.add_argument("--groups", type=int, default=2, help="concurrent stream groups per batch (staged mode)")
-    ap.add_argument("--mode", default="dag", choices=["dag", "staged"], help="execution mode of the batch eval")
+    ap.add_argument("--mode", default="stream", choices=["stream", "dag", "staged"],
+                    help="stream: the timed steps through ONE resident launch (two half-ensembles in flight); dag / staged: "
+                         "one launch (three per panel) per step")
+    ap.add_argument("--stream-groups", type=int, default=2, help="sub-ensembles in flight in --mode stream")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="print `value` even if the library was built from the fallback flag rung (psoap_amd/build.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-strong", action="store_true", help="skip the configs[3] strong-scaling leg (cfg4_strong)")
     ap.add_argument("--no-extras", action="store_true",
@@ -250,8 +263,15 @@ def main():
         else:
             dist.init_process_group(backend="gloo")
 
-    from psoap_amd.chunk import ChunkHandle, microbench
+    from psoap_amd import build as _build
+    from psoap_amd.chunk import ChunkHandle, StreamPipeline, microbench
     from psoap_amd.ensemble import gather_chunk_lnprobs, sum_over_chunks
+
+    # which binary runs: its hash, what it was built from and by, and the rung of the build's flag ladder
+    library = _build.provenance()
+    if library.get("fallback_rung") not in (0, None) and not args.allow_fallback:
+        raise SystemExit(f"bench.py: libpsoap_gp.so was built from fallback rung {library['fallback_rung']} of the flag ladder "
+                         "(no following scheme, 3.3-3.4 ms single evaluations); pass --allow-fallback to measure it anyway")
 
     # ---- workload.  One GPU: the configs[2] chunk (seed 3000).  N GPUs: rank r owns chunk r of the
     # configs[3] ensemble (seeds 4000 + r); walkers identical on every rank by seeding.
@@ -267,10 +287,15 @@ def main():
 
     h = ChunkHandle(chunk.fl, chunk.sigma, max_batch=B, device=local_rank)
     h.set_stream_groups(args.groups)
-    h.set_mode(args.mode)
+    batch_mode = "dag" if args.mode == "stream" else args.mode
+    h.set_mode(batch_mode)
+
+    collectives = {"n": 0}
 
     def gather(lnp):
         table = gather_chunk_lnprobs(lnp[None, :], world, world, rank, local_rank)   # (n_chunks, B)
+        if world > 1:
+            collectives["n"] += 1
         return table, sum_over_chunks(table)
 
     state = {"k": 0}
@@ -291,16 +316,50 @@ def main():
         fence_nohandle()
         h.sync()
 
-    h.upload(*sets[0])
-    for _ in range(args.warmup):
-        table, total = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        table, total = step()
-    fence()
-    dt = time.perf_counter() - t0
-    last_set = (state["k"] - 1) & 1          # the proposal set of the last evaluated step
+    def run_launch_per_step(n_warm, n_steps):
+        """rounds 1-3: one launch per step, the next step's proposals uploaded under it"""
+        state["k"] = 0
+        h.upload(*sets[0])
+        for _ in range(n_warm):
+            table, total = step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            table, total = step()
+        fence()
+        return time.perf_counter() - t0, table, total, (state["k"] - 1) & 1
+
+    stream_info = None
+    if args.mode == "stream":
+        if B % args.stream_groups:
+            raise SystemExit("--walkers must be a multiple of --stream-groups")
+        pipe = StreamPipeline(h, c, B, args.stream_groups)
+
+        def run_stream(n_steps):
+            """n_steps ensemble steps through one resident launch; from nothing in flight to nothing in flight"""
+            pipe.start(*sets[0])
+            lnp = None
+            for k in range(1, n_steps):
+                lnp = pipe.step(*sets[k & 1])          # results of step k - 1, proposals of step k submitted
+                table, total = gather(lnp)
+            lnp = pipe.drain()
+            table, total = gather(lnp)
+            h.stream_pause()                           # the resident launch leaves: the device is free again
+            return table, total, (n_steps - 1) & 1
+
+        pipe.calibrate(*sets[0])                       # a few steps: the period the start-up stagger is set from
+        h.stream_pause()
+        if args.warmup > 0:
+            run_stream(args.warmup)
+        fence_nohandle()
+        t0 = time.perf_counter()
+        table, total, last_set = run_stream(args.steps)
+        fence_nohandle()
+        dt = time.perf_counter() - t0
+        stream_info = dict(h.stream_last_launch(), **h.stream_stats())
+        pipe.close()
+    else:
+        dt, table, total, last_set = run_launch_per_step(args.warmup, args.steps)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -328,6 +387,22 @@ def main():
                 f"gathered (chunk, walker) table differs from the reference goldens: {table[:nk, :nw]} vs {gf[:nk, :nw]}")
         parity["golden_cfg4_table"] = [nk, nw]
 
+    # ---- the launch-per-step path beside the streamed headline (same run, same box; never `value` in stream mode)
+    per_step = None
+    if args.mode == "stream":
+        dps, tps, totps, lsps = run_launch_per_step(min(args.warmup, 2), args.steps)
+        if world > 1:
+            tmax = torch.tensor([dps], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dps = float(tmax.item())
+        if lsps == 1:
+            totps = np.roll(totps, -1)
+        # the same proposals through both paths: equal to the parity tolerance (the stream's task list is that of one
+        # matrix, the batch's that of 32 in lock-step: another order of summation)
+        require(close(totps, total), "launch-per-step path vs streamed path on the same proposals")
+        per_step = {"evals_per_s": evals / dps, "ms_per_step": 1e3 * dps / args.steps,
+                    "what": "rounds 1-3: one launch of the persistent kernel per step, next step's proposals uploaded under it"}
+
     # ---- proposals-resident rate (the round-1 headline; never `value`): eval + fetch + gather only
     h.upload(*sets[0])
     h.eval(); h.fetch()
@@ -351,7 +426,17 @@ def main():
     tm = h.timings()
     h.set_profiling(False)
     mode = "dag" if tm["dag"]["launches"] > 0 else "staged"
-    if mode == "dag":
+    if args.mode == "stream":
+        # the dominant kernel is the RESIDENT launch of the timed region: HIP events around it on its stream
+        # (psoap_stream_last_launch), algorithmic flops = the matrices it completed x F(N)
+        mode = "stream"
+        dom = {"ms": stream_info["ms"], "launches": 1, "flops": float("nan")}
+        dom_name = ("k_chol_dag<%d, false, false, stream> (ONE resident launch over the %d timed steps: persistent tile DAG, "
+                    "v_mfma_f64_16x16x4_f64)" % (c, args.steps))
+        alg_per_launch = stream_info["matrices"] * flops_eval(N)
+        require(stream_info["matrices"] == B * args.steps and stream_info["launches"] >= 1,
+                f"the timed region's resident launch completed {stream_info['matrices']} matrices, expected {B * args.steps}")
+    elif mode == "dag":
         # one persistent launch does the whole factorisation + solve of the batch:
         # algorithmic flops per launch = B x F(N)  
         dom, dom_name = tm["dag"], "k_chol_dag (persistent tile DAG, v_mfma_f64_16x16x4_f64)"
@@ -372,7 +457,7 @@ def main():
     out = None
     extras = {}
     if world == 1 and not args.no_extras:
-        extras = run_extras(args, h, chunk, gps, lwls_a, local_rank, mode)
+        extras = run_extras(args, h, chunk, gps, lwls_a, local_rank, batch_mode)
     h.close()
     # the configs[3] curve: the fixed 8-chunk ensemble over G ranks, at every G (after the headline handle is gone: at
     # G = 1 the eight chunks' 256 matrices take 74 GB)
@@ -384,7 +469,8 @@ def main():
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
             tj = json.load(open(path))
             w = tj.get("workload", {})
-            if (w.get("N"), w.get("components"), w.get("walkers"), w.get("mode")) == (N, c, B, mode):
+            if (w.get("N"), w.get("components"), w.get("walkers"), w.get("mode")) == (N, c, B, mode) and \
+                    (mode != "stream" or w.get("steps") == args.steps):
                 traffic, traffic_src = tj["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
                 break
         out = {
@@ -392,24 +478,40 @@ def main():
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "rccl_ranks": world if (world > 1 and args.backend == "nccl") else (0 if world > 1 else 1),
+            # ranks of the RCCL communicator the gathers of this run actually went through (0: none ran -- one GPU, or gloo)
+            "rccl_ranks": dist.get_world_size() if (world > 1 and args.backend == "nccl" and collectives["n"] > 0) else 0,
+            "collectives_completed": collectives["n"],
             "backend": args.backend if world > 1 else None,
             "config": {"workload": f"SB2 chunk 20 epochs x 300 px (N={N}), {B} walkers per step per GPU, "
-                                   f"one chunk per GPU (BASELINE.json configs[2]; configs[3] at 8 GPUs); "
-                                   f"timed step = H2D of next proposals || eval, D2H of {B} lnprobs, gather",
+                                   f"one chunk per GPU (BASELINE.json configs[2]; configs[3] at 8 GPUs); " +
+                                   (f"the {args.steps} timed steps through ONE resident launch, {args.stream_groups} sub-ensembles "
+                                    f"of {B // args.stream_groups} walkers in flight (proposals pulled from pinned host memory, "
+                                    f"{B} lnprobs per step written to it), gather per step"
+                                    if args.mode == "stream" else
+                                    f"timed step = H2D of next proposals || eval, D2H of {B} lnprobs, gather"),
                        "N": N, "components": c, "walkers": B, "chunks_per_gpu": 1, "mode": args.mode,
-                       "stream_groups": args.groups,
+                       "stream_groups": args.stream_groups if args.mode == "stream" else args.groups,
                        "parallelism": f"chunk-sharded x{world}, RCCL all_gather of walker lnprobs"},
-            "timing_boundary": "pcie_inclusive (per-step H2D of B*c*N doubles double-buffered under the previous eval)",
+            "timing_boundary": ("pcie_inclusive (every proposal is pulled from pinned host memory by the resident launch, "
+                                "every result written to it; the timed region starts and ends with nothing in flight and "
+                                "no launch resident)" if args.mode == "stream" else
+                                "pcie_inclusive (per-step H2D of B*c*N doubles double-buffered under the previous eval)"),
+            "library": library,
+            "launch_per_step": per_step,
+            "stream": stream_info,
             "resident_evals_per_s": resident_value,
             "inclusive_over_resident": value / resident_value,
             "roofline": {"bound": "mfma", "kernel": dom_name,
                          "achieved": achieved, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src,
-                         "launches_per_step": dom["launches"], "avg_launch_ms": avg_ms,
+                         "launches_per_step": (1.0 / args.steps) if args.mode == "stream" else dom["launches"],
+                         "avg_launch_ms": avg_ms,
+                         "units_per_launch": (f"{stream_info['matrices']} evaluations = {args.steps} steps x {B} walkers"
+                                              if args.mode == "stream" else f"{B} evaluations"),
                          "algorithmic_flops_per_launch": alg_per_launch,
-                         "executed_tflops": dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else None,
+                         "executed_tflops": (dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+                                             if dom["ms"] > 0 and dom["flops"] == dom["flops"] else None),
                          "measured_peak": mb["mfma_f64_tflops"]},
             "roofline_eval": {"bound": "mfma", "achieved": value / world * flops_eval(N) / 1e12,
                               "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
@@ -546,9 +648,14 @@ def run_extras(args, h, chunk, gps, lwls, dev, mode):
         h.lnlike_batch(lwls[:4], gps[:4])
         t4.append(time.perf_counter() - t0)
     h.lnlike_batch(lwls, gps)                  # leave the headline batch in the slot
+    tf1 = flops_eval(N) / float(np.median(tds)) / 1e12
     ex["dropin_eval"] = {"call": f"covariance.{lnlike.__name__}(V11, *lwls, fl, sigma, *p_GP), N={N}: upload + one evaluation + fetch",
                          "ms": 1e3 * float(np.median(tds)), "min_ms": 1e3 * float(min(tds)),
-                         "tflops": flops_eval(N) / float(np.median(tds)) / 1e12,
+                         "tflops": tf1,
+                         # the reference's own calling pattern (psoap/sample_parallel.py:193), host call to host result
+                         "roofline": {"bound": "mfma", "achieved": tf1, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": tf1 / PEAK_FP64_TFLOPS, "algorithmic_flops": flops_eval(N),
+                                      "note": "per call, PCIe and Python included; one matrix: bound by the row-to-row chain"},
                          "batch4_ms": 1e3 * float(np.median(t4)), "lnprob": float(v0)}
 
     # the lnprob(p) boundary: orbital parameters in, lnprob out

@@ -270,6 +270,8 @@ int psoap_stream_ready(psoap_chunk *h, long long ticket, int *ready);
 /* the resident launch leaves as soon as what is in flight is done (instead of after the idle time-out) and the call
  * returns when it has; the stream stays open and the next submit relaunches.  Call before a device-wide synchronise. */
 int psoap_stream_pause(psoap_chunk *h);
+/* duration (HIP events around it) of the resident launch that psoap_stream_pause ended last, and the matrices it completed */
+int psoap_stream_last_launch(psoap_chunk *h, double *ms, long long *matrices);
 /* waits for what is in flight, ends the resident launch, frees the stream */
 int psoap_stream_close(psoap_chunk *h);
 /* counters: launches of the resident kernel so far (> 1 after an idle time-out), submissions, completed results, the

@@ -91,6 +91,7 @@ SIGNATURES = {
     "psoap_stream_ready": (ctypes.c_int, [_vp, ctypes.c_longlong, _ip]),
     "psoap_stream_close": (ctypes.c_int, [_vp]),
     "psoap_stream_pause": (ctypes.c_int, [_vp]),
+    "psoap_stream_last_launch": (ctypes.c_int, [_vp, _dp, ctypes.POINTER(ctypes.c_longlong)]),
     "psoap_stream_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong),
                                           ctypes.POINTER(ctypes.c_longlong), _ip, ctypes.POINTER(ctypes.c_longlong)]),
     "psoap_stream_plan": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_longlong,

@@ -182,6 +182,12 @@ class ChunkHandle:
         """The resident launch leaves now (after what is in flight) and the device is free; the next submit relaunches."""
         check(self._L.psoap_stream_pause(self._h), "psoap_stream_pause")
 
+    def stream_last_launch(self) -> dict:
+        """the resident launch ``stream_pause`` ended last: duration by HIP events on its stream, matrices completed"""
+        ms, n = ctypes.c_double(0.0), ctypes.c_longlong(0)
+        check(self._L.psoap_stream_last_launch(self._h, ctypes.byref(ms), ctypes.byref(n)), "psoap_stream_last_launch")
+        return {"ms": ms.value, "matrices": n.value}
+
     def stream_close(self):
         check(self._L.psoap_stream_close(self._h), "psoap_stream_close")
 

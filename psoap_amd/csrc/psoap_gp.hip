@@ -94,8 +94,11 @@ struct StreamState {
     DagMat* dMats = nullptr;
     unsigned long long* dTlog = nullptr;
     unsigned int tlog_cap = 0;
-    hipEvent_t evExit = nullptr;
+    hipEvent_t evStart = nullptr, evExit = nullptr;   // around the resident launch (timed: the roofline of bench.py)
     bool launched = false;
+    unsigned long long completed_before = 0;     // StreamDev::completed when the current launch started
+    double last_launch_ms = 0.0;                 // the launch that ended last (psoap_stream_pause / close measure it)
+    long long last_launch_matrices = 0;
     unsigned long long head = 0;                 // submissions published
     std::vector<long long> lane_ticket;          // ticket held by each lane, -1: free
     std::vector<char> neg;                       // per ring entry: a hyper-parameter was negative -> -inf
@@ -1160,11 +1163,14 @@ extern "C" int psoap_group_stats(psoap_group* g, long long* plan_builds, long lo
 // The reference issues one iteration after another (psoap/sample_parallel.py:434-438: the sampler's loop; :193 the
 // likelihood call inside it).  psoap_stream_* keeps ONE launch of the persistent kernel resident across those
 // iterations: submit() hands proposals to free lanes, fetch() returns their lnprob; see dag_kernel.hpp.
+static int stream_measure_launch(psoap_chunk* h);
+
 static int stream_launch(psoap_chunk* h)
 {
     StreamState& st = h->stream;
     hipStream_t s = h->streams[0];
     HIP_TRY(hipMemsetAsync(st.dDev, 0, 64, s));      // stop, opens (no workgroup of an earlier launch is left: same stream)
+    HIP_TRY(hipEventRecord(st.evStart, s));
     StreamArgs a{};
     a.lanes = st.dLanes;
     a.dev = st.dDev;
@@ -1216,6 +1222,7 @@ static int stream_ensure_running(psoap_chunk* h)
             g_err = std::string("stream: the resident launch failed: ") + hipGetErrorString(q);
             return 1;
         }
+        if (int rc = stream_measure_launch(h)) return rc;     // it left by itself (idle time-out): book it
     }
     return stream_launch(h);
 }
@@ -1227,6 +1234,7 @@ static int stream_free(psoap_chunk* h)
     (void)hipFree(st.dDag); (void)hipFree(st.dMats); (void)hipFree(st.dTlog);
     (void)hipHostFree(st.hHost); (void)hipHostFree(st.hLw); (void)hipHostFree(st.hGp);
     if (st.evExit) (void)hipEventDestroy(st.evExit);
+    if (st.evStart) (void)hipEventDestroy(st.evStart);
     st = StreamState();
     return 0;
 }
@@ -1295,7 +1303,8 @@ static int stream_open_impl(psoap_chunk* h, int c, int lanes, int scheme)
         mats[b] = m;
     }
     HIP_TRY(hipMemcpy(st.dMats, mats.data(), sizeof(DagMat) * lanes, hipMemcpyHostToDevice));
-    HIP_TRY(hipEventCreateWithFlags(&st.evExit, hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&st.evExit));
+    HIP_TRY(hipEventCreate(&st.evStart));
     st.lane_ticket.assign((size_t)lanes, -1);
     st.neg.assign(STREAM_RING, 0);
     st.head = 0;
@@ -1501,6 +1510,22 @@ extern "C" int psoap_stream_tasks(psoap_chunk* h, void* out, long long max_tasks
     return 0;
 }
 
+// (the launch has ended: its duration by the events around it, its matrices by the device's completion counter)
+static int stream_measure_launch(psoap_chunk* h)
+{
+    StreamState& st = h->stream;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, st.evStart, st.evExit));
+    unsigned long long done = 0;
+    HIP_TRY(hipMemcpy(&done, reinterpret_cast<char*>(st.dDev) + offsetof(StreamDev, completed), sizeof done,
+                      hipMemcpyDeviceToHost));
+    st.last_launch_ms = ms;
+    st.last_launch_matrices = (long long)(done - st.completed_before);
+    st.completed_before = done;
+    st.launched = false;            // the next submit launches without asking the event
+    return 0;
+}
+
 // The resident launch leaves NOW (once what is in flight is done) instead of after the idle time-out, and the call
 // returns when it has: the device is free for other work (another handle's launch, a device-wide synchronise).  The
 // stream stays open; the next submit brings the launch back.
@@ -1518,6 +1543,15 @@ extern "C" int psoap_stream_pause(psoap_chunk* h)
         g_err = std::string("psoap_stream_pause: ") + hipGetErrorString(e);
         return 1;
     }
+    return stream_measure_launch(h);
+}
+
+// duration of the resident launch that ended last and the matrices it completed (valid after psoap_stream_pause)
+extern "C" int psoap_stream_last_launch(psoap_chunk* h, double* ms, long long* matrices)
+{
+    if (!h || !h->stream.open) FAIL("psoap_stream_last_launch: no open stream");
+    if (ms) *ms = h->stream.last_launch_ms;
+    if (matrices) *matrices = h->stream.last_launch_matrices;
     return 0;
 }
 

@@ -338,3 +338,53 @@ def test_following_scheme_task_flags_and_ticket_order(P):
             assert off_tickets[q][q + 1] < diag_ticket[q + 1]  # what DIAG(q+1) follows comes from a smaller ticket
     # every tile exactly once, as in the other schemes
     assert sum(len(v) for v in off_tickets.values()) == P * (P - 1) // 2
+
+
+@pytest.mark.parametrize("P,scheme", [(1, 0), (2, 0), (16, 0), (47, 0), (64, 0), (16, 1), (47, 1), (16, 2), (32, 2)])
+def test_lane_plan_of_a_stream(P, scheme):
+    """psoap_stream_plan: the task list every lane of a stream runs (one matrix).  It depends on P and the scheme only
+    (not on the lane count: results are bit-identical for every lane count); DagTask::b carries the burst marks -- the
+    last ticket of a block row's worth of tasks; scheme 0: tile-level dependencies with owned diagonal finals."""
+    from psoap_amd import _lib
+    L = _lib.load()
+
+    def lane_plan(lanes):
+        n, slots, ctrs, sch = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_int(-5)
+        assert L.psoap_stream_plan(P, lanes, 511, scheme, None, 0, ctypes.byref(n), ctypes.byref(slots), ctypes.byref(ctrs),
+                                   ctypes.byref(sch)) == 0
+        tasks = np.zeros(n.value, dtype=TASK)
+        assert L.psoap_stream_plan(P, lanes, 511, scheme, tasks.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n),
+                                   ctypes.byref(slots), ctypes.byref(ctrs), ctypes.byref(sch)) == 0
+        assert sch.value == scheme
+        return tasks, slots.value, ctrs.value
+
+    tasks, n_slots, n_ctrs = lane_plan(32)
+    for lanes in (1, 8, 64):
+        other, s2, c2 = lane_plan(lanes)
+        assert np.array_equal(other, tasks) and (s2, c2) == (n_slots, n_ctrs)
+    ty = tasks["type"] & TYPE_MASK
+    flags = tasks["type"]
+    marks = tasks["b"]
+    assert set(np.unique(marks)) <= {0, 0x8000} and marks[-1] == 0x8000
+    # every tile exactly once
+    finals = {(int(k["q"]), int(k["j"])): t for t, k in enumerate(tasks) if ty[t] != PART}
+    assert len(finals) == P * (P + 1) // 2
+    ends = np.where(marks == 0x8000)[0]
+    if scheme == 0:
+        # a burst = what was emitted for one block row: the parts that pre-accumulate DIAG(q+1), the row's strip solves with
+        # their parts, the owned DIAG(q+1) behind the strip solve of tile (q, q+1)
+        section = np.where((tasks["q"] == tasks["j"]) & (tasks["q"] > 0), tasks["q"].astype(int) - 1, tasks["q"].astype(int))
+        assert np.all(np.diff(section) >= 0)
+        assert list(ends) == [t for t in range(len(tasks)) if t + 1 == len(tasks) or section[t + 1] != section[t]]
+        for q in range(1, P):
+            t = finals[(q, q)]
+            assert flags[t] & NOSOLVE and finals[(q - 1, q)] == t - 1 and flags[t - 1] & FUSED
+        for t, k in enumerate(tasks):
+            q, j = int(k["q"]), int(k["j"])
+            for m in range(int(k["pb"])):
+                assert finals[(m, q)] < t and finals[(m, j)] < t          # the tiles an update reads: smaller tickets
+            if ty[t] == OFF:
+                assert finals[(q, q)] < t                                  # potrf(q)
+    else:
+        # schemes 1, 2: a burst ends in front of every diagonal final
+        assert list(ends) == [t for t in range(len(tasks)) if t + 1 == len(tasks) or ty[t + 1] == DIAG]

@@ -1,0 +1,234 @@
+"""GPU: streamed evaluation (include/psoap_gp.h: psoap_stream_*) -- ONE resident launch of the persistent kernel,
+matrices come and go through lanes.  Parity against the reference's goldens and the oracle through the C ABI, results
+independent of what else is in flight (batch size, submission order, lane count), the host protocol (tickets, lanes,
+idle time-out and relaunch, pause, close with work in flight, refusals), and a short soak."""
+import ctypes
+import os
+import time
+
+import numpy as np
+import pytest
+
+from psoap_amd import synthetic as syn
+from psoap_amd._lib import PsoapError
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10      # |dlnp| <= 1e-10 max(1, |lnp|): SURVEY.md section 8(c)
+
+
+def close(a, b, rtol=RTOL):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return bool(np.all(np.abs(a - b) <= rtol * np.maximum(1.0, np.abs(b))))
+
+
+def _props(ch, B, seed):
+    gps = syn.make_walkers(ch.n_components, B, seed=seed)
+    lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, B, seed=seed + 1))
+    return lw, gps
+
+
+@pytest.mark.parametrize("c,ne,npx,scheme", [(1, 3, 50, -1), (2, 6, 100, 0), (2, 6, 100, 1), (2, 6, 100, 2), (3, 5, 77, -1),
+                                             (2, 1, 1, -1), (1, 1, 128, 0), (2, 3, 43, 0)])
+def test_stream_matches_the_oracle_and_the_batch_path(oracle, c, ne, npx, scheme):
+    """small shapes incl. N = 1, one tile exactly, ragged sizes; every scheme of the lanes' task list"""
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_chunk(c, ne, npx, seed=9100 + 7 * c + npx)
+    B = 5
+    lw, gps = _props(ch, B, 9200 + npx)
+    want = np.array([oracle.lnlike(lw[b], ch.fl, ch.sigma, gps[b]) for b in range(B)])
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
+        batch = h.lnlike_batch(lw, gps)
+        h.stream_open(c, B, scheme)
+        t = h.stream_submit(lw, gps)
+        got = h.stream_fetch(t)
+        st = h.stream_stats()
+        h.stream_close()
+        assert close(got, want) and close(got, batch), (got, want, batch)
+        assert st["submitted"] == B and st["launches"] >= 1 and (scheme < 0 or st["scheme"] == scheme)
+        # the batch path works again after the stream is closed
+        assert np.array_equal(h.lnlike_batch(lw, gps), batch)
+
+
+def test_stream_reference_goldens_cfg3(golden):
+    """BASELINE configs[2] at full size through a stream: walker 0 and the reference's 4-walker batch (golden_v1.npz)"""
+    from psoap_amd.chunk import ChunkHandle, StreamPipeline
+    ch = syn.make_config_chunk(3)
+    B = 8
+    gps = syn.make_walkers(2, B, seed=3500)
+    lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, B, seed=3501))
+    want0 = float(golden["lnlike_vals"][list(golden["lnlike_names"]).index("cfg3_sb2_n6000")])
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
+        pipe = StreamPipeline(h, 2, B, groups=2)
+        pipe.start(lw, gps)
+        first = pipe.step(lw, gps)
+        second = pipe.drain()
+        pipe.close()
+    assert close(first[0], want0) and close(first[:4], golden["walkers_cfg3"][:4])
+    assert np.array_equal(first, second)
+
+
+def test_result_does_not_depend_on_what_else_is_in_flight():
+    """Every lane runs the task list of ONE matrix: a proposal's lnprob is bit-identical whether it travels alone, in a
+    full batch, in another order, through another lane, or through a stream with another lane count -- what an MH
+    chain needs to be the same chain on 1 and on 8 GPUs (the reference's sum is deterministic: sample_parallel.py:387)."""
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_chunk(2, 10, 140, seed=9300)               # N = 1400
+    B = 12
+    lw, gps = _props(ch, B, 9301)
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
+        h.stream_open(2, B, 0)
+        ref = h.stream_fetch(h.stream_submit(lw, gps))
+        # one at a time
+        one = np.array([h.stream_fetch(h.stream_submit(lw[b:b + 1], gps[b:b + 1]))[0] for b in range(B)])
+        # reversed order, in two submissions that overlap
+        perm = np.arange(B)[::-1]
+        ta = h.stream_submit(lw[perm[:5]], gps[perm[:5]])
+        tb = h.stream_submit(lw[perm[5:]], gps[perm[5:]])
+        rev = np.empty(B)
+        rev[perm[5:]] = h.stream_fetch(tb)
+        rev[perm[:5]] = h.stream_fetch(ta)
+        h.stream_close()
+        h.stream_open(2, 3, 0)                               # another lane count, same scheme
+        few = np.concatenate([h.stream_fetch(h.stream_submit(lw[b:b + 3], gps[b:b + 3])) for b in range(0, B, 3)])
+        h.stream_close()
+    assert np.array_equal(one, ref) and np.array_equal(rev, ref) and np.array_equal(few, ref)
+
+
+def test_rejected_and_not_positive_definite_proposals():
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_chunk(2, 4, 90, seed=9400)
+    B = 6
+    lw, gps = _props(ch, B, 9401)
+    gps[2, 1] = -3.0                                          # negative length scale: -inf (covariance.py:339)
+    sig = ch.sigma.copy()
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
+        good = h.lnlike_batch(lw, gps)
+        h.stream_open(2)
+        got = h.stream_fetch(h.stream_submit(lw, gps))
+        h.stream_close()
+    assert np.isneginf(got[2]) and np.isneginf(good[2])
+    keep = np.arange(B) != 2
+    assert close(got[keep], good[keep])
+    # a matrix that is not positive definite: zero noise and two identical pixels
+    lw2 = lw.copy()
+    lw2[:, :, 1] = lw2[:, :, 0]
+    with ChunkHandle(ch.fl, np.zeros_like(sig), max_batch=B) as h:
+        h.stream_open(2)
+        bad = h.stream_fetch(h.stream_submit(lw2, np.abs(gps)))
+        h.stream_close()
+    assert np.all(np.isneginf(bad))
+
+
+def test_host_protocol_tickets_lanes_refusals():
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_chunk(1, 4, 100, seed=9500)
+    B = 4
+    lw, gps = _props(ch, 8, 9501)
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
+        with pytest.raises(PsoapError, match="no open stream"):
+            h._stream_c = 1
+            h.stream_submit(lw[:1], gps[:1])
+        with pytest.raises(PsoapError, match="lanes"):
+            h.stream_open(1, B + 1)
+        h.stream_open(1, B)
+        with pytest.raises(PsoapError, match="already has an open stream"):
+            h.stream_open(1, B)
+        with pytest.raises(PsoapError, match="open stream"):
+            h.lnlike_batch(lw[:2], gps[:2])                  # the workspaces belong to the resident launch
+        t1 = h.stream_submit(lw[:3], gps[:3])
+        with pytest.raises(PsoapError, match="free lanes"):
+            h.stream_submit(lw[3:6], gps[3:6])               # only one lane left
+        t2 = h.stream_submit(lw[3:4], gps[3:4])
+        assert list(t1) == [0, 1, 2] and list(t2) == [3]
+        k = h.stream_wait_any(np.concatenate([t1, t2]))
+        assert 0 <= k < 4
+        a = h.stream_fetch(t1[::-1])[::-1]                   # any order of tickets
+        assert h.stream_ready(int(t2[0])) in (True, False)
+        b = h.stream_fetch(t2)
+        with pytest.raises(PsoapError, match="fetched before"):
+            h.stream_fetch(t2)
+        with pytest.raises(PsoapError, match="unknown ticket"):
+            h.stream_fetch(np.array([99]))
+        t3 = h.stream_submit(lw[4:8], gps[4:8])              # all four lanes free again
+        c_ = h.stream_fetch(t3)
+        h.stream_close()
+        want = h.lnlike_batch(lw[:4], gps[:4])
+        want2 = h.lnlike_batch(lw[4:8], gps[4:8])
+    assert close(np.concatenate([a, b]), want) and close(c_, want2)
+
+
+def test_idle_timeout_relaunch_pause_and_close_with_work_in_flight(monkeypatch):
+    """The resident launch leaves by itself when nothing was in flight for PSOAP_STREAM_IDLE_MS and comes back on the next
+    submit; psoap_stream_pause makes it leave at once; closing with submissions in flight completes them first."""
+    from psoap_amd.chunk import ChunkHandle
+    monkeypatch.setenv("PSOAP_STREAM_IDLE_MS", "5")
+    ch = syn.make_chunk(2, 5, 100, seed=9600)
+    B = 6
+    lw, gps = _props(ch, B, 9601)
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
+        h.stream_open(2, B, 0)
+        ref = h.stream_fetch(h.stream_submit(lw, gps))
+        assert h.stream_stats()["launches"] == 1
+        time.sleep(0.2)                                       # far beyond the idle time-out: the launch has left
+        again = h.stream_fetch(h.stream_submit(lw, gps))
+        assert h.stream_stats()["launches"] == 2 and np.array_equal(again, ref)
+        h.stream_pause()
+        info = h.stream_last_launch()
+        assert info["matrices"] == B and 0.0 < info["ms"] < 1000.0
+        third = h.stream_fetch(h.stream_submit(lw, gps))
+        st = h.stream_stats()
+        assert st["launches"] == 3 and st["submitted"] == 3 * B and st["completed"] == 3 * B and np.array_equal(third, ref)
+        h.stream_submit(lw, gps)                              # never fetched
+        h.stream_close()
+        assert np.array_equal(h.lnlike_batch(lw, gps), h.lnlike_batch(lw, gps))
+    # a handle destroyed with an open stream and work in flight
+    h = ChunkHandle(ch.fl, ch.sigma, max_batch=B)
+    h.stream_open(2, B)
+    h.stream_submit(lw, gps)
+    h.close()
+
+
+def test_pipeline_two_groups_in_flight_any_order_and_stagger():
+    from psoap_amd.chunk import ChunkHandle, StreamPipeline
+    ch = syn.make_chunk(2, 8, 120, seed=9700)                 # N = 960
+    B = 8
+    sets = [_props(ch, B, 9701 + 10 * i) for i in range(5)]
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
+        serial = [h.lnlike_batch(*s) for s in sets]
+        for groups, anyorder in ((2, False), (4, True), (8, True)):
+            pipe = StreamPipeline(h, 2, B, groups)
+            assert pipe.calibrate(*sets[0]) > 0.0
+            pipe.start(*sets[0])
+            got = []
+            for k in range(1, len(sets)):
+                got.append(pipe.step_any_order(*sets[k]) if anyorder else pipe.step(*sets[k]))
+            got.append(pipe.drain())
+            pipe.close()
+            for k in range(len(sets)):
+                assert close(got[k], serial[k]), (groups, k)
+
+
+def test_stream_soak_bit_identical():
+    """many matrices through few lanes of one resident launch, in changing batch sizes: every result bit-identical to
+    the first of its kind, and no wait ever times out (a time-out raises)"""
+    from psoap_amd.chunk import ChunkHandle
+    rng = np.random.default_rng(5)
+    for cfg_, B, scheme, rounds in (((2, 10, 200), 8, 0, 60), ((2, 10, 200), 8, 1, 60), ((1, 6, 100), 16, -1, 60), ((3, 4, 150), 4, 2, 60)):
+        ch = syn.make_chunk(*cfg_, seed=9800)
+        lw, gps = _props(ch, B, 9801)
+        with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
+            h.stream_open(ch.n_components, B, scheme)
+            ref = h.stream_fetch(h.stream_submit(lw, gps))
+            pending = []
+            for _ in range(rounds):
+                idx = rng.permutation(B)[: int(rng.integers(1, B + 1))]
+                # keep up to two submissions in flight
+                if len(pending) == 2 or (pending and sum(len(p[1]) for p in pending) + len(idx) > B):
+                    t, i = pending.pop(0)
+                    assert np.array_equal(h.stream_fetch(t), ref[i])
+                if sum(len(p[1]) for p in pending) + len(idx) <= B:
+                    pending.append((h.stream_submit(lw[idx], gps[idx]), idx))
+            for t, i in pending:
+                assert np.array_equal(h.stream_fetch(t), ref[i])
+            h.stream_close()
