@@ -265,7 +265,13 @@ def main():
 
     from psoap_amd import build as _build
     from psoap_amd.chunk import ChunkHandle, StreamPipeline, microbench
-    from psoap_amd.ensemble import gather_chunk_lnprobs, sum_over_chunks
+    from psoap_amd.ensemble import SharedDeviceLock, _NoLock, gather_chunk_lnprobs, sum_over_chunks
+
+    # Dry runs (--backend gloo: several ranks on one GPU): one rank at a time on the device -- its time-slicing of several
+    # processes' persistent kernels is not covered by the kernels' hand-off protocol (psoap_amd/ensemble.py).  Around
+    # everything from a launch to the fetch of its results, never around a collective.
+    shared_gpu = world > 1 and args.backend == "gloo"
+    gpu = SharedDeviceLock(local_rank) if shared_gpu else _NoLock()
 
     # which binary runs: its hash, what it was built from and by, and the rung of the build's flag ladder
     library = _build.provenance()
@@ -302,10 +308,14 @@ def main():
 
     def step():
         """eval(k) || upload(k+1), fetch(k), gather.  One H2D, one evaluation, one D2H per step."""
-        h.eval()
-        state["k"] += 1
-        h.upload(*sets[state["k"] & 1])
-        return gather(h.fetch())
+        with gpu:
+            h.eval()
+            state["k"] += 1
+            h.upload(*sets[state["k"] & 1])
+            lnp = h.fetch()
+            if shared_gpu:
+                h.sync()                   # (the upload too: nothing of this rank is left on the device)
+        return gather(lnp)
 
     def fence_nohandle():
         if world > 1:
@@ -319,7 +329,9 @@ def main():
     def run_launch_per_step(n_warm, n_steps):
         """rounds 1-3: one launch per step, the next step's proposals uploaded under it"""
         state["k"] = 0
-        h.upload(*sets[0])
+        with gpu:
+            h.upload(*sets[0])
+            h.sync()
         for _ in range(n_warm):
             table, total = step()
         fence()
@@ -335,8 +347,21 @@ def main():
             raise SystemExit("--walkers must be a multiple of --stream-groups")
         pipe = StreamPipeline(h, c, B, args.stream_groups)
 
+        def run_stream_shared(n_steps):
+            """the dry-run form: a step's sub-ensembles go through the stream together and the resident launch leaves
+            before the gather -- the same entry points, no overlap (the device belongs to one rank at a time)"""
+            for k in range(n_steps):
+                with gpu:
+                    pipe.start(*sets[k & 1], stagger=0.0)
+                    lnp = pipe.drain()
+                    h.stream_pause()
+                table, total = gather(lnp)
+            return table, total, (n_steps - 1) & 1
+
         def run_stream(n_steps):
             """n_steps ensemble steps through one resident launch; from nothing in flight to nothing in flight"""
+            if shared_gpu:
+                return run_stream_shared(n_steps)
             pipe.start(*sets[0])
             lnp = None
             for k in range(1, n_steps):
@@ -347,8 +372,9 @@ def main():
             h.stream_pause()                           # the resident launch leaves: the device is free again
             return table, total, (n_steps - 1) & 1
 
-        pipe.calibrate(*sets[0])                       # a few steps: the period the start-up stagger is set from
-        h.stream_pause()
+        with gpu:
+            pipe.calibrate(*sets[0])                   # a few steps: the period the start-up stagger is set from
+            h.stream_pause()
         if args.warmup > 0:
             run_stream(args.warmup)
         fence_nohandle()
@@ -357,7 +383,8 @@ def main():
         fence_nohandle()
         dt = time.perf_counter() - t0
         stream_info = dict(h.stream_last_launch(), **h.stream_stats())
-        pipe.close()
+        with gpu:
+            pipe.close()
     else:
         dt, table, total, last_set = run_launch_per_step(args.warmup, args.steps)
     if world > 1:
@@ -399,18 +426,26 @@ def main():
             totps = np.roll(totps, -1)
         # the same proposals through both paths: equal to the parity tolerance (the stream's task list is that of one
         # matrix, the batch's that of 32 in lock-step: another order of summation)
-        require(close(totps, total), "launch-per-step path vs streamed path on the same proposals")
+        if not close(totps, total):
+            bad = np.where(np.abs(totps - total) > PARITY_RTOL * np.maximum(1.0, np.abs(total)))[0]
+            raise SystemExit("bench.py: PARITY FAILURE: launch-per-step path vs streamed path on the same proposals: walkers "
+                             f"{bad.tolist()}: launch-per-step {totps[bad].tolist()} streamed {total[bad].tolist()}; per-chunk "
+                             f"tables of those walkers: launch-per-step {tps[:, bad].tolist() if lsps == 0 else np.roll(tps, -1, axis=1)[:, bad].tolist()} "
+                             f"streamed {table[:, bad].tolist()} (rank {rank})")
         per_step = {"evals_per_s": evals / dps, "ms_per_step": 1e3 * dps / args.steps,
                     "what": "rounds 1-3: one launch of the persistent kernel per step, next step's proposals uploaded under it"}
 
     # ---- proposals-resident rate (the round-1 headline; never `value`): eval + fetch + gather only
-    h.upload(*sets[0])
-    h.eval(); h.fetch()
+    with gpu:
+        h.upload(*sets[0])
+        h.eval(); h.fetch()
     fence()
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        h.eval()
-        gather(h.fetch())
+        with gpu:
+            h.eval()
+            lnp_r = h.fetch()
+        gather(lnp_r)
     fence()
     dt_res = time.perf_counter() - t1
     if world > 1:
@@ -420,11 +455,12 @@ def main():
     resident_value = evals / dt_res
 
     # ---- live per-kernel timing (HIP events on the launch stream) for the roofline object
-    h.set_profiling(True)
-    h.eval()
-    h.fetch()
-    tm = h.timings()
-    h.set_profiling(False)
+    with gpu:
+        h.set_profiling(True)
+        h.eval()
+        h.fetch()
+        tm = h.timings()
+        h.set_profiling(False)
     mode = "dag" if tm["dag"]["launches"] > 0 else "staged"
     if args.mode == "stream":
         # the dominant kernel is the RESIDENT launch of the timed region: HIP events around it on its stream
@@ -434,8 +470,10 @@ def main():
         dom_name = ("k_chol_dag<%d, false, false, stream> (ONE resident launch over the %d timed steps: persistent tile DAG, "
                     "v_mfma_f64_16x16x4_f64)" % (c, args.steps))
         alg_per_launch = stream_info["matrices"] * flops_eval(N)
-        require(stream_info["matrices"] == B * args.steps and stream_info["launches"] >= 1,
+        require(shared_gpu or (stream_info["matrices"] == B * args.steps and stream_info["launches"] >= 1),
                 f"the timed region's resident launch completed {stream_info['matrices']} matrices, expected {B * args.steps}")
+        if shared_gpu:       # dry run: one launch per step -- the line's roofline object describes the last one
+            alg_per_launch = stream_info["matrices"] * flops_eval(N)
     elif mode == "dag":
         # one persistent launch does the whole factorisation + solve of the batch:
         # algorithmic flops per launch = B x F(N)  
@@ -458,10 +496,11 @@ def main():
     extras = {}
     if world == 1 and not args.no_extras:
         extras = run_extras(args, h, chunk, gps, lwls_a, local_rank, batch_mode)
-    h.close()
+    with gpu:
+        h.close()
     # the configs[3] curve: the fixed 8-chunk ensemble over G ranks, at every G (after the headline handle is gone: at
     # G = 1 the eight chunks' 256 matrices take 74 GB)
-    strong = None if args.no_strong else strong_leg(args, world, rank, local_rank, fence_nohandle, allreduce_max)
+    strong = None if args.no_strong else strong_leg(args, world, rank, local_rank, fence_nohandle, allreduce_max, gpu)
 
     if rank == 0:
         mb = microbench(local_rank)
@@ -548,31 +587,42 @@ def main():
         dist.destroy_process_group()
 
 
-def strong_leg(args, world, rank, dev, fence, allreduce_max):
+def strong_leg(args, world, rank, dev, fence, allreduce_max, gpu):
     """BASELINE configs[3] as named: the FIXED 8-chunk x 32-walker ensemble (seeds 4000..4007), chunk k on rank
     k mod G (psoap/sample_parallel.py:258-278 fans the chunks out, :378-387 gathers and sums), all chunks of a rank
     in ONE launch of the persistent kernel (ChunkGroup) -- 256 evaluations per step whatever G is: strong scaling.
     Same timing protocol as the headline (barrier + synchronize on both sides, max over ranks, next step's
     proposals uploaded under the evaluation); every (chunk, walker) value of the first walkers is checked against
     the reference's goldens on every rank."""
-    from psoap_amd.ensemble import EnsembleEvaluator
+    from psoap_amd.ensemble import EnsembleEvaluator, SharedDeviceLock
+    shared = isinstance(gpu, SharedDeviceLock)
     B = args.walkers
     n_chunks = 8
     chunks8 = [syn.make_config_chunk(4, k) for k in range(n_chunks)]
     gps4 = syn.make_walkers(2, B, seed=4500)
-    ev8 = EnsembleEvaluator.from_chunks(chunks8, max_batch=B, world=world, rank=rank, device_index=dev)
+    with gpu:
+        ev8 = EnsembleEvaluator.from_chunks(chunks8, max_batch=B, world=world, rank=rank, device_index=dev)
+    ev8.device_lock = gpu
     props8 = {k: (syn.walker_lwls(chunks8[k], syn.make_walker_velocities(chunks8[k], B, seed=4501 + k)), gps4)
               for k in ev8.mine}
     N = chunks8[0].N
     tot8 = ev8.lnprob(props8)                # warm-up: plans, workspaces, the collective
-    ev8.upload(props8)
+    with gpu:
+        ev8.upload(props8)
+        for hk in ev8.handles.values():
+            hk.sync()
     n4 = max(2, min(args.steps, 4))
     fence()
     t4 = time.perf_counter()
     for _ in range(n4):                      # same boundary as the headline: H2D of the next step under the evaluation
-        ev8.launch()
-        ev8.upload(props8)
-        tot8 = ev8.collect()
+        with gpu:
+            ev8.launch()
+            ev8.upload(props8)
+            local8 = ev8.fetch_local()
+            if shared:                       # dry run: nothing of this rank may be left on the device outside the lock
+                for hk in ev8.handles.values():
+                    hk.sync()
+        tot8 = ev8._gather_and_sum(local8)
     fence()
     dt4 = allreduce_max(time.perf_counter() - t4)
     rate = n4 * n_chunks * B / dt4
@@ -584,7 +634,8 @@ def strong_leg(args, world, rank, dev, fence, allreduce_max):
         want = want + gf[k, :nw]
     require(close(tot8[:nw], want), "configs[3] strong leg: walker sums vs reference goldens")
     stats = ev8.group.stats() if getattr(ev8, "group", None) is not None else None
-    ev8.close()
+    with gpu:
+        ev8.close()
     return {"workload": f"BASELINE configs[3]: {n_chunks} SB2 chunks (N={N}) x {B} walkers = {n_chunks * B} evals per step, "
                         f"chunk k on rank k mod {world}, one launch per rank",
             "evals_per_s": rate, "ms_per_step": 1e3 * dt4 / n4, "steps": n4, "n_gpus": world, "scaling": "strong",

@@ -975,7 +975,9 @@ struct alignas(64) StreamLane {
     unsigned int pad0;
     unsigned long long seq;         // submission number of that matrix
     unsigned long long stamp;       // when the lane's last burst was handed out (s_memrealtime; 0: none yet)
-    unsigned int pad[10];
+    unsigned int retired;           // tasks of the matrix that have RETIRED (their last store is out): the one that makes it
+                                    // n_tasks reports the result -- see stream_retire
+    unsigned int pad[9];
 };
 constexpr unsigned short STREAM_BURST_END = 0x8000;   // DagTask::b of a lane's task list (the matrix index is the lane):
                                                       // the last ticket of a burst -- the next one starts a block row
@@ -1183,8 +1185,8 @@ __device__ __forceinline__ void stream_next_lane(const StreamArgs& st, int lane)
     __hip_atomic_store(&st.dev->cur[lane & 7].lane, (unsigned int)pick, PSOAP_RLX_AGENT);
 }
 
-// The matrix of `lane` is complete (thread 0 of the workgroup that finished its last diagonal block, after its release):
-// lnprob and the submission number go straight to pinned host memory.
+// The matrix of `lane` is complete: lnprob and the submission number go straight to pinned host memory (thread 0 of the
+// workgroup whose task retired last: stream_retire).
 __device__ __forceinline__ void stream_complete(const StreamArgs& st, int lane, MatAcc* acc)
 {
     const double lh = __hip_atomic_load(&acc->logdet_half, PSOAP_RLX_AGENT);
@@ -1197,6 +1199,21 @@ __device__ __forceinline__ void stream_complete(const StreamArgs& st, int lane, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&res->seq1, seq + 1ull, PSOAP_RLX_SYSTEM);
     __hip_atomic_fetch_add(&st.dev->completed, 1ull, PSOAP_RLX_AGENT);
+}
+
+// A task of the matrix in `lane` has retired (thread 0, behind the task's last store).  The result is reported by whoever
+// retires LAST, not by the last diagonal task: in the latency schemes the tasks that FOLLOW a factorisation hand their
+// tiles over row block by row block, the diagonal task they feed can be through before they have written their own
+// completion words -- and the host, told too early, resubmits to the lane, whose flags the dispatcher then clears under a
+// straggler's late store (seen as a rare wrong lnprob with eight processes sharing one GPU).
+__device__ __forceinline__ void stream_retire(const StreamArgs& st, int lane, MatAcc* acc)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's completion words are out
+    const unsigned int old = __hip_atomic_fetch_add(&st.lanes[lane].retired, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == st.n_tasks) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        stream_complete(st, lane, acc);
+    }
 }
 
 // Workgroup 0 of a streamed launch (all 256 threads): open lanes as the host publishes submissions, end the launch.
@@ -1282,6 +1299,7 @@ __device__ __forceinline__ void stream_dispatch(const StreamArgs& st, const DagM
                     const int lane = __hip_atomic_load(&st.host->entry[(opened + k) % STREAM_RING].lane, PSOAP_RLX_SYSTEM);
                     __hip_atomic_store(&st.lanes[lane].seq, opened + k, PSOAP_RLX_AGENT);
                     __hip_atomic_store(&st.lanes[lane].stamp, 0ull, PSOAP_RLX_AGENT);
+                    __hip_atomic_store(&st.lanes[lane].retired, 0u, PSOAP_RLX_AGENT);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 for (unsigned int k = 0; k < nb; ++k) {
@@ -1485,8 +1503,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
             dag_special<C, AUG>(&args);
             if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
             if constexpr (STREAM) {
-                // (the last diagonal block: nothing of this matrix is left -- thread 0 published the task's completion)
-                if (fast_diag && q == mat.P - 1 && threadIdx.x == 0) stream_complete(st, b, mat.acc);
+                if (threadIdx.x == 0) stream_retire(st, b, mat.acc);
             }
             continue;
         }
@@ -1496,7 +1513,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
                           &arrive_l[task.ctr], n_wait, dag_opaque_lds(psoap_smem), dag_opaque_lds(vec1), dag_opaque_lds(vec2),
                           tlog_l ? tlog_l + ticket * 8 : nullptr);
             if constexpr (STREAM) {
-                if (q == mat.P - 1 && threadIdx.x == 0) stream_complete(st, b, mat.acc);
+                if (threadIdx.x == 0) stream_retire(st, b, mat.acc);
             }
             continue;
         }
@@ -1549,6 +1566,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
                 __hip_atomic_fetch_add(&arrive_l[task.ctr], 1, PSOAP_RLX_AGENT);
             }
             if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+            if constexpr (STREAM) {
+                if (threadIdx.x == 0) stream_retire(st, b, mat.acc);
+            }
             continue;
         }
         if (AUG && ttype == DAG_SCHUR) continue;     // nobody inside the launch reads Sigma: no drain, no counter
@@ -1583,9 +1603,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
                 }
             } else if (threadIdx.x == 0) {
                 dag_task_done<CONT>(f, q, ntasks_row);
-                if constexpr (STREAM) {
-                    if (q == mat.P - 1) stream_complete(st, b, mat.acc);
-                }
             }
             __builtin_amdgcn_s_setprio(0);
         } else if (task.type & DAG_NOSOLVE) {
@@ -1612,6 +1629,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
             if constexpr (CONT) cont = (task.type & DAG_FUSED) != 0;
         }
         if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+        if constexpr (STREAM) {
+            if (threadIdx.x == 0) stream_retire(st, b, mat.acc);
+        }
     }
 }
 

@@ -30,12 +30,31 @@ def _dist():
     return dist
 
 
+class _GatherBuffers:
+    """Send / receive tensors of one (n_chunks, B, world, backend, device) gather: allocated once, reused every step
+    (round 3 allocated two tensors and went numpy -> torch -> device -> .cpu() per step)."""
+
+    def __init__(self, per: int, B: int, world: int, dev):
+        import torch
+        self.send = torch.zeros((per, B), dtype=torch.float64, device=dev)
+        self.recv = torch.empty((world * per, B), dtype=torch.float64, device=dev)
+        # pinned staging for the device case: one H2D and one D2H of a few KB, no pageable copies
+        self.cuda = dev.type == "cuda"
+        if self.cuda:
+            self.h_send = torch.zeros((per, B), dtype=torch.float64).pin_memory()
+            self.h_recv = torch.empty((world * per, B), dtype=torch.float64).pin_memory()
+
+
+_buffers: dict = {}
+
+
 def gather_chunk_lnprobs(local: np.ndarray, n_chunks: int, world: int, rank: int,
-                         device_index: int | None = None) -> np.ndarray:
+                         device_index: int | None = None, force_collective: bool = False) -> np.ndarray:
     """all_gather the (n_local, B) block of every rank into the (n_chunks, B) table.
 
     ``local[i]`` is the lnprob vector of chunk ``owned_chunks(...)[i]``.  Ranks with fewer
-    chunks are padded so the collective has equal counts.
+    chunks are padded so the collective has equal counts.  ``force_collective``: go through the
+    process group even when ``world == 1`` (a one-rank RCCL communicator exercises the same code).
     """
     local = np.ascontiguousarray(local, dtype=np.float64)
     if local.ndim != 2:
@@ -44,24 +63,40 @@ def gather_chunk_lnprobs(local: np.ndarray, n_chunks: int, world: int, rank: int
     mine = owned_chunks(n_chunks, world, rank)
     if local.shape[0] != len(mine):
         raise ValueError(f"rank {rank} owns {len(mine)} chunks but got {local.shape[0]} rows")
-    if world == 1:
+    if world == 1 and not force_collective:
         return local.copy()
     import torch
     dist = _dist()
     per = -(-n_chunks // world)
-    padded = np.zeros((per, B))
-    padded[:len(mine)] = local
     use_cuda = dist.get_backend() == "nccl"
     dev = torch.device("cuda", device_index if device_index is not None else torch.cuda.current_device()) \
         if use_cuda else torch.device("cpu")
-    send = torch.from_numpy(padded).to(dev)
-    recv = torch.empty((world * per, B), dtype=torch.float64, device=dev)
-    dist.all_gather_into_tensor(recv, send)
-    table = recv.cpu().numpy().reshape(world, per, B)
+    key = (per, B, world, dist.get_backend(), str(dev))
+    buf = _buffers.get(key)
+    if buf is None:
+        buf = _buffers[key] = _GatherBuffers(per, B, world, dev)
+    if buf.cuda:
+        buf.h_send.zero_()
+        buf.h_send[:len(mine)] = torch.from_numpy(local)
+        buf.send.copy_(buf.h_send, non_blocking=True)
+        dist.all_gather_into_tensor(buf.recv, buf.send)
+        buf.h_recv.copy_(buf.recv, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        table = buf.h_recv.numpy().reshape(world, per, B)
+    else:
+        buf.send.zero_()
+        buf.send[:len(mine)] = torch.from_numpy(local)
+        dist.all_gather_into_tensor(buf.recv, buf.send)
+        table = buf.recv.numpy().reshape(world, per, B)
     out = np.empty((n_chunks, B))
     for k in range(n_chunks):
         out[k] = table[k % world, k // world]
     return out
+
+
+def release_gather_buffers():
+    """drop the cached tensors (before ``destroy_process_group``)"""
+    _buffers.clear()
 
 
 def sum_over_chunks(table: np.ndarray) -> np.ndarray:
@@ -82,6 +117,43 @@ def gather_and_sum(lnp: np.ndarray, world: int, device_index: int | None = None)
     return sum_over_chunks(table)
 
 
+class SharedDeviceLock:
+    """Dry runs only: several ranks on ONE GPU (``--backend gloo`` on a one-GPU box).  The device then time-slices the
+    ranks' persistent kernels (compute wave save / restore), and a workgroup that is suspended between its stores and the
+    release that publishes them is not covered by the kernel's hand-off protocol -- measured with 8 ranks on one MI355X:
+    a wrong (chunk, walker) value in about every second run, with the round-3 library as well; never with one process
+    per GPU, which is the production layout.  This lock (``flock`` on a file named after the job) lets one
+    rank at a time use the device: take it around everything from a launch to the fetch of its results, never around
+    a collective."""
+
+    def __init__(self, device_index: int = 0, job: str | None = None):
+        import os
+        import tempfile
+        job = job or os.environ.get("TORCHELASTIC_RUN_ID") or os.environ.get("MASTER_PORT") or "solo"
+        self.path = os.path.join(tempfile.gettempdir(), f"psoap_shared_gpu{device_index}_{job}.lock")
+        self._fh = None
+
+    def __enter__(self):
+        import fcntl
+        self._fh = open(self.path, "w")
+        fcntl.flock(self._fh, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self._fh, fcntl.LOCK_UN)
+        self._fh.close()
+        self._fh = None
+
+
+class _NoLock:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        pass
+
+
 class EnsembleEvaluator:
     """Evaluates ``lnprob(walker) = sum_k lnlike(chunk k, walker)`` for a walker ensemble.
 
@@ -98,6 +170,7 @@ class EnsembleEvaluator:
         self.device_index = device_index
         self.evaluate = evaluate
         self.mine = owned_chunks(self.n_chunks, self.world, self.rank)
+        self.device_lock = _NoLock()       # SharedDeviceLock for dry runs with several ranks on one GPU
 
     @classmethod
     def from_chunks(cls, chunks: Sequence, max_batch: int, world: int = 1, rank: int = 0,
@@ -122,9 +195,11 @@ class EnsembleEvaluator:
 
     def lnprob(self, proposals) -> np.ndarray:
         if getattr(self, "handles", None):
-            self.upload(proposals)
-            self.launch()
-            return self.collect()
+            with self.device_lock:
+                self.upload(proposals)
+                self.launch()
+                local = self.fetch_local()
+            return self._gather_and_sum(local)
         local = [np.asarray(self.evaluate(k, proposals), dtype=np.float64) for k in self.mine]
         return self._gather_and_sum(local)
 
@@ -144,8 +219,12 @@ class EnsembleEvaluator:
             for k in self.mine:
                 self.handles[k].eval()
 
+    def fetch_local(self) -> list:
+        """the results of this rank's chunks (blocks until the launch is through); no collective"""
+        return [np.asarray(self.handles[k].fetch(), dtype=np.float64) for k in self.mine]
+
     def collect(self) -> np.ndarray:
-        return self._gather_and_sum([np.asarray(self.handles[k].fetch(), dtype=np.float64) for k in self.mine])
+        return self._gather_and_sum(self.fetch_local())
 
     def _gather_and_sum(self, local) -> np.ndarray:
         B = local[0].shape[0] if local else 0

@@ -104,6 +104,9 @@ chunks = [syn.make_chunk(2, 5 + (k %% 3), 90 + 10 * k, seed=7800 + k) for k in r
 gps = syn.make_walkers(2, B, seed=7850)
 props = {k: (syn.walker_lwls(ch, syn.make_walker_velocities(ch, B, seed=7860 + k)), gps) for k, ch in enumerate(chunks)}
 ev = EnsembleEvaluator.from_chunks(chunks, max_batch=B, world=world, rank=rank, device_index=0)
+# (both ranks on ONE device: one at a time -- see SharedDeviceLock)
+from psoap_amd.ensemble import SharedDeviceLock
+ev.device_lock = SharedDeviceLock(0)
 tot = ev.lnprob(props)
 tot2 = ev.lnprob(props)
 assert np.array_equal(tot, tot2)
@@ -186,6 +189,80 @@ def test_bench_launches_its_own_ranks_gloo_dry_run():
     assert st["scaling"] == "strong" and st["n_gpus"] == 2 and st["chunks_per_rank"] == [4, 4]
     assert st["evals_per_s"] > 0 and st["parity_checked"] is True and st["parity_table"] == [8, 4]
     assert st["group_plan_builds"] == 1
+
+
+# ---------------------------------------------------------------------------------------------- the RCCL branch
+_NCCL_RANK_CODE = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from psoap_amd import synthetic as syn
+from psoap_amd.chunk import ChunkHandle
+from psoap_amd.ensemble import gather_chunk_lnprobs, release_gather_buffers, sum_over_chunks
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+B = 32
+ch = syn.make_chunk(2, 6, 100, seed=7900)
+gps = syn.make_walkers(2, B, seed=7901)
+lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, B, seed=7902))
+# torch's HIP context and libpsoap_gp.so's share device 0: evaluate, then push the (1, 32) block through the SAME code the
+# N > 1 path uses (device tensors in, all_gather_into_tensor over RCCL, table out)
+with ChunkHandle(ch.fl, ch.sigma, max_batch=B, device=0) as h:
+    lnp = h.lnlike_batch(lw, gps)
+    h.stream_open(2, B)
+    lnp_s = h.stream_fetch(h.stream_submit(lw, gps))      # ... also beside a resident launch of the stream
+    table_s = gather_chunk_lnprobs(lnp_s[None, :], 1, world, rank, 0, force_collective=True)
+    h.stream_close()
+table = gather_chunk_lnprobs(lnp[None, :], 1, world, rank, 0, force_collective=True)
+again = gather_chunk_lnprobs(lnp[None, :], 1, world, rank, 0, force_collective=True)      # the cached tensors
+ranks = dist.get_world_size()
+release_gather_buffers()
+dist.barrier()
+dist.destroy_process_group()
+print("RESULT " + json.dumps({"backend": "nccl", "ranks": ranks, "equal": bool(np.array_equal(table[0], lnp)),
+                              "equal_again": bool(np.array_equal(again[0], lnp)), "equal_stream": bool(np.array_equal(table_s[0], lnp_s)),
+                              "finite": bool(np.all(np.isfinite(lnp))), "sum": float(sum_over_chunks(table)[0]), "lnp0": float(lnp[0])}), flush=True)
+'''
+
+
+def test_rccl_branch_with_one_rank(tmp_path):
+    """The `nccl` (= RCCL) branch of the walker-lnprob gather on hardware: ONE rank under torch.distributed.run with
+    backend="nccl", device_id=cuda:0 -- RCCL loads, torch's HIP context and libpsoap_gp.so's share the device, device
+    tensors in, table out, equal to the input.  (A scaling curve needs more GPUs than this pool has.)"""
+    prog = tmp_path / "nccl_rank.py"
+    prog.write_text(_NCCL_RANK_CODE % ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node=1", str(prog)]
+    env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res, first = _run_retry_rendezvous_only(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0, (first, res.stdout[-1500:], res.stderr[-3000:])
+    rec = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):])
+    assert rec["backend"] == "nccl" and rec["ranks"] == 1
+    assert rec["equal"] and rec["equal_again"] and rec["equal_stream"] and rec["finite"] and rec["sum"] == rec["lnp0"]
+
+
+def test_bench_eight_ranks_gloo_dry_run():
+    """The 8-rank layout of BASELINE configs[3] as a dry run on ONE GPU: `python bench.py --gpus 8 --backend gloo` -- one
+    chunk per rank, the gathered (chunk, walker) table against the reference goldens, the strong leg with one chunk per
+    rank.  (The ranks share the device: their resident launches take turns, so this says nothing about speed.)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PSOAP_STREAM_IDLE_MS="2")
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    res, first = _run_retry_rendezvous_only([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo",
+                                             "--steps", "2", "--warmup", "1", "--walkers", "8"],
+                                            capture_output=True, text=True, timeout=1500, env=env)
+    noise = ("[Gloo]", "amdgpu.ids", "hostname of the client socket")
+    err = "\n".join(ln for ln in res.stderr.splitlines() if not any(x in ln for x in noise))
+    assert res.returncode == 0, (first, res.stdout[-1500:], err[-6000:])
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["parity_checked"] is True and rec["backend"] == "gloo" and rec["rccl_ranks"] == 0
+    assert rec["parity"]["golden_cfg4_table"] == [8, 4] and rec["collectives_completed"] > 0
+    st = rec["cfg4_strong"]
+    assert st["chunks_per_rank"] == [1] * 8 and st["parity_table"] == [8, 4] and st["parity_checked"] is True
 
 
 # ---------------------------------------------------------------------------------------------- forced split schemes
