@@ -1804,8 +1804,23 @@ inline void dag_emit_schur(DagPlan& plan, int b, int P, int Ms, int len = 8)
         }
 }
 
+// PSOAP_FIXED_PLAN=1 (round 4): every matrix gets the task structure of a stream lane (dag_build_lane_plan: scheme 0, the
+// split factors of ONE matrix on the nominal share of the workgroups) whatever the batch -- so the order of summation
+// inside a matrix, and with it every bit of its lnprob, is the same for every batch size, for every number of chunks in
+// a launch, for every number of GPUs, and equal to what a stream returns.  What it costs: small batches lose the
+// latency schemes (a single N = 6000 evaluation: 11 ms instead of 2.6).  For runs that have to be reproducible across
+// world sizes (an MH chain decided in the last bits: the reference's np.sum over chunks is deterministic,
+// psoap/sample_parallel.py:387).
+inline bool dag_fixed_plan()
+{
+    const char* e = getenv("PSOAP_FIXED_PLAN");
+    return e && e[0] == '1';
+}
+constexpr int STREAM_NOMINAL_LANES = 32;
+inline int dag_nominal_share(int workers_total) { const int s = workers_total / STREAM_NOMINAL_LANES / 2; return s > 0 ? s : 1; }
+
 inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const std::vector<int>& Ps, int workers,
-                            int Bq_nominal, int scheme, int Mt = 0, int Ms = 0)
+                            int Bq_nominal, int scheme, int Mt = 0, int Ms = 0, int fixed_share = 0)
 {
     // Ps[b]: block rows of matrix b.  A heterogeneous batch (matrices of several chunks) walks the block
     // rows of all its matrices together; a matrix simply drops out once its rows are used up.
@@ -1838,7 +1853,11 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
             live = Bq_nominal;
         }
         const int Bq = live;
-        const int S_off = dag_split_factor((int)row_tiles, q, workers, scheme, (int)Ps.size());
+        // (fixed_share > 0: per matrix, from its own size only)
+        auto s_off = [&](int b) {
+            return fixed_share > 0 ? dag_split_factor(Ps[b] + Mt - q, q, fixed_share, scheme, 1)
+                                   : dag_split_factor((int)row_tiles, q, workers, scheme, (int)Ps.size());
+        };
         // latency scheme: DIAG(q) also solves the tile right of the diagonal (DAG_FUSED) whenever a next
         // diagonal tile exists, and DIAG(q >= 1) waits only for that tile of the row above (DAG_WAITNEXT)
         // scheme 2 ("following"): from block row 2 on -- where the diagonal task is the fused fast one, which publishes its
@@ -1902,7 +1921,9 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
         // Latency scheme: the PART that needs the block row just above (panel q-1, available only when ALL
         // of row q-1 is finished) is one panel long; the long ones cover [0, q-1) and run a row earlier.
         if (q + 1 < P && q >= 1) {
-            const int S_pre = dag_split_factor(Bq, q, workers / 4 > 0 ? workers / 4 : 1, scheme, (int)Ps.size());
+            const int S_pre = fixed_share > 0
+                                  ? dag_split_factor(1, q, fixed_share / 4 > 0 ? fixed_share / 4 : 1, scheme, 1)
+                                  : dag_split_factor(Bq, q, workers / 4 > 0 ? workers / 4 : 1, scheme, (int)Ps.size());
             for (int b : mats) {
                 if (q + 1 >= Ps[b]) continue;
                 const unsigned int ctr = plan.n_ctrs++;
@@ -1968,7 +1989,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
         for (int b : mats)
             for (int j = q + 1; j < Ps[b] + Mt && q < Ps[b]; ++j) {
                 const bool owner = cont0 && j == q + 1 && q + 1 < Ps[b];     // its workgroup goes on with DIAG(q+1)
-                dag_emit(plan, DAG_OFF, b, q, j, 0, q, S_off, scheme,
+                dag_emit(plan, DAG_OFF, b, q, j, 0, q, s_off(b), scheme,
                          following ? (unsigned char)(DAG_WAITNEXT | (xlink(q) ? DAG_FUSED : 0) |
                                                      ((j == q + 1 && q + 1 < Ps[b]) ? DAG_NOSOLVE : 0))
                                    : (unsigned char)(((j == q + 1 && fused(b)) ? DAG_NOSOLVE : 0) | (owner ? DAG_FUSED : 0)),
@@ -2025,10 +2046,13 @@ inline int dag_auto_scheme(const std::vector<int>& Ps)
 #endif
     return latency;
 }
-inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int scheme = -1, int Mt = 0, int Ms = 0)
+// fixed_share > 0: the fixed plan (dag_fixed_plan) -- scheme 0, every matrix cut as ONE matrix on `fixed_share` workgroups
+inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int scheme = -1, int Mt = 0, int Ms = 0,
+                               int fixed_share = 0)
 {
     DagPlan plan;
     const int B = (int)Ps.size();
+    if (fixed_share > 0) scheme = 0;
     if (scheme < 0) scheme = dag_auto_scheme(Ps);
 #ifndef PSOAP_FOLLOW
     if (scheme == 2) scheme = 1;       // the following scheme needs the kernels built with -DPSOAP_FOLLOW
@@ -2041,7 +2065,7 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
         plan.queues.first[g] = (unsigned int)plan.tasks.size();
         std::vector<int> mats;
         for (int b = g; b < B; b += DAG_QUEUES) mats.push_back(b);
-        dag_build_queue(plan, mats, Ps, per_queue, (B + DAG_QUEUES - 1) / DAG_QUEUES, scheme, Mt, Ms);
+        dag_build_queue(plan, mats, Ps, per_queue, (B + DAG_QUEUES - 1) / DAG_QUEUES, scheme, Mt, Ms, fixed_share);
         if (scheme >= 1) {
             // Latency scheme: hand the tasks out in order of READINESS instead of block row by block row.
             // A task over panels [pa, pb) can run once block row pb-1 is finished ("stage" pb); within a
@@ -2158,13 +2182,14 @@ inline double dag_batch_flops(const std::vector<int>& Ps, int Mt = 0)
 // workgroups' share of one lane): with other matrices in other phases always in flight, sparse block
 // rows need not fill the device by themselves, and every part saved is a partial tile that does not travel (measured:
 // 38.5 -> 38.2 ms per 32-walker step).
-constexpr int STREAM_NOMINAL_LANES = 32;
 inline DagPlan dag_build_lane_plan(int P, int lanes, int workers, int scheme, bool bursts = true)
 {
     (void)lanes;
-    int share = workers / STREAM_NOMINAL_LANES > 0 ? workers / STREAM_NOMINAL_LANES : 1;
-    if (scheme == 0) share = share / 2 > 0 ? share / 2 : 1;
-    DagPlan plan = dag_build_tasks(std::vector<int>(1, P), share, scheme);
+    // (scheme 0: dag_nominal_share -- half the workgroups' share of one of 32 lanes: the fixed plan, also what a batch
+    // launch gets under PSOAP_FIXED_PLAN=1)
+    const int share15 = workers / STREAM_NOMINAL_LANES > 0 ? workers / STREAM_NOMINAL_LANES : 1;
+    DagPlan plan = scheme == 0 ? dag_build_tasks(std::vector<int>(1, P), share15, 0, 0, 0, dag_nominal_share(workers))
+                               : dag_build_tasks(std::vector<int>(1, P), share15, scheme);
     const bool rows = plan.scheme == 0 && DAG_TILE_DEPS;
     auto section = [](const DagTask& t) { return (t.q == t.j && t.q > 0) ? (int)t.q - 1 : (int)t.q; };
     for (size_t i = 0; i < plan.tasks.size(); ++i) {

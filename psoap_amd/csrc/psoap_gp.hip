@@ -774,7 +774,9 @@ static int dag_prepare(psoap_chunk* h)
     const char* env_scheme = getenv("PSOAP_DAG_SCHEME");
     const std::vector<int> Ps((size_t)sl.B, h->P);
     const int workers = dag_pick_workers(dag_batch_flops(Ps), h->P, h->n_cus, h->dag_grid, (int)Ps.size());
-    DagPlan plan = dag_build_tasks(Ps, workers, env_scheme ? atoi(env_scheme) : -1);
+    // (PSOAP_FIXED_PLAN=1: the task structure of a stream lane for every matrix, whatever the batch -- dag_fixed_plan)
+    DagPlan plan = dag_build_tasks(Ps, workers, env_scheme ? atoi(env_scheme) : -1, 0, 0,
+                                   dag_fixed_plan() ? dag_nominal_share(h->dag_grid - 1) : 0);
     if (plan.n_ctrs > h->arrive_cap) FAIL("internal: arrival counter capacity exceeded");
     if (plan.tasks.size() > h->tasks_cap) {
         if (h->dTasks) HIP_TRY(hipFree(h->dTasks));
@@ -1058,7 +1060,8 @@ extern "C" int psoap_group_eval(psoap_group* g)
         int Pmax = 0;
         for (int P : Ps) Pmax = P > Pmax ? P : Pmax;
         g->workers = dag_pick_workers(dag_batch_flops(Ps), Pmax, g->hs[0]->n_cus, g->hs[0]->dag_grid, (int)Ps.size());
-        DagPlan plan = dag_build_tasks(Ps, g->workers, env_scheme ? atoi(env_scheme) : -1);
+        DagPlan plan = dag_build_tasks(Ps, g->workers, env_scheme ? atoi(env_scheme) : -1, 0, 0,
+                                       dag_fixed_plan() ? dag_nominal_share(g->hs[0]->dag_grid - 1) : 0);
         if ((size_t)total > g->mats_cap) {
             if (g->dMats) HIP_TRY(hipFree(g->dMats));
             g->dMats = nullptr;

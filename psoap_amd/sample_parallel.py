@@ -27,7 +27,7 @@ import numpy as np
 from . import data as pdata
 from . import priors as ppriors
 from . import utils
-from .ensemble import gather_chunk_lnprobs, owned_chunks, sum_over_chunks
+from .ensemble import _NoLock, gather_chunk_lnprobs, owned_chunks, sum_over_chunks
 from .samplers import MultiChainMHSampler
 
 
@@ -91,6 +91,7 @@ class Posterior:
                                    fix_params=self.fix_params, defaults=self.parameters, max_batch=self.max_batch,
                                    device=device_index, soften=soften)
         self.workers = {k: make_worker(chunks[k]) for k in self.mine}
+        self.device_lock = _NoLock()      # ensemble.SharedDeviceLock in dry runs with several ranks on one GPU
         # several chunks on this GPU: ONE launch of the persistent kernel over all of them per evaluation
         self.group = None
         if len(self.mine) > 1 and all(hasattr(w, "upload_proposals") and hasattr(w, "handle") for w in self.workers.values()):
@@ -120,17 +121,18 @@ class Posterior:
             Pev = P.copy()
             Pev[~ok] = P[ok][0]
             block = np.empty((len(self.mine), B))
-            for s in range(0, B, self.max_batch):
-                piece = Pev[s:s + self.max_batch]
-                if self.group is not None:
-                    for k in self.mine:
-                        self.workers[k].upload_proposals(piece)
-                    self.group.eval()
-                    for i, k in enumerate(self.mine):
-                        block[i, s:s + self.max_batch] = self.workers[k].handle.fetch()
-                else:
-                    for i, k in enumerate(self.mine):
-                        block[i, s:s + self.max_batch] = self.workers[k].lnprob_batch(piece)
+            with self.device_lock:
+                for s in range(0, B, self.max_batch):
+                    piece = Pev[s:s + self.max_batch]
+                    if self.group is not None:
+                        for k in self.mine:
+                            self.workers[k].upload_proposals(piece)
+                        self.group.eval()
+                        for i, k in enumerate(self.mine):
+                            block[i, s:s + self.max_batch] = self.workers[k].handle.fetch()
+                    else:
+                        for i, k in enumerate(self.mine):
+                            block[i, s:s + self.max_batch] = self.workers[k].lnprob_batch(piece)
             table = gather_chunk_lnprobs(block, self.n_chunks, self.world, self.rank, self.device_index)
             out[ok] = (sum_over_chunks(table) + lnprior)[ok]
         return out
@@ -140,7 +142,7 @@ class Posterior:
 
 
 def run(config, chunks, run_index=0, n_chains=1, seed=None, world=1, rank=0, device_index=None, iterations=None,
-        config_path=None, make_worker=None, prior=None, verbose=True, overwrite=False):
+        config_path=None, make_worker=None, prior=None, verbose=True, overwrite=False, device_lock=None):
     """Sample ``n_chains`` chains for ``config['samples']`` iterations; returns the sampler.
 
     Chain b uses ``RandomState(seed + b)`` when ``seed`` is given (fresh entropy otherwise -- then every
@@ -172,6 +174,8 @@ def run(config, chunks, run_index=0, n_chains=1, seed=None, world=1, rank=0, dev
                               + ", ".join(taken))
     post = Posterior(model, chunks, fix, pars, soften=config.get("soften", 1.0), max_batch=n_chains, world=world,
                      rank=rank, device_index=device_index, prior=prior, make_worker=make_worker)
+    if device_lock is not None:
+        post.device_lock = device_lock
     try:
         if verbose and rank == 0:
             print("Trying first evaluation")

@@ -265,6 +265,52 @@ def test_bench_eight_ranks_gloo_dry_run():
     assert st["chunks_per_rank"] == [1] * 8 and st["parity_table"] == [8, 4] and st["parity_checked"] is True
 
 
+# ---------------------------------------------------------------------------------------------- determinism across world sizes
+_CHAIN_CODE = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from psoap_amd import sample_parallel as sp
+from psoap_amd.ensemble import SharedDeviceLock
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo")
+config = sp.load_config(%r)
+config["outdir"] = config["outdir"] + "_w%%d" %% world
+chunks = sp.load_chunks(config, prefix=%r)
+s = sp.run(config, chunks, run_index=0, n_chains=3, seed=33, world=world, rank=rank, device_index=0, iterations=50,
+           verbose=False, device_lock=SharedDeviceLock(0))
+if rank == 0:
+    print("RESULT " + json.dumps({"chain": [float(x).hex() for x in s.chain.ravel()],
+                                  "lnp": [float(x).hex() for x in s.lnprobability.ravel()],
+                                  "accepted": [int(a) for a in s.naccepted]}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_fixed_plan_chain_is_the_same_chain_on_one_and_on_two_ranks(tmp_path):
+    """PSOAP_FIXED_PLAN=1: the per-chunk lnprobs are bit-identical whatever the launch they were computed in, so the
+    fixed-order sum over chunks -- and an MH chain of 50 steps decided by it -- is the same on one rank (both chunks in
+    one group launch, the start-up evaluation a batch of one) and on two (one chunk each).  The reference's np.sum
+    over its workers' values is deterministic for any process count (psoap/sample_parallel.py:387)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_sampler import _write_dataset
+    _write_dataset(tmp_path)
+    prog = tmp_path / "chain_prog.py"
+    prog.write_text(_CHAIN_CODE % (ROOT, os.path.join(ROOT, "tests"), str(tmp_path / "config.yaml"), str(tmp_path) + "/"))
+    outs = {}
+    for world in (1, 2):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               f"--nproc-per-node={world}", str(prog)]
+        env = dict(os.environ, OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0", PSOAP_FIXED_PLAN="1")
+        res, first = _run_retry_rendezvous_only(cmd, capture_output=True, text=True, timeout=1500, env=env)
+        assert res.returncode == 0, (first, res.stdout[-1500:], res.stderr[-3000:])
+        outs[world] = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):])
+    assert outs[1]["chain"] == outs[2]["chain"] and outs[1]["lnp"] == outs[2]["lnp"] and outs[1]["accepted"] == outs[2]["accepted"]
+    assert 0 < sum(outs[1]["accepted"]) < 150
+
+
 # ---------------------------------------------------------------------------------------------- forced split schemes
 @pytest.mark.parametrize("scheme", ["0", "1", "2"])
 def test_parity_under_forced_split_scheme(scheme):
