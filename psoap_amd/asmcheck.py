@@ -33,6 +33,8 @@ _VWRITE = re.compile(r"^(v_|scratch_load|global_load|flat_load|ds_read|ds_bpermu
 # no vector destination, or (v_writelane: an SGPR spill into ONE lane) a write that ignores the exec mask
 _NO_VDST = re.compile(r"^(v_cmp|v_cmpx|v_readlane|v_readfirstlane|v_writelane|global_load_lds|v_nop)")
 _EXEC_RESTORE = re.compile(r"^s_or_b64\s+exec,\s*(exec,\s*s\[\d+:\d+\]|s\[\d+:\d+\],\s*exec)")
+# the other ways this compiler re-enables lanes at a join: a plain copy of the saved mask, or-and-save (the else mask)
+_EXEC_RESTORE_ALT = re.compile(r"^(s_mov_b64\s+exec,\s*s\[\d+:\d+\]|s_or_saveexec_b64\s+s\[\d+:\d+\],\s*s\[\d+:\d+\])")
 _BRANCH_Z = re.compile(r"^s_cbranch_execz\s+(\S+)")
 _LABEL = re.compile(r"^([A-Za-z_.$][\w.$]*):")
 
@@ -53,7 +55,13 @@ def short(mangled: str | None) -> str:
 def scan_exec_restore(text: str):
     """-> [(function, join block, line of its label, [(line, instruction), ...]), ...]: the join blocks -- targets of an
     ``s_cbranch_execz``, or the fall-through exit of a loop closed by ``s_cbranch_execnz`` -- in which an instruction that
-    writes a vector register sits ahead of the ``s_or_b64 exec, exec, s[..]`` that re-enables the lanes."""
+    writes a vector register sits ahead of the instruction that re-enables the lanes (``s_or_b64 exec, exec, s[..]``,
+    ``s_mov_b64 exec, s[..]``, ``s_or_saveexec_b64``).
+
+    SCOPE: this finds ONE code shape -- the one the defect was traced to -- inside one basic block.  A clean scan says
+    that shape is absent, not that the binary is free of exec-mask defects: a restore behind an intermediate label or
+    branch, or through another instruction form, is not followed.  The evidence that the shipped code shapes are sound
+    is the GPU variant matrix (tools/lat_variants.py: 68 builds, prediction against outcome) and the GPU suites."""
     code = [ln.split(";")[0].strip() for ln in text.split("\n")]
     fn_of = []
     cur = None
@@ -84,7 +92,7 @@ def scan_exec_restore(text: str):
             if _LABEL.match(s2):
                 break
             op = s2.split()[0]
-            if _EXEC_RESTORE.match(s2):
+            if _EXEC_RESTORE.match(s2) or _EXEC_RESTORE_ALT.match(s2):
                 if pend:
                     hits.append((fn_of[n], name, n + 1, pend))
                 break

@@ -139,6 +139,9 @@ def compile_checked(extra: list[str], out_dir: str, verbose: bool = False, scan=
         with open(asm_path) as fh:
             hits = scan(fh.read())
         tried.append((flags, hits))
+        if verbose and not hits:
+            print("  assembly scan clean (asmcheck.scan_exec_restore: the ONE known code shape of the exec-restore defect, "
+                  "within basic blocks; not a proof of absence)")
         if hits:
             if verbose:
                 for fn, label, line, pend in hits:

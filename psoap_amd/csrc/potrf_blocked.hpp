@@ -141,7 +141,10 @@ __device__ __forceinline__ void chol16(d4& t, d4& w, int lane, int& bad, SM sm =
 
 // one finished block of W into the k-major operand Wt[e][i] = W[i][e] of the strip solve, transposed
 // through a per-wave LDS scratch so the global stores are 128-byte row segments
-template <class SM = SmemKernel>
+// COUNTED: the caller counts this routine's global stores in an s_waitcnt vmcnt(N) (potrf_spine.hpp, pub_flag): exactly
+// four store instructions, which relaxed wavefront-scope atomic stores guarantee -- same instruction as a plain store,
+// but the compiler may neither merge nor split nor drop them.
+template <class SM = SmemKernel, bool COUNTED = false>
 __device__ __forceinline__ void emit_w(const d4& w, int I, int J, int lane, int wave, double* Wm, SM sm = SM())
 {
     const int q = lane >> 4, c = lane & 15;
@@ -150,7 +153,12 @@ __device__ __forceinline__ void emit_w(const d4& w, int I, int J, int lane, int 
     for (int r = 0; r < 4; ++r) tr[(q + 4 * r) * 17 + c] = w[r];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Wm[(size_t)(16 * J + q + 4 * r) * NB + 16 * I + c] = tr[c * 17 + q + 4 * r];
+    for (int r = 0; r < 4; ++r) {
+        double* dst = &Wm[(size_t)(16 * J + q + 4 * r) * NB + 16 * I + c];
+        const double v = tr[c * 17 + q + 4 * r];
+        if constexpr (COUNTED) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        else *dst = v;
+    }
     __builtin_amdgcn_wave_barrier();
 }
 

@@ -127,8 +127,15 @@ __device__ __forceinline__ void pub_block(const SpinePub& pub, int b, int J, int
 // issued AFTER the stores the flag vouches for (they may still be in flight: stores complete in issue order, and these
 // waves issue nothing but stores inside the step loop).  Waiting for everything instead stalled every wave of the
 // factorisation by ~1.3 us per step -- the write-through stores take longer than a step to be acknowledged.
+// The count is exact by construction: every operation between the vouched-for stores and the wait is a relaxed ATOMIC
+// store (pub_block; pb::emit_w<.., COUNTED>), four per block, which the compiler can neither merge nor drop -- a wait
+// for `younger` outstanding operations would otherwise let vouched-for stores stay in flight if fewer had been emitted.
+// -DPSOAP_PUB_WAIT_ALL: wait for everything (the knob to rule the counting out when a result is in doubt).
 __device__ __forceinline__ void pub_flag(const SpinePub& pub, int wave, int n_steps, int lane, int younger = 0)
 {
+#ifdef PSOAP_PUB_WAIT_ALL
+    younger = 0;
+#endif
     switch (younger) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
@@ -344,7 +351,7 @@ __device__ __forceinline__ void worker(double* Km, int ld, int k0, double* Wm, d
         // in wave 1, the four stores of W_(bb-1) at the end of the previous step
         if (pub.mb && bb > 0) pub_flag(pub, W, bb, lane, 4 * pub_count(W, bb) + (W == 1 ? 4 : 0));
         // W_bb itself (parked by the spine in the row buffer) goes out to memory from here, off the spine's chain
-        if (W == 1) pb::emit_w(pb::load_blk(row_off(bb) + bb * BLK, lane, sm), bb, bb, lane, 1, Wm, sm);
+        if (W == 1) pb::emit_w<SM, true>(pb::load_blk(row_off(bb) + bb * BLK, lane, sm), bb, bb, lane, 1, Wm, sm);
     }
     if (pub.mb) pub_flag(pub, W, 8, lane);
     double zz = 0.0;

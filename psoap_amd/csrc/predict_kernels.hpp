@@ -328,6 +328,19 @@ inline void factor_augmented(hipStream_t st, double* dK, size_t ld, int P, int M
 // thread while the GPU is still factoring, the copy then runs at the link rate (1.4 ms) straight into it, and the
 // registration is dropped afterwards (10 us).  (Round 3 first built a pinned bounce buffer emptied by 16 host threads:
 // 1.7 ms on one box, 3.7 ms on another -- NUMA placement of buffer and threads.)  Small outputs skip all that.
+// Prior variance of prediction column q: the squared amplitudes of the components that contribute to it (fill_V11_* put
+// amp^2 on the diagonal), + the 1e-8 nugget of predict_f_g_sum.  ONE routine for the diagonal of the fused Sigma and for
+// psoap_*_predict_var, with FMA contraction off: both round alike (and like the reference's a*a + b*b).
+inline double predict_prior_variance(int mode, int c, int M, int q, const double* gp)
+{
+#pragma clang fp contract(off)
+    if (mode == 0) return gp[2 * (q / M)] * gp[2 * (q / M)];
+    double a2 = gp[0] * gp[0];
+    for (int k = 1; k < c; ++k) a2 = a2 + gp[2 * k] * gp[2 * k];
+    if (mode == 1 && c == 2) a2 = a2 + 1e-8;
+    return a2;
+}
+
 struct SigmaPin {
     double* ptr = nullptr;
     size_t bytes = 0;
@@ -335,6 +348,8 @@ struct SigmaPin {
     std::thread th;
     std::atomic<int> ok{0};
     bool started = false;
+    hipStream_t copy_stream = nullptr;      // an asynchronous copy INTO the array was queued on this stream
+    bool copy_queued = false;
     static constexpr size_t MIN_BYTES = (size_t)4 << 20;
 
     void start(double* out, size_t n_bytes, int dev)
@@ -355,9 +370,17 @@ struct SigmaPin {
         if (started && th.joinable()) th.join();
         return ok.load(std::memory_order_acquire) != 0;
     }
+    void queued_on(hipStream_t s)
+    {
+        copy_stream = s;
+        copy_queued = true;
+    }
     void release()
     {
         if (started && th.joinable()) th.join();
+        // (an early return may come here with the DMA into the array still in flight: the registration outlives it)
+        if (copy_queued) (void)hipStreamSynchronize(copy_stream);
+        copy_queued = false;
         if (ok.load()) (void)hipHostUnregister(ptr);
         ok.store(0);
         started = false;
@@ -501,18 +524,7 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
                     const double x = h_colx[(size_t)cc * Rq_pad + q];
                     h_rowx[(size_t)cc * Rq_pad + q] = (x == 1e30) ? -1e30 : x;
                 }
-            for (int q = 0; q < Rq_pad; ++q) {
-                double a2 = 0.0;
-                if (q < Rq) {
-                    if (mode == 0) a2 = gp[2 * (q / M)] * gp[2 * (q / M)];
-                    else {
-                        a2 = gp[0] * gp[0];
-                        for (int k = 1; k < c; ++k) a2 = a2 + gp[2 * k] * gp[2 * k];
-                        if (mode == 1 && c == 2) a2 = a2 + 1e-8;
-                    }
-                }
-                h_diag[q] = a2;
-            }
+            for (int q = 0; q < Rq_pad; ++q) h_diag[q] = q < Rq ? predict_prior_variance(mode, c, M, q, gp) : 0.0;
             PR_TRY(ws.Rowx.need((size_t)c * Rq_pad));
             PR_TRY(ws.Diag.need(Rq_pad));
             PR_TRY(ws.S.need((size_t)Rq_pad * Rq_pad));
@@ -620,9 +632,11 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         // the download, queued right behind the product on the same stream: into the page-locked caller's array when the
         // registration went through (it did its work under the factorisation), through the runtime's staging otherwise
         const bool locked = pin.wait();
-        if (locked)
+        if (locked) {
+            pin.queued_on(st);
             PR_TRY(hipMemcpy2DAsync(Sigma_out, sizeof(double) * Rq, dS, sizeof(double) * Rq_pad, sizeof(double) * Rq, (size_t)Rq,
                                     hipMemcpyDeviceToHost, st));
+        }
         sigma_direct = locked;
     }
     if (var_out) {
@@ -631,17 +645,7 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         PR_TRY(ws.Var.need(Rq_pad));
         PR_TRY(ws.Prior.need(Rq_pad));
         double* h_prior = h_mu + Rq_pad + 8;          // behind h_mu and h_acc in the pinned staging block
-        for (int q = 0; q < Rq; ++q) {
-            double a2 = 0.0;
-            if (mode == 0) a2 = gp[2 * (q / M)] * gp[2 * (q / M)];
-            else {
-#pragma clang fp contract(off)
-                a2 = gp[0] * gp[0];
-                for (int k = 1; k < c; ++k) a2 = a2 + gp[2 * k] * gp[2 * k];
-                if (mode == 1 && c == 2) a2 = a2 + 1e-8;
-            }
-            h_prior[q] = a2;
-        }
+        for (int q = 0; q < Rq; ++q) h_prior[q] = predict_prior_variance(mode, c, M, q, gp);
         PR_TRY(hipMemcpyAsync(ws.Prior, h_prior, sizeof(double) * Rq, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_colnorm_partial, dim3((Rq + 127) / 128, nslab), dim3(256), 0, st, dK + Npad, ld, Npad, Rq, dPart);
         hipLaunchKernelGGL(k_var_finish, dim3((Rq + 255) / 256), dim3(256), 0, st, dPart, nslab, Rq, ws.Prior.p, ws.Var.p);

@@ -18,7 +18,12 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-needs_hipcc = pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc")
+def _have_hipcc():
+    from psoap_amd import build
+    return shutil.which(build.hipcc()) is not None          # (the HIPCC variable, as the build itself resolves it)
+
+
+needs_hipcc = pytest.mark.skipif(not _have_hipcc(), reason="needs hipcc")
 
 
 @needs_hipcc

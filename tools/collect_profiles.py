@@ -18,6 +18,14 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles")
 KERNEL = "k_chol_dag"
+# round 4: the dominant kernel is the RESIDENT launch, k_chol_dag<2, false, false, true> (STREAM); bench.py --steps 5
+# --warmup 5 gives it 160 evaluations per dispatch
+EVALS_PER_DISPATCH = 160
+
+
+def is_stream(name):
+    head = name.split("(")[0].replace(" ", "")
+    return "k_chol_dag" in head and head.endswith(",true>")
 
 
 def newest(pattern):
@@ -31,15 +39,31 @@ shutil.copy(newest("trace/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_kern
 if glob.glob(os.path.join(src, "trace_full/*/*_kernel_stats.csv")):
     shutil.copy(newest("trace_full/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats_full_bench.csv"))
 shutil.copy(os.path.join(src, f"summary_{tag}.md"), os.path.join(dst, f"{tag}_summary.md"))
+# every dispatch of the persistent kernels (resident and launch-per-step) from the kernel trace: the per-dispatch durations
+# the roofline of bench.py has to agree with
+trace_rows = list(csv.DictReader(open(newest("trace/*/*_kernel_trace.csv"))))
+with open(os.path.join(dst, f"{tag}_kernel_trace_dag.csv"), "w", newline="") as f:
+    keep_cols = ["Dispatch_Id", "Kernel_Name", "Start_Timestamp", "End_Timestamp", "Workgroup_Size", "Grid_Size", "VGPR_Count",
+                 "Scratch_Size", "LDS_Block_Size"]
+    cols = [c_ for c_ in keep_cols if c_ in trace_rows[0]]
+    w = csv.DictWriter(f, fieldnames=cols + ["Duration_ms"])
+    w.writeheader()
+    for r in trace_rows:
+        if KERNEL in r["Kernel_Name"]:
+            row = {c_: (r[c_].split("(")[0] if c_ == "Kernel_Name" else r[c_]) for c_ in cols}
+            row["Duration_ms"] = "%.4f" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+            w.writerow(row)
 means = {}
 for name in ("sq", "fetch", "write"):
     rows = list(csv.DictReader(open(newest(f"pmc_{name}/*/*_counter_collection.csv"))))
     keep = [r for r in rows if KERNEL in r["Kernel_Name"]]
+    stream_rows = [r for r in keep if is_stream(r["Kernel_Name"])]
+    dominant = stream_rows if stream_rows else keep
     with open(os.path.join(dst, f"{tag}_pmc_{name}.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         w.writeheader()
         w.writerows(keep)
-    for r in keep:
+    for r in dominant:
         means.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 fetch_kb = sum(means["FETCH_SIZE"]) / len(means["FETCH_SIZE"])
 write_kb = sum(means["WRITE_SIZE"]) / len(means["WRITE_SIZE"])
@@ -47,13 +71,14 @@ tpath = os.path.join(dst, f"{tag}_traffic.json")
 old = json.load(open(tpath)) if os.path.exists(tpath) else {
     "round": int(tag[1:]) if tag[1:].isdigit() else tag,
     "source": f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, "
-              "bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-strong)",
-    "kernel": "k_chol_dag<2, false, false>",
-    "workload": {"N": 6000, "components": 2, "walkers": 32, "mode": "dag"},
+              "bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-extras --no-strong)",
+    "kernel": "k_chol_dag<2, false, false, true> (the resident launch of bench.py --mode stream)",
+    "workload": {"N": 6000, "components": 2, "walkers": 32, "mode": "stream", "evaluations_per_launch": EVALS_PER_DISPATCH},
     "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16 B/lane coalesced reads); "
             "WRITE_SIZE taken as is"}
 old.update(fetch_size_kb_raw=fetch_kb, write_size_kb_raw=write_kb, fetch_correction=2.0,
-           hbm_bytes_per_launch=(2.0 * fetch_kb + write_kb) * 1024.0)
+           hbm_bytes_per_launch=(2.0 * fetch_kb + write_kb) * 1024.0,
+           hbm_bytes_per_evaluation=(2.0 * fetch_kb + write_kb) * 1024.0 / EVALS_PER_DISPATCH)
 json.dump(old, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=2)
 for a, b in ((f"latency_{tag}.jsonl", f"{tag}_latency_table.jsonl"), (f"bench_{tag}.json", f"{tag}_bench.json")):
     p = os.path.join(ROOT, "gpurun_out", a)

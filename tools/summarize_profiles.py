@@ -7,13 +7,15 @@ def one(pattern):
     return g[0] if g else None
 
 print(f"# rocprofv3 summary {tag}\n")
-print("Command profiled: `python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-strong` on one MI355X (ROCm 7.2): 32 walkers x SB2")
-print("N=6000 per step, so every k_chol_dag dispatch is the headline launch: 1 + 1 warm-up, 5 timed (H2D of the next")
-print("proposals under the evaluation), 1 + 5 proposals-resident, 1 event-profiled.  The k_stream_* / k_mfma_f64_peak /")
-print("k_tile_engine_bench kernels are the micro-benchmarks behind `measured_peak`.  The second trace (`trace_full`) is the")
-print("default `bench.py` with its side legs: the staged step that times k_fill_sym, predict at the retrieve shape")
-print("(k_chol_dag<3, true, true>, which since round 3 also computes Sigma as Schur-complement tasks), the configs[3] strong leg")
-print("(8 chunks x 32 walkers in one launch of k_chol_dag<2, false, false>: the one long dispatch of that kernel), the lnprob(p) and sampler legs.\n")
+print("Command profiled: `python3 bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-extras --no-strong` on one MI355X (ROCm 7.2): 32 walkers x SB2")
+print("N=6000 per step.  Round 4: the headline runs through ONE resident launch of `k_chol_dag<2, false, false, true>` (the last")
+print("template argument: STREAM) per region -- the warm-up's 5 steps and the timed region's 5 steps are one dispatch each, 160")
+print("evaluations per dispatch, so the dispatches of that kernel in this run are alike.  `k_chol_dag<2, false, false, false>` is the")
+print("launch-per-step path measured beside it (2 warm-up + 5 timed + 1 + 5 proposals-resident + 1 event-profiled dispatches of 32")
+print("evaluations).  The k_stream_* / k_mfma_f64_peak / k_tile_engine_bench kernels are the micro-benchmarks behind `measured_peak`")
+print("(libpsoap_bench.so).  The second trace (`trace_full`) is the default `bench.py` with its side legs: the staged step that times")
+print("k_fill_sym, predict at the retrieve shape (k_chol_dag<3, true, true, false>), the configs[3] strong leg (8 chunks x 32 walkers in")
+print("one launch of k_chol_dag<2, false, false, false>: the one long dispatch of that kernel), the lnprob(p) and sampler legs.\n")
 f = one("trace/**/*kernel_stats.csv")
 if f:
     print("## --kernel-trace --stats\n")
@@ -33,6 +35,24 @@ if f:
         if float(r["Percentage"]) >= 0.01:
             print(f"| {name} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
     print()
+
+f = one("trace/**/*kernel_trace.csv")
+if f:
+    def is_stream(name):
+        head = name.split("(")[0].replace(" ", "")
+        return "k_chol_dag" in head and head.endswith(",true>")
+    rows = [r for r in csv.DictReader(open(f)) if is_stream(r["Kernel_Name"])]
+    if rows:
+        print("## every dispatch of the resident (stream) kernel, from the kernel trace\n")
+        print("| dispatch | duration ms | evaluations (bench.py: 5 steps x 32) | algorithmic TFLOP/s | of 78.6 |")
+        print("|---|---|---|---|---|")
+        F = 6000.0 ** 3 / 3.0 + 2.0 * 6000.0 ** 2
+        for r in rows:
+            ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+            tf = 160 * F / (ms * 1e-3) / 1e12
+            print(f"| {r['Dispatch_Id']} | {ms:.3f} | 160 | {tf:.2f} | {tf / 78.6:.3f} |")
+        print()
+
 
 def counters(sub):
     f = one(f"{sub}/**/*counter_collection.csv")
