@@ -1426,8 +1426,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
             ticket = queues.first[g] + local;
         }
         if (__hip_atomic_fetch_or(&ctl->error, 0u, PSOAP_RLX_AGENT) != 0u) return;
+        // (ticket and matrix index are loop-carried since round 4 -- a strip solve continues into the next record, a stream
+        // keeps its lane: said to be wave-uniform HERE, so that the records below are scalar loads and the pointers in them
+        // scalars -- as loop-carried values the compiler kept copies of them in vector registers and spilled those)
+        ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
         const DagTask task = tasks[ticket];
         if constexpr (!STREAM) b = task.b;
+        b = __builtin_amdgcn_readfirstlane(b);
         if constexpr (STREAM) {
             // (the burst ends with the TICKET, whoever runs the task)
             if (!owned_run && (task.b & STREAM_BURST_END) && threadIdx.x == 0) stream_next_lane(st, b);
