@@ -725,6 +725,20 @@ def run_extras(args, h, chunk, gps, lwls, dev, mode):
     for _ in range(3):
         worker.lnprob_batch(pfit)
     ex["lnprob_of_p_evals_per_s"] = 3 * B / (time.perf_counter() - t2)
+    # ... and the same boundary through ONE resident launch: orbital parameters to the lanes, Kepler solve, |v| >= c rule
+    # and Doppler shift inside the launch (psoap_stream_submit_orbits), two half-ensembles in flight
+    from psoap_amd.chunk import StreamPipeline
+    lnp_batch = worker.lnprob_batch(pfit)
+    spipe = StreamPipeline(worker.handle, c, B, 2, submit=worker.stream_submit)
+    spipe.calibrate(pfit)
+    t2s = time.perf_counter()
+    spipe.start(pfit)
+    for _ in range(5):
+        lnp_s = spipe.step(pfit)
+    lnp_s = spipe.drain()
+    ex["lnprob_of_p_streamed_evals_per_s"] = 6 * B / (time.perf_counter() - t2s)
+    spipe.close()
+    require(close(lnp_s, lnp_batch), "lnprob(p) through the stream vs the batch path")
     # the sampler boundary (8(f) f-2): B Metropolis-Hastings chains in lock-step on that worker
     mh = MultiChainMHSampler(1e-6 * np.eye(pfit.shape[1]), pfit.shape[1], worker.lnprob_batch, B,
                              seeds=[7000 + b for b in range(B)])

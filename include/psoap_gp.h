@@ -259,6 +259,13 @@ int psoap_stream_open(psoap_chunk *h, int c, int lanes, int scheme);
 /* n proposals -- lwl (n, c, N), gp (n, 2c) as psoap_batch_upload -- into n free lanes; tickets[n] identify them.
  * Fails when fewer than n lanes are free. */
 int psoap_stream_submit(psoap_chunk *h, int n, const double *lwl, const double *gp, double mu_GP, long long *tickets);
+/* The same with radial velocities (n, c, n_epochs) -- the resident launch shifts the chunk's grid itself (as
+ * psoap_batch_upload_velocities: replicate_wls + lredshift, psoap/data.py:37,61) -- or with orbital parameters
+ * (n, n_orb(model)): Kepler solve per epoch, the |v| >= c_kms -> -inf rule (sample_parallel.py:183-187) and the shift
+ * inside the launch (as psoap_batch_upload_orbits).  psoap_chunk_set_grid / _set_dates BEFORE psoap_stream_open. */
+int psoap_stream_submit_velocities(psoap_chunk *h, int n, const double *vel, const double *gp, double mu_GP, long long *tickets);
+int psoap_stream_submit_orbits(psoap_chunk *h, int n, int model, const double *p_orb, const double *gp, double mu_GP,
+                               long long *tickets);
 /* blocks until the n results are there (any order of tickets); frees their lanes.  -inf for a negative hyper-parameter
  * (covariance.py:317) or a matrix that is not positive definite. */
 int psoap_stream_fetch(psoap_chunk *h, int n, const long long *tickets, double *out);

@@ -86,6 +86,9 @@ SIGNATURES = {
     "psoap_group_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
     "psoap_stream_open": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "psoap_stream_submit": (ctypes.c_int, [_vp, ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.POINTER(ctypes.c_longlong)]),
+    "psoap_stream_submit_velocities": (ctypes.c_int, [_vp, ctypes.c_int, _dp, _dp, ctypes.c_double, ctypes.POINTER(ctypes.c_longlong)]),
+    "psoap_stream_submit_orbits": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_double,
+                                                  ctypes.POINTER(ctypes.c_longlong)]),
     "psoap_stream_fetch": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), _dp]),
     "psoap_stream_wait_any": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), _ip]),
     "psoap_stream_ready": (ctypes.c_int, [_vp, ctypes.c_longlong, _ip]),

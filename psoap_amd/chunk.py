@@ -148,6 +148,31 @@ class ChunkHandle:
                                           tickets.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))), "psoap_stream_submit")
         return tickets
 
+    def stream_submit_velocities(self, velocities, gps, mu_GP: float = 1.0) -> np.ndarray:
+        """``velocities`` (n, c, n_epochs): the resident launch shifts the chunk's grid itself (``set_grid`` before
+        ``stream_open``)"""
+        vel = as_f64(velocities)
+        if vel.ndim != 3 or vel.shape[1:] != (self._stream_c, self.n_epochs):
+            raise ValueError(f"velocities must have shape (n, {self._stream_c}, {self.n_epochs}); call set_grid first")
+        n = vel.shape[0]
+        gps = as_f64(gps, (n, 2 * self._stream_c))
+        tickets = np.empty(n, dtype=np.int64)
+        check(self._L.psoap_stream_submit_velocities(self._h, n, dptr(vel), dptr(gps), float(mu_GP),
+                                                     tickets.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))),
+              "psoap_stream_submit_velocities")
+        return tickets
+
+    def stream_submit_orbits(self, model_id: int, p_orb, gps, mu_GP: float = 1.0) -> np.ndarray:
+        """orbital parameters (n, n_orb): Kepler solve, |v| >= c rule and Doppler shift inside the resident launch"""
+        p_orb = as_f64(np.atleast_2d(p_orb))
+        n = p_orb.shape[0]
+        gps = as_f64(gps, (n, 2 * self._stream_c))
+        tickets = np.empty(n, dtype=np.int64)
+        check(self._L.psoap_stream_submit_orbits(self._h, n, int(model_id), dptr(p_orb), dptr(gps), float(mu_GP),
+                                                 tickets.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong))),
+              "psoap_stream_submit_orbits")
+        return tickets
+
     def stream_fetch(self, tickets) -> np.ndarray:
         tickets = np.ascontiguousarray(tickets, dtype=np.int64)
         out = np.empty(tickets.shape[0])
@@ -252,28 +277,36 @@ class StreamPipeline:
 
     ``step`` returns the lnprob of the proposals submitted one call earlier, in walker order."""
 
-    def __init__(self, handle: ChunkHandle, c: int, walkers: int, groups: int = 2, scheme: int = -1):
+    def __init__(self, handle: ChunkHandle, c: int, walkers: int, groups: int = 2, scheme: int = -1, submit=None):
+        """``submit``: what turns the rows of a group into tickets -- default ``handle.stream_submit(lwls, gps, mu_GP)``;
+        e.g. ``handle.stream_submit_velocities`` or ``ChunkWorker.stream_submit`` (orbital parameters in): ``start`` /
+        ``step`` then take that callable's array arguments, each sliced by the group's rows."""
         if walkers % groups:
             raise ValueError("walkers must be a multiple of groups")
         self.h, self.c, self.walkers, self.groups = handle, int(c), int(walkers), int(groups)
         self.rows = [slice(g * walkers // groups, (g + 1) * walkers // groups) for g in range(groups)]
         handle.stream_open(c, walkers, scheme)
+        self._submit = submit if submit is not None else handle.stream_submit
         self.tickets = [None] * groups
         self.period = None             # seconds per ensemble step, measured by calibrate()
 
-    def calibrate(self, lwls, gps, mu_GP: float = 1.0, steps: int = 2) -> float:
+    def _go(self, g, arrays, mu_GP):
+        r = self.rows[g]
+        self.tickets[g] = self._submit(*[a[r] for a in arrays], mu_GP)
+
+    def calibrate(self, *arrays, mu_GP: float = 1.0, steps: int = 2) -> float:
         """Seconds per ensemble step in the steady state (a few untimed steps): what the start-up stagger is set from."""
         import time
-        self.start(lwls, gps, mu_GP, stagger=0.0)
-        self.step(lwls, gps, mu_GP)
+        self.start(*arrays, mu_GP=mu_GP, stagger=0.0)
+        self.step(*arrays, mu_GP=mu_GP)
         t0 = time.perf_counter()
         for _ in range(steps):
-            self.step(lwls, gps, mu_GP)
+            self.step(*arrays, mu_GP=mu_GP)
         self.period = (time.perf_counter() - t0) / steps
         self.drain()
         return self.period
 
-    def start(self, lwls, gps, mu_GP: float = 1.0, stagger: float | None = None):
+    def start(self, *arrays, mu_GP: float = 1.0, stagger: float | None = None):
         """Submit every group, group g a little later than group g - 1, so that the groups end up ``1 / groups`` of a
         period apart and their first block rows and tails never coincide.  While only k groups are in flight they have
         the whole device and advance ``groups / k`` times as fast as in the steady state: the k-th interval is
@@ -283,19 +316,19 @@ class StreamPipeline:
         if stagger is None:
             stagger = (self.period or 0.0) / self.groups ** 2
         t0 = time.perf_counter()
-        for g, r in enumerate(self.rows):
+        for g in range(self.groups):
             while time.perf_counter() - t0 < 0.5 * g * (g + 1) * stagger:
                 pass
-            self.tickets[g] = self.h.stream_submit(lwls[r], gps[r], mu_GP)
+            self._go(g, arrays, mu_GP)
 
-    def step(self, lwls, gps, mu_GP: float = 1.0) -> np.ndarray:
+    def step(self, *arrays, mu_GP: float = 1.0) -> np.ndarray:
         out = np.empty(self.walkers)
         for g, r in enumerate(self.rows):
             out[r] = self.h.stream_fetch(self.tickets[g])
-            self.tickets[g] = self.h.stream_submit(lwls[r], gps[r], mu_GP)
+            self._go(g, arrays, mu_GP)
         return out
 
-    def step_any_order(self, lwls, gps, mu_GP: float = 1.0) -> np.ndarray:
+    def step_any_order(self, *arrays, mu_GP: float = 1.0) -> np.ndarray:
         """The same step with the groups taken in the order in which they COMPLETE (``groups == walkers``: every chain
         resubmitted the moment its result is there -- independent chains): no lane waits for the slowest matrix of a
         group.  Every group is fetched and resubmitted exactly once per call."""
@@ -307,7 +340,7 @@ class StreamPipeline:
             g = left.pop(k)
             r = self.rows[g]
             out[r] = self.h.stream_fetch(self.tickets[g])
-            self.tickets[g] = self.h.stream_submit(lwls[r], gps[r], mu_GP)
+            self._go(g, arrays, mu_GP)
         return out
 
     def drain(self) -> np.ndarray:

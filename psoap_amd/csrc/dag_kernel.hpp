@@ -45,6 +45,7 @@
 #include "fill_kernels.hpp"
 #include "potrf_blocked.hpp"
 #include "potrf_spine.hpp"
+#include "orbit_kernels.hpp"
 
 namespace psoap {
 
@@ -977,7 +978,8 @@ struct alignas(64) StreamLane {
     unsigned long long stamp;       // when the lane's last burst was handed out (s_memrealtime; 0: none yet)
     unsigned int retired;           // tasks of the matrix that have RETIRED (their last store is out): the one that makes it
                                     // n_tasks reports the result -- see stream_retire
-    unsigned int pad[9];
+    unsigned int too_fast;          // an orbit submission with |v| >= c somewhere: the result is -inf (sample_parallel.py:186)
+    unsigned int pad[8];
 };
 constexpr unsigned short STREAM_BURST_END = 0x8000;   // DagTask::b of a lane's task list (the matrix index is the lane):
                                                       // the last ticket of a burst -- the next one starts a block row
@@ -1001,9 +1003,14 @@ struct alignas(64) StreamDev {
 };
 constexpr int STREAM_RING = 256;    // ring of submissions; at most `n_lanes` (<= 64) are ever outstanding
 constexpr int STREAM_MAX_LANES = 64;
+// what the host left in the lane's pinned buffer: the ln-wavelengths themselves (psoap_stream_submit), the radial
+// velocities per component and epoch -- the dispatcher shifts the chunk's grid (psoap_stream_submit_velocities;
+// replicate_wls + lredshift, psoap/data.py:37,61) --, or orbital parameters -- the dispatcher solves Kepler's equation
+// per epoch first (psoap_stream_submit_orbits; orbit.models[model](...).get_velocities(), sample_parallel.py:183-187)
+enum : int { STREAM_IN_LWL = 0, STREAM_IN_VELOCITIES = 1, STREAM_IN_ORBITS = 2 };
 struct StreamEntry {
     int lane;
-    int pad;
+    int kind;                       // STREAM_IN_* in the low byte, the orbit model (ORB_*) in the next
     double mu;
 };
 struct StreamResult {
@@ -1028,6 +1035,11 @@ struct StreamArgs {                 // kernel argument, by value
     const double* h_lw;             // pinned proposals, lane-major: C x N ln-wavelengths ...
     const double* h_gp;             // ... and 2 C hyper-parameters per lane
     const double* fl;               // the chunk's flux vector (device)
+    const double* grid;             // observed-frame ln-wavelengths, epoch of every pixel, observation dates (device;
+    const int32_t* epoch;           // psoap_chunk_set_grid / _set_dates) -- nullptr: only ln-wavelength submissions
+    const double* dates;
+    int n_epochs;
+    int h_stride;                   // doubles per lane in h_lw: max(C N, 16) -- ln-wavelengths, velocities or parameters
     unsigned int n_lanes, n_tasks, ctrs_per_lane, slots_per_lane;
     int C, N;
     unsigned int gate;              // scheme 0: 100 MHz ticks that have to lie between two bursts (block rows) of one lane
@@ -1193,8 +1205,9 @@ __device__ __forceinline__ void stream_complete(const StreamArgs& st, int lane, 
     const double qd = __hip_atomic_load(&acc->quad, PSOAP_RLX_AGENT);
     const double info = __hip_atomic_load(&acc->info, PSOAP_RLX_AGENT);
     const unsigned long long seq = __hip_atomic_load(&st.lanes[lane].seq, PSOAP_RLX_AGENT);
+    const unsigned int fast = __hip_atomic_load(&st.lanes[lane].too_fast, PSOAP_RLX_AGENT);
     StreamResult* res = &st.host->result[seq % STREAM_RING];
-    __hip_atomic_store(&res->lnp, stream_lnp(lh, qd, info != 0.0), PSOAP_RLX_SYSTEM);
+    __hip_atomic_store(&res->lnp, stream_lnp(lh, qd, info != 0.0 || fast != 0u), PSOAP_RLX_SYSTEM);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&res->seq1, seq + 1ull, PSOAP_RLX_SYSTEM);
@@ -1218,7 +1231,8 @@ __device__ __forceinline__ void stream_retire(const StreamArgs& st, int lane, Ma
 
 // Workgroup 0 of a streamed launch (all 256 threads): open lanes as the host publishes submissions, end the launch.
 __device__ __forceinline__ void stream_dispatch(const StreamArgs& st, const DagMat* __restrict__ mats, MatFlags* flags,
-                                                int* arrive, DagCtl* ctl, unsigned long long* box /* LDS, 4 words */)
+                                                int* arrive, DagCtl* ctl, unsigned long long* box /* LDS, 4 words */,
+                                                double* vbuf /* LDS: 3 x n_epochs velocities + 16 parameters */)
 {
     const int tid = threadIdx.x;
     unsigned long long opened = __hip_atomic_load(&st.dev->opened, PSOAP_RLX_AGENT);
@@ -1245,24 +1259,67 @@ __device__ __forceinline__ void stream_dispatch(const StreamArgs& st, const DagM
             break;
         }
         if (opened < head) {
+            int* const fastv = reinterpret_cast<int*>(vbuf + 3 * st.n_epochs + 16);      // per entry of this pass: |v| >= c
             // everything published so far in one go: the proposals of all its lanes first (one pass of PCIe pulls), ONE
             // drain and release (the write-back of this XCD's L2 is what a release costs), then the lanes open together
             const unsigned int nb = (unsigned int)(head - opened < (unsigned long long)st.n_lanes ? head - opened : st.n_lanes);
             bool bad = false;
             for (unsigned int k = 0; k < nb; ++k) {
                 const StreamEntry* e = &st.host->entry[(opened + k) % STREAM_RING];
-                const int lane = __hip_atomic_load(&e->lane, PSOAP_RLX_SYSTEM);
+                // (every thread reads the same entry: said to be wave-uniform, so that the branches below are scalar branches
+                // and not exec-masked regions -- the shape the build's assembly scan objects to)
+                const int lane = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&e->lane, PSOAP_RLX_SYSTEM));
+                const int kind_word = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&e->kind, PSOAP_RLX_SYSTEM));
+                const int kind = kind_word & 0xff, model = (kind_word >> 8) & 0xff;
                 const double mu = __hip_atomic_load(&e->mu, PSOAP_RLX_SYSTEM);
-                if (lane < 0 || lane >= (int)st.n_lanes) {         // a corrupt entry: refuse, loudly
-                    bad = true;
+                if (lane < 0 || lane >= (int)st.n_lanes || kind > STREAM_IN_ORBITS ||
+                    (kind != STREAM_IN_LWL && (!st.grid || !st.epoch || (kind == STREAM_IN_ORBITS && !st.dates)))) {
+                    bad = true;                                    // a corrupt entry: refuse, loudly
                     break;
                 }
                 const DagMat mat = mats[lane];
+                if (kind == STREAM_IN_LWL && tid == 0) fastv[k] = 0;
+                if (kind != STREAM_IN_LWL) {
+                    // velocities (C x n_epochs) into LDS -- from the host as they are, or from the orbital parameters
+                    // there with the arithmetic of k_orbit_velocities (one thread per epoch) -- then the Doppler
+                    // shift of the chunk's grid with the arithmetic of k_doppler_shift
+                    const double* src = st.h_lw + (size_t)lane * st.h_stride;
+                    const int nv = st.C * st.n_epochs;
+                    unsigned int fast = 0u;
+                    __syncthreads();                               // (vbuf of the previous entry has been read)
+                    if (tid == 0) fastv[k] = 0;
+                    if (kind == STREAM_IN_VELOCITIES) {
+                        for (int i = tid; i < nv; i += GEMM_THREADS) vbuf[i] = __hip_atomic_load(&src[i], PSOAP_RLX_SYSTEM);
+                    } else {
+                        const int np = orbit_n_params(model);
+                        double* par = vbuf + 3 * st.n_epochs;
+                        if (tid < np) par[tid] = __hip_atomic_load(&src[tid], PSOAP_RLX_SYSTEM);
+                        __syncthreads();
+                        for (int ep = tid; ep < st.n_epochs; ep += GEMM_THREADS) {
+                            double v[3];
+                            orbit_velocities_at(model, par, st.dates[ep], v);
+                            for (int k = 0; k < st.C; ++k) {
+                                vbuf[k * st.n_epochs + ep] = v[k];
+                                if (fabs(v[k]) >= C_KMS) fast = 1u;     // sample_parallel.py:186-187
+                            }
+                        }
+                    }
+                    if (fast) fastv[k] = 1;                        // (after the barrier above; every writer writes 1)
+                    __syncthreads();
+                    double* dst = const_cast<double*>(mat.lw);
+                    for (int k = 0; k < st.C; ++k)
+                        for (int i = tid; i < st.N; i += GEMM_THREADS) {
+                            const double v = vbuf[k * st.n_epochs + st.epoch[i]];
+                            dst[(size_t)k * st.N + i] = st.grid[i] + (-v) / C_KMS;
+                        }
+                    if (tid < 2 * st.C)
+                        const_cast<double*>(mat.gp)[tid] = __hip_atomic_load(&st.h_gp[(size_t)lane * 2 * st.C + tid], PSOAP_RLX_SYSTEM);
+                } else
                 // the proposal: pinned host memory -> the lane's device arrays (uncached system-scope loads, sixteen in
                 // flight per thread: one after the other, a lane's 96 KB took 48 PCIe round trips)
                 {
                     const size_t n = (size_t)st.C * st.N;
-                    const double* src = st.h_lw + (size_t)lane * n;
+                    const double* src = st.h_lw + (size_t)lane * st.h_stride;
                     double* dst = const_cast<double*>(mat.lw);
                     size_t i = tid;
                     for (; i + 15 * GEMM_THREADS < n; i += 16 * GEMM_THREADS) {
@@ -1300,6 +1357,7 @@ __device__ __forceinline__ void stream_dispatch(const StreamArgs& st, const DagM
                     __hip_atomic_store(&st.lanes[lane].seq, opened + k, PSOAP_RLX_AGENT);
                     __hip_atomic_store(&st.lanes[lane].stamp, 0ull, PSOAP_RLX_AGENT);
                     __hip_atomic_store(&st.lanes[lane].retired, 0u, PSOAP_RLX_AGENT);
+                    __hip_atomic_store(&st.lanes[lane].too_fast, (unsigned int)fastv[k], PSOAP_RLX_AGENT);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 for (unsigned int k = 0; k < nb; ++k) {
@@ -1348,7 +1406,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
     __shared__ int s_lane;
     if constexpr (STREAM) {
         if (blockIdx.x == 0) {
-            stream_dispatch(st, mats, flags, arrive, ctl, reinterpret_cast<unsigned long long*>(vec1));
+            stream_dispatch(st, mats, flags, arrive, ctl, reinterpret_cast<unsigned long long*>(vec1), psoap_smem);
             return;
         }
     }
@@ -2196,6 +2254,9 @@ inline DagPlan dag_build_lane_plan(int P, int lanes, int workers, int scheme, bo
     DagPlan plan = scheme == 0 ? dag_build_tasks(std::vector<int>(1, P), share15, 0, 0, 0, dag_nominal_share(workers))
                                : dag_build_tasks(std::vector<int>(1, P), share15, scheme);
     const bool rows = plan.scheme == 0 && DAG_TILE_DEPS;
+    // (schemes 1, 2: the list is in order of readiness already and its tasks are short -- the lanes ticket by ticket in turn
+    // measured 8 % faster at N = 2000, the same at N = 4096)
+    if (plan.scheme != 0) bursts = false;
     auto section = [](const DagTask& t) { return (t.q == t.j && t.q > 0) ? (int)t.q - 1 : (int)t.q; };
     for (size_t i = 0; i < plan.tasks.size(); ++i) {
         const bool last = i + 1 == plan.tasks.size();

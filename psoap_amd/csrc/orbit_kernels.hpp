@@ -48,17 +48,11 @@ __device__ inline double rv_term(double K, double e, double omega_deg, double f)
     return K * (cos(w + f) + e * cos(w));
 }
 
-__global__ void k_orbit_velocities(int model, int B, int n_epochs, const double* __restrict__ p_orb,
-                                   const double* __restrict__ dates, double* __restrict__ vel,
-                                   int* __restrict__ too_fast)
+// velocities of the c components of one proposal at one date (p: its orbit_n_params(model) parameters)
+__device__ inline void orbit_velocities_at(int model, const double* __restrict__ p, double t, double (&v)[3])
 {
-    const int ep = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = blockIdx.y;
-    if (ep >= n_epochs || b >= B) return;
-    const int np = orbit_n_params(model), c = orbit_n_components(model);
-    const double* p = p_orb + (size_t)b * np;
-    const double t = dates[ep];
-    double v[3] = {0.0, 0.0, 0.0};
+    const int c = orbit_n_components(model);
+    v[0] = v[1] = v[2] = 0.0;
     if (model == ORB_SB1) {                       // K, e, omega, P, T0, gamma
         const double f = true_anomaly(t, p[4], p[3], p[1]);
         v[0] = rv_term(p[0], p[1], p[2], f) + p[5];
@@ -83,6 +77,18 @@ __global__ void k_orbit_velocities(int model, int B, int n_epochs, const double*
         if (c >= 2) v[1] = rv_term(K_in / q_in, e_in, w_in + 180.0, f_in) + v3 + gamma;         // :364
         if (c == 3) v[2] = rv_term(K_out / q_out, e_out, w_out + 180.0, f_out) + gamma;         // :443-455
     }
+}
+
+__global__ void k_orbit_velocities(int model, int B, int n_epochs, const double* __restrict__ p_orb,
+                                   const double* __restrict__ dates, double* __restrict__ vel,
+                                   int* __restrict__ too_fast)
+{
+    const int ep = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (ep >= n_epochs || b >= B) return;
+    const int np = orbit_n_params(model), c = orbit_n_components(model);
+    double v[3];
+    orbit_velocities_at(model, p_orb + (size_t)b * np, dates[ep], v);
     bool fast = false;
     for (int k = 0; k < c; ++k) {
         vel[((size_t)b * c + k) * n_epochs + ep] = v[k];

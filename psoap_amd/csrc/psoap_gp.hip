@@ -80,6 +80,7 @@ namespace psoap { struct PredictWs; }
 struct StreamState {
     bool open = false;
     int C = 0, lanes = 0, scheme = 0;
+    size_t h_stride = 0;               // doubles per lane in hLw
     unsigned int n_tasks = 0, ctrs_per_lane = 0, slots_per_lane = 0;
     DagQueues queues{};
     DagTask* dTasks = nullptr;
@@ -1181,6 +1182,11 @@ static int stream_launch(psoap_chunk* h)
     a.h_lw = st.hLw;
     a.h_gp = st.hGp;
     a.fl = h->dFl;
+    a.grid = h->dGrid;                 // (nullptr without psoap_chunk_set_grid / _set_dates: ln-wavelength submissions only)
+    a.epoch = h->dEpoch;
+    a.dates = h->dDates;
+    a.n_epochs = h->n_epochs;
+    a.h_stride = (int)st.h_stride;
     a.n_lanes = (unsigned int)st.lanes;
     a.n_tasks = st.n_tasks;
     a.ctrs_per_lane = st.ctrs_per_lane;
@@ -1281,7 +1287,8 @@ static int stream_open_impl(psoap_chunk* h, int c, int lanes, int scheme)
     }
     HIP_TRY(hipHostMalloc(&st.hHost, sizeof(StreamHost), hipHostMallocCoherent));
     memset(st.hHost, 0, sizeof(StreamHost));
-    HIP_TRY(hipHostMalloc(&st.hLw, sizeof(double) * (size_t)lanes * c * h->N, hipHostMallocCoherent));
+    st.h_stride = (size_t)c * h->N > 16 ? (size_t)c * h->N : 16;      // (orbital parameters: up to 13 doubles)
+    HIP_TRY(hipHostMalloc(&st.hLw, sizeof(double) * (size_t)lanes * st.h_stride, hipHostMallocCoherent));
     HIP_TRY(hipHostMalloc(&st.hGp, sizeof(double) * (size_t)lanes * 2 * c, hipHostMallocCoherent));
     HIP_TRY(hipMalloc(&st.dWs, sizeof(double) * NB * NB * (size_t)st.slots_per_lane * lanes));
     st.arrive_off = sizeof(DagCtl) + sizeof(MatFlags) * (size_t)lanes;
@@ -1339,24 +1346,23 @@ extern "C" int psoap_stream_open(psoap_chunk* h, int c, int lanes, int scheme)
     return 0;
 }
 
-extern "C" int psoap_stream_submit(psoap_chunk* h, int n, const double* lwl, const double* gp, double mu_GP,
-                                   long long* tickets)
+// kind: STREAM_IN_LWL (payload (n, c, N) ln-wavelengths), STREAM_IN_VELOCITIES ((n, c, n_epochs)), STREAM_IN_ORBITS ((n, np))
+static int stream_submit_impl(psoap_chunk* h, int n, int kind, int model, const double* payload, size_t per, const double* gp,
+                              double mu_GP, long long* tickets, const char* who)
 {
-    if (!h || !lwl || !gp || !tickets || n < 1) FAIL("psoap_stream_submit: bad arguments");
     StreamState& st = h->stream;
-    if (!st.open) FAIL("psoap_stream_submit: no open stream (psoap_stream_open)");
+    if (!st.open) { g_err = std::string(who) + ": no open stream (psoap_stream_open)"; return 2; }
     if (set_dev(h)) return 1;
-    if (st.hHost->error != 0u) FAIL("psoap_stream_submit: the stream has failed (a dependency wait timed out); close it");
+    if (st.hHost->error != 0u) { g_err = std::string(who) + ": the stream has failed (a dependency wait timed out); close it"; return 2; }
     int free_lanes = 0;
     for (long long t : st.lane_ticket) free_lanes += (t < 0);
-    if (n > free_lanes) FAIL("psoap_stream_submit: not enough free lanes (fetch outstanding results first)");
+    if (n > free_lanes) { g_err = std::string(who) + ": not enough free lanes (fetch outstanding results first)"; return 2; }
     const int c = st.C;
-    const size_t nl = (size_t)c * h->N;
     int lane = 0;
     for (int k = 0; k < n; ++k) {
         while (st.lane_ticket[lane] >= 0) ++lane;
         const unsigned long long seq = st.head + (unsigned long long)k;
-        memcpy(st.hLw + (size_t)lane * nl, lwl + (size_t)k * nl, sizeof(double) * nl);
+        memcpy(st.hLw + (size_t)lane * st.h_stride, payload + (size_t)k * per, sizeof(double) * per);
         memcpy(st.hGp + (size_t)lane * 2 * c, gp + (size_t)k * 2 * c, sizeof(double) * 2 * c);
         char neg = 0;
         for (int i = 0; i < 2 * c; ++i)
@@ -1364,6 +1370,7 @@ extern "C" int psoap_stream_submit(psoap_chunk* h, int n, const double* lwl, con
         st.neg[seq % STREAM_RING] = neg;
         StreamEntry& e = st.hHost->entry[seq % STREAM_RING];
         e.lane = lane;
+        e.kind = kind | (model << 8);
         e.mu = mu_GP;
         st.hHost->result[seq % STREAM_RING].seq1 = 0ull;
         st.lane_ticket[lane] = (long long)seq;
@@ -1374,6 +1381,37 @@ extern "C" int psoap_stream_submit(psoap_chunk* h, int n, const double* lwl, con
     st.head += (unsigned long long)n;
     __atomic_store_n(&st.hHost->head, st.head, __ATOMIC_RELEASE);
     return stream_ensure_running(h);
+}
+
+extern "C" int psoap_stream_submit(psoap_chunk* h, int n, const double* lwl, const double* gp, double mu_GP,
+                                   long long* tickets)
+{
+    if (!h || !lwl || !gp || !tickets || n < 1) FAIL("psoap_stream_submit: bad arguments");
+    return stream_submit_impl(h, n, STREAM_IN_LWL, 0, lwl, (size_t)h->stream.C * h->N, gp, mu_GP, tickets, "psoap_stream_submit");
+}
+
+// radial velocities (n, c, n_epochs) instead of ln-wavelengths: the dispatcher shifts the chunk's grid (psoap_chunk_set_grid)
+extern "C" int psoap_stream_submit_velocities(psoap_chunk* h, int n, const double* vel, const double* gp, double mu_GP,
+                                              long long* tickets)
+{
+    if (!h || !vel || !gp || !tickets || n < 1) FAIL("psoap_stream_submit_velocities: bad arguments");
+    if (!h->dGrid) FAIL("psoap_stream_submit_velocities: call psoap_chunk_set_grid first (before psoap_stream_open)");
+    return stream_submit_impl(h, n, STREAM_IN_VELOCITIES, 0, vel, (size_t)h->stream.C * h->n_epochs, gp, mu_GP, tickets,
+                              "psoap_stream_submit_velocities");
+}
+
+// orbital parameters (n, orbit_n_params(model)): Kepler solve, |v| >= c rule and Doppler shift in the dispatcher
+extern "C" int psoap_stream_submit_orbits(psoap_chunk* h, int n, int model, const double* p_orb, const double* gp, double mu_GP,
+                                          long long* tickets)
+{
+    if (!h || !p_orb || !gp || !tickets || n < 1) FAIL("psoap_stream_submit_orbits: bad arguments");
+    if (!h->dGrid || !h->dDates)
+        FAIL("psoap_stream_submit_orbits: call psoap_chunk_set_grid and psoap_chunk_set_dates first (before psoap_stream_open)");
+    if (int rc = check_orbits(model, n, p_orb)) return rc;
+    if (h->stream.open && orbit_n_components(model) != h->stream.C)
+        FAIL("psoap_stream_submit_orbits: the model's number of components differs from the stream's");
+    return stream_submit_impl(h, n, STREAM_IN_ORBITS, model, p_orb, (size_t)orbit_n_params(model), gp, mu_GP, tickets,
+                              "psoap_stream_submit_orbits");
 }
 
 // 1: the result of `ticket` is there, 0: not yet (never blocks)

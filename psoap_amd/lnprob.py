@@ -42,6 +42,22 @@ class ChunkWorker:
               "psoap_batch_upload_orbits")
         h._B = B
 
+    # -- streamed form: ONE resident launch across sampler iterations (include/psoap_gp.h: psoap_stream_*) ----------
+    def stream_open(self, lanes: int | None = None, scheme: int = -1):
+        self.handle.stream_open(N_COMPONENTS[self.model], lanes, scheme)
+
+    def stream_submit(self, ps, mu_GP: float = 1.0) -> np.ndarray:
+        """fitted parameter vectors (n, n_fit) -> tickets; Kepler solve, |v| >= c rule, Doppler shift and likelihood all
+        inside the resident launch (``Worker.lnprob`` for n proposals, sample_parallel.py:168-198)"""
+        p_orb, p_gp = convert_vectors(np.atleast_2d(ps), self.model, self.fix_params, **self.defaults)
+        return self.handle.stream_submit_orbits(MODEL_ID[self.model], p_orb, p_gp, mu_GP)
+
+    def stream_fetch(self, tickets) -> np.ndarray:
+        return self.handle.stream_fetch(tickets)
+
+    def stream_close(self):
+        self.handle.stream_close()
+
     def lnprob_batch(self, ps, mu_GP: float = 1.0) -> np.ndarray:
         self.upload_proposals(ps, mu_GP)
         self.handle.eval()

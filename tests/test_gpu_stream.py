@@ -269,3 +269,55 @@ def test_fixed_plan_is_bit_identical_across_batch_sizes_groups_and_streams(monke
         ref = h.lnlike_batch(*props[0])
         one = np.array([h.lnlike_batch(props[0][0][b:b + 1], props[0][1][b:b + 1])[0] for b in range(B)])
     assert close(one, ref, 1e-13) and not np.array_equal(one, ref)
+
+
+def test_stream_velocity_and_orbit_submissions(monkeypatch):
+    """The other two forms a proposal can take (as psoap_batch_upload_velocities / _orbits): radial velocities -- the
+    resident launch shifts the chunk's grid -- and orbital parameters -- it solves Kepler's equation per epoch first and
+    applies the |v| >= c -> -inf rule (sample_parallel.py:183-187).  Against the batch path on the same inputs: within the
+    parity tolerance, and bit for bit under the fixed plan (same arithmetic, same order of summation)."""
+    from psoap_amd.chunk import ChunkHandle
+    from psoap_amd.lnprob import ChunkWorker
+    ch = syn.make_chunk(2, 8, 75, seed=610, masked_fraction=0.1)
+    B = 6
+    gps = syn.make_walkers(2, B, seed=9951)
+    vel = syn.make_walker_velocities(ch, B, seed=9952)
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
+        h.set_grid(ch.lwl, ch.epoch_index, len(ch.dates))
+        h.upload_velocities(vel, gps)
+        h.eval()
+        want = h.fetch()
+        h.stream_open(2, B)
+        got = h.stream_fetch(h.stream_submit_velocities(vel, gps))
+        also = h.stream_fetch(h.stream_submit(syn.walker_lwls(ch, vel), gps))
+        h.stream_close()
+    assert close(got, want) and np.array_equal(got, also)
+    P = syn.make_orbit_proposals("SB2", B, seed=611)
+    fit = np.hstack([P, gps])
+    fit[3, 1] = 4.0e5                              # K: faster than light -> -inf
+    fit[4, -1] = -1.0                              # l_g < 0 -> -inf
+    for fixed in ("0", "1"):
+        monkeypatch.setenv("PSOAP_FIXED_PLAN", fixed)
+        w = ChunkWorker("SB2", ch.lwl, ch.fl, ch.sigma, ch.epoch_index, ch.dates, max_batch=B)
+        try:
+            want = w.lnprob_batch(fit)
+            w.stream_open(B, 0 if fixed == "1" else -1)
+            got = w.stream_fetch(w.stream_submit(fit))
+            one = np.array([w.stream_fetch(w.stream_submit(fit[b:b + 1]))[0] for b in range(B)])
+            w.stream_close()
+        finally:
+            w.close()
+        assert np.isneginf(want[3]) and np.isneginf(want[4]) and np.isneginf(got[3]) and np.isneginf(got[4])
+        keep = np.array([0, 1, 2, 5])
+        assert close(got[keep], want[keep], 1e-10) and np.array_equal(one, got)
+        if fixed == "1":
+            assert np.array_equal(got[keep], want[keep])
+    # refusals: no grid / dates on the handle, a model with another component count
+    with ChunkHandle(ch.fl, ch.sigma, max_batch=2) as h:
+        h.stream_open(2, 2)
+        h.n_epochs = len(ch.dates)
+        with pytest.raises(PsoapError, match="set_grid"):
+            h.stream_submit_velocities(vel[:1], gps[:1])
+        with pytest.raises(PsoapError, match="set_grid"):
+            h.stream_submit_orbits(1, P[:1], gps[:1])
+        h.stream_close()
