@@ -8,6 +8,7 @@
 #include <stddef.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1425,6 +1426,14 @@ extern "C" int psoap_stream_ready(psoap_chunk* h, long long ticket, int* ready)
     return 0;
 }
 
+// A host-side bound on every wait for a result (seconds; PSOAP_STREAM_FETCH_TIMEOUT_S, default 120): the device's waits are
+// bounded and reported, but a result that never comes for any other reason must end in an error, not in a hung process.
+static double stream_fetch_timeout_s()
+{
+    const char* e = getenv("PSOAP_STREAM_FETCH_TIMEOUT_S");
+    return (e && atof(e) > 0.0) ? atof(e) : 120.0;
+}
+
 // blocks until ONE of the n tickets has its result; *which = its index in `tickets` (the lowest ready one)
 extern "C" int psoap_stream_wait_any(psoap_chunk* h, int n, const long long* tickets, int* which)
 {
@@ -1435,6 +1444,8 @@ extern "C" int psoap_stream_wait_any(psoap_chunk* h, int n, const long long* tic
     for (int k = 0; k < n; ++k)
         if (tickets[k] < 0 || (unsigned long long)tickets[k] >= st.head) FAIL("psoap_stream_wait_any: unknown ticket");
     long long spins = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    const double limit = stream_fetch_timeout_s();
     for (;;) {
         for (int k = 0; k < n; ++k) {
             const unsigned long long t = (unsigned long long)tickets[k];
@@ -1447,6 +1458,8 @@ extern "C" int psoap_stream_wait_any(psoap_chunk* h, int n, const long long* tic
             if (__atomic_load_n(&st.hHost->error, __ATOMIC_ACQUIRE) != 0u)
                 FAIL("psoap_stream_wait_any: a dependency wait in the resident kernel timed out (results invalid)");
             if (int rc = stream_ensure_running(h)) return rc;
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > limit)
+                FAIL("psoap_stream_wait_any: no result within PSOAP_STREAM_FETCH_TIMEOUT_S");
         }
 #if defined(__x86_64__)
         __builtin_ia32_pause();
@@ -1469,8 +1482,12 @@ extern "C" int psoap_stream_fetch(psoap_chunk* h, int n, const long long* ticket
             if (st.lane_ticket[l] == t) lane = l;
         if (lane < 0) FAIL("psoap_stream_fetch: the ticket was fetched before (or is too old)");
         long long spins = 0;
+        const auto t_begin = std::chrono::steady_clock::now();
+        const double limit = stream_fetch_timeout_s();
         while (__atomic_load_n(&st.hHost->result[idx].seq1, __ATOMIC_ACQUIRE) != (unsigned long long)t + 1ull) {
             if ((++spins & 1023) == 0) {
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > limit)
+                    FAIL("psoap_stream_fetch: no result within PSOAP_STREAM_FETCH_TIMEOUT_S (the stream is unusable: close it)");
                 if (__atomic_load_n(&st.hHost->error, __ATOMIC_ACQUIRE) != 0u) {
                     char buf[256];
                     snprintf(buf, sizeof buf,
