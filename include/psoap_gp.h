@@ -18,6 +18,14 @@
  * Threading: a handle may be used by one host thread at a time.  HIP is
  * initialised lazily by the first call in the calling process (safe after
  * fork(), as psoap/sample_parallel.py:258-278 requires).
+ *
+ * Several processes on one GPU (that reference's worker-per-chunk model with
+ * more chunks than GPUs): the library serves them in turn -- an advisory lock
+ * on /tmp/psoap_gpu_<PCI bus id>.lock is held from an evaluation's launch to
+ * the fetch / sync that sees it complete, by every predict call, and by a
+ * stream while it has tickets outstanding (the persistent kernels of several
+ * processes must not be time-sliced against each other: DESIGN.md 5).  Within
+ * a process it is counted.  PSOAP_DEVICE_LOCK=0 switches it off.
  */
 #ifndef PSOAP_GP_H
 #define PSOAP_GP_H

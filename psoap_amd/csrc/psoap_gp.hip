@@ -8,7 +8,13 @@
 #include <stddef.h>
 #include <string.h>
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <chrono>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -43,6 +49,68 @@ static thread_local std::string g_err;
     } while (0)
 
 static const int MAX_GROUPS = 8;
+
+// ---- one process at a time on a device while a persistent launch is in flight ------------------------------------------
+// The reference forks one worker PROCESS per chunk (psoap/sample_parallel.py:258-278); with more chunks than GPUs several
+// of them share a device.  The device then time-slices their persistent kernels (compute wave save / restore), and the
+// cross-workgroup hand-offs of k_chol_dag do not survive a workgroup being suspended between the stores
+// and the fences that publish / acquire them: measured with 8 forked workers on one MI355X, N = 6000, one evaluation per
+// call -- 3 wrong values in 800 evaluations (tools/shared_gpu_probe.py), and with 8 ranks in bench.py's dry run a wrong
+// value in every second run, round 3's library included.  So an evaluation holds an advisory lock on the device
+// (flock on /tmp/psoap_gpu_<PCI bus id>.lock) from its launch to the fetch that sees it complete; a stream holds it
+// while it has tickets outstanding.  Uncontended that is two system calls per evaluation; contended, the processes take
+// turns -- which is what the device does with persistent kernels anyway, minus the wrong answers.  Within one process the
+// lock is counted (its own launches never exclude each other).  PSOAP_DEVICE_LOCK=0 switches it off.
+struct DeviceLock {
+    int fd = -1;
+    int refs = 0;
+    pid_t pid = 0;
+};
+static std::mutex g_devlock_mu;
+static std::map<int, DeviceLock> g_devlocks;
+
+static bool device_lock_enabled()
+{
+    static const bool on = !(getenv("PSOAP_DEVICE_LOCK") && getenv("PSOAP_DEVICE_LOCK")[0] == '0');
+    return on;
+}
+
+static void device_lock_acquire(int device)
+{
+    if (!device_lock_enabled()) return;
+    std::lock_guard<std::mutex> g(g_devlock_mu);
+    DeviceLock& L = g_devlocks[device];
+    if (L.pid != getpid()) {          // first use in this process (a descriptor inherited through fork() shares its lock)
+        if (L.fd >= 0) (void)close(L.fd);
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) snprintf(bus, sizeof bus, "index%d", device);
+        for (char* c = bus; *c; ++c)
+            if (!((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z'))) *c = '_';
+        const std::string path = std::string("/tmp/psoap_gpu_") + bus + ".lock";
+        const mode_t old = umask(0);
+        L.fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        (void)umask(old);
+        L.pid = getpid();
+        L.refs = 0;
+        if (L.fd < 0) {
+            static bool warned = false;
+            if (!warned) fprintf(stderr, "psoap: cannot open %s: several processes on this GPU are not serialised\n", path.c_str());
+            warned = true;
+        }
+    }
+    if (L.fd >= 0 && L.refs++ == 0) {
+        while (flock(L.fd, LOCK_EX) != 0 && errno == EINTR) {}
+    }
+}
+
+static void device_lock_release(int device)
+{
+    if (!device_lock_enabled()) return;
+    std::lock_guard<std::mutex> g(g_devlock_mu);
+    auto it = g_devlocks.find(device);
+    if (it == g_devlocks.end() || it->second.fd < 0 || it->second.pid != getpid() || it->second.refs <= 0) return;
+    if (--it->second.refs == 0) (void)flock(it->second.fd, LOCK_UN);
+}
 
 // Owning device / pinned-host pointer: early returns free whatever was allocated so far.
 template <class T>
@@ -177,7 +245,26 @@ struct psoap_chunk {
     psoap::PredictWs* pws = nullptr;
     // streamed evaluation (psoap_stream_*)
     StreamState stream;
+    bool dev_locked = false;     // this handle holds a reference on the device's inter-process lock (device_lock_acquire)
 };
+
+static void handle_lock(psoap_chunk* h)
+{
+    if (!h->dev_locked) {
+        device_lock_acquire(h->device);
+        h->dev_locked = true;
+    }
+}
+static void handle_unlock(psoap_chunk* h, bool force = false)
+{
+    if (!force)
+        for (long long t : h->stream.lane_ticket)
+            if (t >= 0) return;           // a stream with tickets outstanding keeps the device
+    if (h->dev_locked) {
+        device_lock_release(h->device);
+        h->dev_locked = false;
+    }
+}
 
 static int set_dev(const psoap_chunk* h) { HIP_TRY(hipSetDevice(h->device)); return 0; }
 
@@ -327,6 +414,7 @@ extern "C" int psoap_chunk_destroy(psoap_chunk* h)
     (void)hipSetDevice(h->device);
     if (h->stream.open) (void)psoap_stream_close(h);
     (void)hipDeviceSynchronize();
+    handle_unlock(h, true);
     (void)hipFree(h->dFl); (void)hipFree(h->dSigma); (void)hipFree(h->dGrid); (void)hipFree(h->dEpoch);
     (void)hipFree(h->dK); (void)hipFree(h->dWt); (void)hipFree(h->dR); (void)hipFree(h->dAcc);
     (void)hipFree(h->dVel); (void)hipFree(h->dOut);
@@ -861,7 +949,12 @@ extern "C" int psoap_batch_eval(psoap_chunk* h)
     if (set_dev(h)) return 1;
     if (int rc = promote_slot(h, "psoap_batch_eval")) return rc;
     // the persistent kernel indexes block rows with 8 bits; beyond N = 32640 use the staged path
-    if (h->mode == 1 && h->P <= 255) return eval_dag(h);
+    if (h->mode == 1 && h->P <= 255) {
+        handle_lock(h);                   // released by the fetch / sync that sees the launch complete
+        const int rc = eval_dag(h);
+        if (rc) handle_unlock(h);
+        return rc;
+    }
     BatchSlot& sl = h->slot[h->act];
     const int B = sl.B, C = sl.C, N = h->N, P = h->P;
     const int G = h->profiling ? 1 : (h->groups < B ? h->groups : B);
@@ -1032,10 +1125,21 @@ extern "C" int psoap_group_destroy(psoap_group* g)
 
 // Launch the uploaded batches of all member handles; afterwards psoap_batch_fetch on each handle returns
 // its results (every handle's stream waits for the group launch).
+static int group_eval_locked(psoap_group* g);
+
 extern "C" int psoap_group_eval(psoap_group* g)
 {
     if (!g) FAIL("psoap_group_eval: null group");
     HIP_TRY(hipSetDevice(g->device));
+    for (psoap_chunk* h : g->hs) handle_lock(h);      // each member's fetch releases its own reference
+    const int rc = group_eval_locked(g);
+    if (rc)
+        for (psoap_chunk* h : g->hs) handle_unlock(h);
+    return rc;
+}
+
+static int group_eval_locked(psoap_group* g)
+{
     std::vector<int> key, acts;
     int total = 0;
     for (psoap_chunk* h : g->hs)
@@ -1358,6 +1462,9 @@ static int stream_submit_impl(psoap_chunk* h, int n, int kind, int model, const 
     int free_lanes = 0;
     for (long long t : st.lane_ticket) free_lanes += (t < 0);
     if (n > free_lanes) { g_err = std::string(who) + ": not enough free lanes (fetch outstanding results first)"; return 2; }
+    // the device is this process's while the stream has tickets outstanding (taken BEFORE the head moves: a resident
+    // dispatcher starts on the proposals at once); the fetch that takes the last result gives it back
+    handle_lock(h);
     const int c = st.C;
     int lane = 0;
     for (int k = 0; k < n; ++k) {
@@ -1506,6 +1613,7 @@ extern "C" int psoap_stream_fetch(psoap_chunk* h, int n, const long long* ticket
         out[k] = st.neg[idx] ? -INFINITY : st.hHost->result[idx].lnp;
         st.lane_ticket[lane] = -1;
     }
+    handle_unlock(h);                     // (only if nothing is outstanding any more)
     return 0;
 }
 
@@ -1630,6 +1738,7 @@ extern "C" int psoap_stream_close(psoap_chunk* h)
     if (pending && st.hHost->error == 0u) rc = stream_ensure_running(h);
     if (hipStreamSynchronize(h->streams[0]) != hipSuccess) rc = rc ? rc : 1;
     (void)stream_free(h);
+    handle_unlock(h, true);               // (the handle's stream is idle: nothing of this handle is in flight)
     return rc;
 }
 
@@ -1638,7 +1747,9 @@ extern "C" int psoap_batch_fetch(psoap_chunk* h, double* out)
     if (!h || !out || h->act < 0 || h->slot[h->act].B < 1) FAIL("psoap_batch_fetch: nothing evaluated");
     if (set_dev(h)) return 1;
     const BatchSlot& sl = h->slot[h->act];
-    HIP_TRY(hipStreamSynchronize(h->streams[0]));
+    const hipError_t e_sync = hipStreamSynchronize(h->streams[0]);
+    handle_unlock(h);
+    HIP_TRY(e_sync);
     if (collect_timings(h)) return 1;
     if (h->mode == 1 && h->P <= 255 && h->hDagErr[0] != 0) {
         char buf[512];
@@ -1661,9 +1772,12 @@ extern "C" int psoap_chunk_sync(psoap_chunk* h)
 {
     if (!h) FAIL("null handle");
     if (set_dev(h)) return 1;
+    hipError_t e = hipSuccess;
     for (int g = 0; g < MAX_GROUPS; ++g)
-        if (h->streams[g]) HIP_TRY(hipStreamSynchronize(h->streams[g]));
-    HIP_TRY(hipStreamSynchronize(h->copy));
+        if (h->streams[g] && e == hipSuccess) e = hipStreamSynchronize(h->streams[g]);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->copy);
+    handle_unlock(h);
+    HIP_TRY(e);
     return 0;
 }
 
@@ -1764,9 +1878,11 @@ extern "C" int psoap_predict(int device, int mode, int c, int N, int M, const do
     PredictWs ws;
     if (int rc = dag_workers(device, &ws.workers, &ws.n_cus)) return rc;
     int status = 0;
+    device_lock_acquire(device);
     const int rc = predict_run(ws, mode, c, N, M, lwl, fl, sigma, nullptr, nullptr, lwl_pred, mu_c, gp, mu_out,
                                Sigma_out, &status, g_err);
     (void)hipDeviceSynchronize();
+    device_lock_release(device);
     if (status_out) *status_out = status;
     return rc;
 }
@@ -1820,8 +1936,10 @@ extern "C" int psoap_predictor_run(psoap_predictor* p, int mode, int c, int N, i
     if (int rc = predict_check(mode, c, N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
     if (int rc = enter_device(p->device)) return rc;
     int status = 0;
+    device_lock_acquire(p->device);
     const int rc = predict_run(p->ws, mode, c, N, M, lwl, fl, sigma, nullptr, nullptr, lwl_pred, mu_c, gp, mu_out,
                                Sigma_out, &status, g_err);
+    device_lock_release(p->device);
     if (status_out) *status_out = status;
     return rc;
 }
@@ -1835,8 +1953,10 @@ extern "C" int psoap_predictor_run_var(psoap_predictor* p, int mode, int c, int 
     if (int rc = predict_check(mode, c, N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
     if (int rc = enter_device(p->device)) return rc;
     int status = 0;
+    device_lock_acquire(p->device);
     const int rc = predict_run(p->ws, mode, c, N, M, lwl, fl, sigma, nullptr, nullptr, lwl_pred, mu_c, gp, mu_out,
                                nullptr, &status, g_err, var_out);
+    device_lock_release(p->device);
     if (status_out) *status_out = status;
     return rc;
 }
@@ -1883,8 +2003,10 @@ static int chunk_predict(psoap_chunk* h, int mode, int c, int M, const double* l
         h->pws->n_cus = h->n_cus;
     }
     int status = 0;
+    device_lock_acquire(h->device);
     const int rc = predict_run(*h->pws, mode, c, h->N, M, lwl, nullptr, nullptr, h->dFl, h->dSigma, lwl_pred, mu_c, gp,
                                mu_out, Sigma_out, &status, g_err, var_out);
+    device_lock_release(h->device);
     if (status_out) *status_out = status;
     return rc;
 }
