@@ -2081,15 +2081,40 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
 // more than one matrix; throughput beyond (N = 6000, B = 32: 39.2 vs 39.9 ms; N = 8192, B = 32: 95.0 vs 96.1).
 // (Readiness ordering was also tried for the throughput scheme: 800 -> 776 evals/s, not adopted.)
 constexpr int DAG_LATENCY_QUEUE_ROWS = 150;
+// How many of the 8 ticket queues a batch uses (matrix b goes to queue b mod that number; the workgroups of an XCD whose own
+// queue is empty spread evenly over the queues in use -- k_chol_dag's steal0).  A queue's matrices share its workgroups, so a
+// batch is through when its FULLEST queue is: 12 matrices on 8 queues are 2 + 1 per queue and cost what 16 do, 9 cost
+// what 16 do.  Round 4 (tools/queue_sweep.py, profiles/r4_queue_sweep.txt; N = 6000, ms per batch with 8 / 4 / 2 / 1 queues):
+//    9 matrices 17.9 / 14.2 / 13.1 / 12.6     12: 20.1 / 16.0 / 16.0 / --      13: 20.3 / 19.4 / 17.7 / 17.4
+//   17 matrices 26.8 / 24.0 / 22.2 / 21.8     25: 33.4 / 33.4 / 32.2 / 31.3    16, 24, 32: the same within 0.5 % (8 ahead)
+// i.e. time ~ ceil(B / n) x n, with all XCDs drawing from ONE in-order list costing about 1 % (every matrix in front of
+// all eight L2s).  The rule: the n in {8, 4, 2, 1} with the smallest ceil(B / n) x n, the larger n on a tie.  Up to 8
+// matrices keep a queue each (the XCDs without one steal; one shared queue measures the same).
+inline int dag_queue_count(int B)
+{
+    if (const char* e = getenv("PSOAP_DAG_QUEUES"))      // experiments
+        if (atoi(e) > 0) return atoi(e) < DAG_QUEUES ? atoi(e) : DAG_QUEUES;
+    if (B <= DAG_QUEUES) return DAG_QUEUES;
+    int best = DAG_QUEUES, best_cost = (B + DAG_QUEUES - 1) / DAG_QUEUES * DAG_QUEUES;
+    for (int n = DAG_QUEUES / 2; n >= 1; n /= 2) {
+        const int cost = (B + n - 1) / n * n;
+        if (cost < best_cost) {
+            best = n;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
 constexpr int DAG_FOLLOW_MAX_MATS = 8;
 constexpr int DAG_FOLLOW_SMALL_ROWS = 20;
 inline int dag_auto_scheme(const std::vector<int>& Ps)
 {
     long long rows[DAG_QUEUES] = {};
     int count[DAG_QUEUES] = {};
+    const int nq = dag_queue_count((int)Ps.size());
     for (size_t b = 0; b < Ps.size(); ++b) {
-        rows[b % DAG_QUEUES] += Ps[b];
-        ++count[b % DAG_QUEUES];
+        rows[b % nq] += Ps[b];
+        ++count[b % nq];
     }
     long long max_rows = 0;
     int max_count = 0;
@@ -2097,7 +2122,8 @@ inline int dag_auto_scheme(const std::vector<int>& Ps)
         max_rows = rows[g] > max_rows ? rows[g] : max_rows;
         max_count = count[g] > max_count ? count[g] : max_count;
     }
-    const int latency = (max_rows <= DAG_LATENCY_QUEUE_ROWS || max_count <= 1) ? 1 : 0;
+    // (block rows per XCD: a queue shared by 8 / nq XCDs works its rows off that much faster)
+    const int latency = (max_rows * nq <= (long long)DAG_LATENCY_QUEUE_ROWS * DAG_QUEUES || max_count <= 1) ? 1 : 0;
 #ifdef PSOAP_FOLLOW
     // following strip solves (scheme 2) where they were measured to win (profiles/r3_follow_table.txt: N = 2000 .. 8192, B =
     // 1 .. 32, against scheme 1 with its PARTs just in time): up to eight matrices everywhere -- single evaluations 12-37 %
@@ -2122,13 +2148,15 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
 #endif
     plan.scheme = scheme;
     // workgroups of XCDs whose own queue is empty steal, so the workers are shared by the queues in use
-    const int used = B < DAG_QUEUES ? (B > 0 ? B : 1) : DAG_QUEUES;
+    const int nq = dag_queue_count(B);
+    const int used = B < nq ? (B > 0 ? B : 1) : nq;
     const int per_queue = workers / used > 0 ? workers / used : 1;
     for (int g = 0; g < DAG_QUEUES; ++g) {
         plan.queues.first[g] = (unsigned int)plan.tasks.size();
         std::vector<int> mats;
-        for (int b = g; b < B; b += DAG_QUEUES) mats.push_back(b);
-        dag_build_queue(plan, mats, Ps, per_queue, (B + DAG_QUEUES - 1) / DAG_QUEUES, scheme, Mt, Ms, fixed_share);
+        if (g < nq)
+            for (int b = g; b < B; b += nq) mats.push_back(b);
+        dag_build_queue(plan, mats, Ps, per_queue, (B + nq - 1) / nq, scheme, Mt, Ms, fixed_share);
         if (scheme >= 1) {
             // Latency scheme: hand the tasks out in order of READINESS instead of block row by block row.
             // A task over panels [pa, pb) can run once block row pb-1 is finished ("stage" pb); within a

@@ -47,18 +47,21 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
     assert TASK.itemsize == 16
     # latency scheme (chained partial sums) while the fullest queue holds at most ~150 block rows or a
     # single matrix; gathered otherwise
-    q_rows = [sum(Ps[g::8]) for g in range(8)]
-    q_count = [len(Ps[g::8]) for g in range(8)]
-    want_chain = max(q_rows) <= 150 or max(q_count) <= 1
+    # (queues in use, dag_queue_count: of 8, 4, 2, 1 the one that leaves the fullest queue relatively emptiest -- 12 matrices:
+    # 4 x 3, 9 matrices: one list -- the larger on a tie; up to 8 matrices a queue each)
+    nq = 8 if B <= 8 else min((8, 4, 2, 1), key=lambda n: ((B + n - 1) // n * n, -n))
+    q_rows = [sum(Ps[g::nq]) for g in range(nq)]
+    q_count = [len(Ps[g::nq]) for g in range(nq)]
+    want_chain = max(q_rows) * nq <= 150 * 8 or max(q_count) <= 1
     # ... and within that, the following scheme (scheme 2) for up to eight matrices (24 small ones): the strip solves follow the
     # factorisation (DAG_WAITNEXT on OFF finals), the diagonal task solves nothing
     following = want_chain and (B <= 8 or (B <= 24 and max(Ps) <= 20))
     assert np.all(chain[tasks["S"] > 1] == want_chain) if (tasks["S"] > 1).any() else True
-    # one queue per XCD: matrix b lives in queue b mod 8, queues are contiguous ranges of the list
+    # one queue per XCD: matrix b lives in queue b mod nq, queues are contiguous ranges of the list
     first = plan.queue_first
     assert first[0] == 0 and first[8] == len(tasks) and all(first[g] <= first[g + 1] for g in range(8))
     for g in range(8):
-        assert np.all(tasks["b"][first[g]:first[g + 1]] % 8 == g)
+        assert np.all(tasks["b"][first[g]:first[g + 1]] % nq == g)
     finals = {}
     covered = {}           # (b, q, j) -> list of (pa, pb)
     part_done_ticket = {}  # ctr -> list of tickets of its PARTs

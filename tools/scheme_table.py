@@ -1,4 +1,5 @@
-"""Split-scheme comparison of the persistent DAG kernel (PSOAP_DAG_SCHEME=0 gather / 1 chain) over batch sizes."""
+"""Scheme comparison of the persistent DAG kernel (PSOAP_DAG_SCHEME=0 throughput / 1 latency / 2 following, and the automatic
+rule) over batch sizes: is dag_auto_scheme still where the crossovers are?"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,8 +13,11 @@ for cfg in (1, 2, 3, 5):
         gps = syn.make_walkers(c, B, seed=1)
         lw = np.repeat(ch.lwls[None], B, axis=0)
         res = {}
-        for scheme in (0, 1):
-            os.environ["PSOAP_DAG_SCHEME"] = str(scheme)
+        for scheme in (0, 1, 2, -1):
+            if scheme >= 0:
+                os.environ["PSOAP_DAG_SCHEME"] = str(scheme)
+            else:
+                os.environ.pop("PSOAP_DAG_SCHEME", None)
             with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
                 h.upload(lw, gps)
                 for _ in range(2):
@@ -23,5 +27,7 @@ for cfg in (1, 2, 3, 5):
                 for _ in range(n):
                     h.eval(); h.fetch()
                 res[scheme] = (1e3 * (time.perf_counter() - t0) / n, out[0])
-        assert abs(res[0][1] - res[1][1]) <= 1e-10 * abs(res[0][1]), res
-        print(f"N={ch.N:5d} B={B:2d}: gather {res[0][0]:8.2f} ms   chain {res[1][0]:8.2f} ms   best {'chain' if res[1][0] < res[0][0] else 'gather'}", flush=True)
+        assert all(abs(res[0][1] - res[k][1]) <= 1e-10 * abs(res[0][1]) for k in res), res
+        best = min((0, 1, 2), key=lambda k: res[k][0])
+        print(f"N={ch.N:5d} B={B:2d}: scheme 0 {res[0][0]:8.2f} ms   1 {res[1][0]:8.2f} ms   2 {res[2][0]:8.2f} ms   auto {res[-1][0]:8.2f} ms"
+              f"   best {best}   auto/best {res[-1][0] / res[best][0]:.3f}", flush=True)
