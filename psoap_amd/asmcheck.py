@@ -41,14 +41,16 @@ _LABEL = re.compile(r"^([A-Za-z_.$][\w.$]*):")
 
 def short(mangled: str | None) -> str:
     """k_chol_dag<3,true,true> for _ZN5psoap10k_chol_dagILi3ELb1ELb1EEE...; other names are returned as they are"""
-    m = re.match(r"_ZN5psoap10k_chol_dagILi(\d)ELb([01])ELb([01])E(?:Lb([01])E)?EE", mangled or "")
+    m = re.match(r"_ZN5psoap10k_chol_dagILi(\d)ELb([01])ELb([01])E(?:Lb([01])E)?(?:Li(\d)E)?EE", mangled or "")
     if m:
-        # (the fourth parameter, STREAM, is printed only when set: the names of rounds 1-3 stay as they were)
-        return "k_chol_dag<%s,%s,%s%s>" % (m.group(1), "true" if m.group(2) == "1" else "false",
-                                           "true" if m.group(3) == "1" else "false", ",stream" if m.group(4) == "1" else "")
-    m = re.match(r"_ZN5psoap11dag_specialILi(\d)ELb([01])EEE", mangled or "")
+        # (the fourth parameter, STREAM, and the fifth, one wave per SIMD, are printed only when set: the names of rounds
+        # 1-3 stay as they were)
+        return "k_chol_dag<%s,%s,%s%s%s>" % (m.group(1), "true" if m.group(2) == "1" else "false",
+                                             "true" if m.group(3) == "1" else "false", ",stream" if m.group(4) == "1" else "",
+                                             ",wide" if m.group(5) == "1" else "")
+    m = re.match(r"_ZN5psoap11dag_specialILi(\d)ELb([01])E(?:Li(\d)E)?EE", mangled or "")
     if m:
-        return "dag_special<%s,%s>" % (m.group(1), "true" if m.group(2) == "1" else "false")
+        return "dag_special<%s,%s%s>" % (m.group(1), "true" if m.group(2) == "1" else "false", ",wide" if m.group(3) == "1" else "")
     return mangled or "?"
 
 

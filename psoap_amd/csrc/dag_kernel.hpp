@@ -859,8 +859,15 @@ struct DagSpecialArgs {
     int xfirst;                    // the first block row whose strip solves follow
 };
 
-template <int C, bool AUG>
-__device__ __attribute__((noinline)) void dag_special(const DagSpecialArgs* a)
+// The record travels through LDS (round 4; rounds 2-3: through the caller's stack frame, i.e. 288 B of scratch memory per
+// lane written before every call and read back through the vector memory path at the head of the chain's tasks): every
+// lane of the caller writes the same values, the callee reads them with broadcast ds_reads.
+typedef __attribute__((address_space(3))) const DagSpecialArgs lds_special_args;
+// not_tail_called: with no pointer into the caller's frame among the arguments LLVM marks the call `tail`, and a function
+// with a `tail` call site is not compiled without callee-saved registers (isSafeForNoCSROpt) -- the routine then saves and
+// restores ~270 registers through scratch memory around every task (1120 B per lane).
+template <int C, bool AUG, int WPE = 2>
+__device__ __attribute__((noinline, not_tail_called)) void dag_special(lds_special_args* a)
 {
     if (a->mode == 0) {
         dag_diag_fast(a->Km, a->ld, a->k0, a->Wm, a->Rv, a->acc, a->prev, a->Npad, a->f, a->ctl, a->q, a->ntasks_row,
@@ -911,7 +918,9 @@ __device__ __attribute__((noinline)) void dag_special(const DagSpecialArgs* a)
 #pragma clang fp contract(off)
             for (int c = 1; c < C; ++c) dsum = dsum + g.a2[c];
         }
-        dag_store_updated<C, AUG, true>(t, nullptr, 0, k0, j0, a->lw, g, dsum, a->sigma, a->N, scale, a->Npad, a->aug, nullptr);
+        // (member by member: the record lives in LDS, DagAug's copy constructor takes a generic reference)
+        const DagAug aug_l{a->aug.Pt, a->aug.R, a->aug.Rpad, a->aug.colx, a->aug.rowx, a->aug.diag, a->aug.S, a->aug.lds};
+        dag_store_updated<C, AUG, true>(t, nullptr, 0, k0, j0, a->lw, g, dsum, a->sigma, a->N, scale, a->Npad, aug_l, nullptr);
         dag_negate(t);
     }
     const int xupd = xlink && q >= si(a->xfirst) + 1;      // the row above is a following one that delivers its tiles progressively
@@ -1393,8 +1402,12 @@ __device__ __forceinline__ void stream_dispatch(const StreamArgs& st, const DagM
 // throughput scheme never runs it, so it gets a kernel without it.
 // STREAM: the resident form (above): tickets come from the lanes' own counters, matrix index = lane, workgroup 0
 // dispatches.  The task bodies are the same code.
-template <int C, bool AUG = false, bool LAT = false, bool STREAM = false>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __restrict__ mats,
+// WPE: waves per SIMD the kernel is compiled for.  2 = two workgroups per compute unit, 256 registers per lane.  1 (LAT
+// kernels launched with at most one workgroup per compute unit -- single evaluations, predict: dag_pick_workers): the whole
+// unified file, 512 registers per lane -- the accumulator tile can live in the AccVGPR half and what the chain phases of the
+// out-of-line routine spilled to scratch memory (29-62 VGPRs, 632-904 B per lane with 256) stays in registers.
+template <int C, bool AUG = false, bool LAT = false, bool STREAM = false, int WPE = 2>
+__global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __restrict__ mats,
                                                              const DagTask* __restrict__ tasks, DagQueues queues,
                                                              MatFlags* flags, int* arrive, double* wspace,
                                                              DagCtl* ctl, unsigned long long* tlog, DagAug aug,
@@ -1545,7 +1558,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
         if (fast_diag || follow) {
             // scheme 2's strip solves follow the factorisation of block q step by step, on the tile in registers; the
             // whole task -- update, covariance evaluation, solve -- runs in the out-of-line routine
-            DagSpecialArgs args;
+            __shared__ DagSpecialArgs args;      // (every lane writes the same record; the barriers of the ticket hand-out
+                                                 // separate its readers from the next task's writes)
             args.mode = fast_diag ? 0 : 1;
             args.Km = Km; args.ld = ld; args.k0 = k0; args.j0 = j0; args.Wm = Wm; args.Rv = Rv; args.acc = mat.acc;
             args.prev = prev; args.Npad = Npad; args.f = f; args.ctl = ctl; args.q = q; args.ntasks_row = ntasks_row;
@@ -1563,7 +1577,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_dag(const DagMat* __re
             // DAG_FUSED on a strip solve (it delivers its tile row block by row block, and follows the row above likewise)
             args.xlink = fast_diag ? ((task.type & DAG_NOSOLVE) != 0) : ((task.type & DAG_FUSED) != 0);
             args.xfirst = (int)queues.follow_first;
-            dag_special<C, AUG>(&args);
+            __syncthreads();
+            {
+                unsigned int aa = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) DagSpecialArgs*)&args;
+                asm volatile("" : "+s"(aa));     // (opaque, like dag_opaque_lds: the callee must not be specialised on it)
+                dag_special<C, AUG, WPE>((lds_special_args*)(uintptr_t)aa);
+            }
             if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
             if constexpr (STREAM) {
                 if (threadIdx.x == 0) stream_retire(st, b, mat.acc);

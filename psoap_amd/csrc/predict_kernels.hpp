@@ -211,6 +211,9 @@ inline hipError_t predict_configure_kernels()
     PSOAP_SET_LDS(k_chol_dag<1, true, true>);
     PSOAP_SET_LDS(k_chol_dag<2, true, true>);
     PSOAP_SET_LDS(k_chol_dag<3, true, true>);
+    PSOAP_SET_LDS(k_chol_dag<1, true, true, false, 1>);
+    PSOAP_SET_LDS(k_chol_dag<2, true, true, false, 1>);
+    PSOAP_SET_LDS(k_chol_dag<3, true, true, false, 1>);
 #undef PSOAP_SET_LDS
     return e;
 }
@@ -544,14 +547,16 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         PR_TRY(hipMemcpyAsync(ws.Mat, &hm, sizeof(DagMat), hipMemcpyHostToDevice, st));
         PR_TRY(hipStreamSynchronize(st));   // hm is a stack object; the staging copies are tiny
         PR_TRY(hipEventRecord(ws.ev[1], st));
-#define PSOAP_LAUNCH_AUG(CC, LAT)                                                                                 \
-    hipLaunchKernelGGL((k_chol_dag<CC, true, LAT>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, ws.Mat.p,  \
-                       ws.Tasks.p, plan.queues, fl_, reinterpret_cast<int*>(ws.Dag.p + arrive_off), ws.Ws.p, ctl_,  \
-                       (unsigned long long*)nullptr, aug, StreamArgs{})
+#define PSOAP_LAUNCH_AUG(CC, LAT, WPE)                                                                            \
+    hipLaunchKernelGGL((k_chol_dag<CC, true, LAT, false, WPE>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st,  \
+                       ws.Mat.p, ws.Tasks.p, plan.queues, fl_, reinterpret_cast<int*>(ws.Dag.p + arrive_off),        \
+                       ws.Ws.p, ctl_, (unsigned long long*)nullptr, aug, StreamArgs{})
         const bool lat = plan.scheme >= 1;
-        if (c == 1) { if (lat) PSOAP_LAUNCH_AUG(1, true); else PSOAP_LAUNCH_AUG(1, false); }
-        else if (c == 2) { if (lat) PSOAP_LAUNCH_AUG(2, true); else PSOAP_LAUNCH_AUG(2, false); }
-        else { if (lat) PSOAP_LAUNCH_AUG(3, true); else PSOAP_LAUNCH_AUG(3, false); }
+        // (at most one workgroup per compute unit: the kernels compiled for one wave per SIMD, as in psoap_gp.hip: eval_dag)
+        const bool wide = lat && ws.n_cus > 0 && grid <= ws.n_cus && !(getenv("PSOAP_DAG_WIDE") && getenv("PSOAP_DAG_WIDE")[0] == '0');
+        if (c == 1) { if (wide) PSOAP_LAUNCH_AUG(1, true, 1); else if (lat) PSOAP_LAUNCH_AUG(1, true, 2); else PSOAP_LAUNCH_AUG(1, false, 2); }
+        else if (c == 2) { if (wide) PSOAP_LAUNCH_AUG(2, true, 1); else if (lat) PSOAP_LAUNCH_AUG(2, true, 2); else PSOAP_LAUNCH_AUG(2, false, 2); }
+        else { if (wide) PSOAP_LAUNCH_AUG(3, true, 1); else if (lat) PSOAP_LAUNCH_AUG(3, true, 2); else PSOAP_LAUNCH_AUG(3, false, 2); }
 #undef PSOAP_LAUNCH_AUG
         PR_TRY(hipGetLastError());
     } else {

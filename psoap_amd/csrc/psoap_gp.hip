@@ -299,6 +299,9 @@ static int configure_kernels(int device)
     PSOAP_SET_LDS(k_chol_dag<1, false, true>);
     PSOAP_SET_LDS(k_chol_dag<2, false, true>);
     PSOAP_SET_LDS(k_chol_dag<3, false, true>);
+    PSOAP_SET_LDS(k_chol_dag<1, false, true, false, 1>);
+    PSOAP_SET_LDS(k_chol_dag<2, false, true, false, 1>);
+    PSOAP_SET_LDS(k_chol_dag<3, false, true, false, 1>);
     PSOAP_SET_LDS(k_chol_dag<1, false, false, true>);
     PSOAP_SET_LDS(k_chol_dag<2, false, false, true>);
     PSOAP_SET_LDS(k_chol_dag<3, false, false, true>);
@@ -918,14 +921,17 @@ static int eval_dag(psoap_chunk* h)
     {
         MatFlags* fl_ = reinterpret_cast<MatFlags*>(h->dDag + sizeof(DagCtl));
         DagCtl* ctl_ = reinterpret_cast<DagCtl*>(h->dDag);
-#define PSOAP_LAUNCH_DAG(CC, LAT)                                                                                \
-    hipLaunchKernelGGL((k_chol_dag<CC, false, LAT>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, sl.dMats, \
-                       h->dTasks, h->plan_queues, fl_, reinterpret_cast<int*>(h->dDag + h->arrive_off), h->dWs,   \
-                       ctl_, h->dTlog, DagAug{P, 0, 0, nullptr}, StreamArgs{})
+#define PSOAP_LAUNCH_DAG(CC, LAT, WPE)                                                                           \
+    hipLaunchKernelGGL((k_chol_dag<CC, false, LAT, false, WPE>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, \
+                       sl.dMats, h->dTasks, h->plan_queues, fl_, reinterpret_cast<int*>(h->dDag + h->arrive_off),   \
+                       h->dWs, ctl_, h->dTlog, DagAug{P, 0, 0, nullptr}, StreamArgs{})
         const bool lat = h->plan_scheme >= 1;
-        if (C == 1) { if (lat) PSOAP_LAUNCH_DAG(1, true); else PSOAP_LAUNCH_DAG(1, false); }
-        else if (C == 2) { if (lat) PSOAP_LAUNCH_DAG(2, true); else PSOAP_LAUNCH_DAG(2, false); }
-        else { if (lat) PSOAP_LAUNCH_DAG(3, true); else PSOAP_LAUNCH_DAG(3, false); }
+        // at most one workgroup per compute unit (single evaluations: dag_pick_workers): the kernels compiled for one wave
+        // per SIMD -- 512 registers per lane, nothing of the chain phases in scratch memory
+        const bool wide = lat && grid <= h->n_cus && !(getenv("PSOAP_DAG_WIDE") && getenv("PSOAP_DAG_WIDE")[0] == '0');
+        if (C == 1) { if (wide) PSOAP_LAUNCH_DAG(1, true, 1); else if (lat) PSOAP_LAUNCH_DAG(1, true, 2); else PSOAP_LAUNCH_DAG(1, false, 2); }
+        else if (C == 2) { if (wide) PSOAP_LAUNCH_DAG(2, true, 1); else if (lat) PSOAP_LAUNCH_DAG(2, true, 2); else PSOAP_LAUNCH_DAG(2, false, 2); }
+        else { if (wide) PSOAP_LAUNCH_DAG(3, true, 1); else if (lat) PSOAP_LAUNCH_DAG(3, true, 2); else PSOAP_LAUNCH_DAG(3, false, 2); }
 #undef PSOAP_LAUNCH_DAG
     }
     HIP_TRY(hipGetLastError());
@@ -1232,14 +1238,15 @@ static int group_eval_locked(psoap_group* g)
         const int grid = (int)(g->n_tasks < workers ? g->n_tasks : workers);
         MatFlags* fl_ = reinterpret_cast<MatFlags*>(g->dDag + sizeof(DagCtl));
         DagCtl* ctl_ = reinterpret_cast<DagCtl*>(g->dDag);
-#define PSOAP_LAUNCH_GROUP(CC, LAT)                                                                             \
-    hipLaunchKernelGGL((k_chol_dag<CC, false, LAT>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, g->dMats, \
-                       g->dTasks, g->queues, fl_, reinterpret_cast<int*>(g->dDag + g->arrive_off), g->dWs, ctl_,  \
-                       (unsigned long long*)nullptr, DagAug{0, 0, 0, nullptr}, StreamArgs{})
+#define PSOAP_LAUNCH_GROUP(CC, LAT, WPE)                                                                        \
+    hipLaunchKernelGGL((k_chol_dag<CC, false, LAT, false, WPE>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, \
+                       g->dMats, g->dTasks, g->queues, fl_, reinterpret_cast<int*>(g->dDag + g->arrive_off),        \
+                       g->dWs, ctl_, (unsigned long long*)nullptr, DagAug{0, 0, 0, nullptr}, StreamArgs{})
         const bool lat = g->scheme >= 1;
-        if (C == 1) { if (lat) PSOAP_LAUNCH_GROUP(1, true); else PSOAP_LAUNCH_GROUP(1, false); }
-        else if (C == 2) { if (lat) PSOAP_LAUNCH_GROUP(2, true); else PSOAP_LAUNCH_GROUP(2, false); }
-        else { if (lat) PSOAP_LAUNCH_GROUP(3, true); else PSOAP_LAUNCH_GROUP(3, false); }
+        const bool wide = lat && grid <= g->hs[0]->n_cus && !(getenv("PSOAP_DAG_WIDE") && getenv("PSOAP_DAG_WIDE")[0] == '0');
+        if (C == 1) { if (wide) PSOAP_LAUNCH_GROUP(1, true, 1); else if (lat) PSOAP_LAUNCH_GROUP(1, true, 2); else PSOAP_LAUNCH_GROUP(1, false, 2); }
+        else if (C == 2) { if (wide) PSOAP_LAUNCH_GROUP(2, true, 1); else if (lat) PSOAP_LAUNCH_GROUP(2, true, 2); else PSOAP_LAUNCH_GROUP(2, false, 2); }
+        else { if (wide) PSOAP_LAUNCH_GROUP(3, true, 1); else if (lat) PSOAP_LAUNCH_GROUP(3, true, 2); else PSOAP_LAUNCH_GROUP(3, false, 2); }
 #undef PSOAP_LAUNCH_GROUP
     }
     HIP_TRY(hipGetLastError());

@@ -46,10 +46,32 @@ def test_no_spill_reloads_inside_mfma_loop_stages():
     res = asmcheck.scan_hot_loops(build.device_asm())
     kernels = {k: v for k, v in res.items() if k.startswith("k_chol_dag")}
     special = {k: v for k, v in res.items() if k.startswith("dag_special")}
-    # C = 1, 2, 3  x  AUG  x  LAT, plus the streamed forms (round 4: C x LAT, never AUG)
-    assert len(kernels) == 18 and len(special) == 6, res
+    # C = 1, 2, 3  x  AUG  x  LAT, plus the streamed forms (round 4: C x LAT, never AUG) and the LAT kernels compiled for one
+    # wave per SIMD (C x AUG; their out-of-line routine is an instantiation of its own)
+    assert len(kernels) == 24 and len(special) == 12, res
     # 3 K-loop stage blocks per kernel, 5 in the out-of-line routine (its following update has two more): no scratch access
     assert all(v == (3, 0) for v in kernels.values()) and all(v == (5, 0) for v in special.values()), res
+
+
+@needs_hipcc
+def test_single_evaluation_kernels_keep_their_chain_phases_in_registers():
+    """The LAT kernels that run single evaluations and predict (at most one workgroup per compute unit: compiled for one
+    wave per SIMD, 512 registers per lane) spill no vector register and have no frame to speak of -- the argument record of
+    the out-of-line routine travels through LDS, and the routine is compiled without callee-saved registers (it must not be
+    tail-called for that: dag_kernel.hpp).  Code-object metadata; the bound asked for is 16 spilled VGPRs / 256 B."""
+    from psoap_amd import asmcheck, build
+    res = asmcheck.kernel_resources(build.device_asm())
+    wide = {k: v for k, v in res.items() if k.startswith("k_chol_dag") and k.endswith(",wide>")}
+    assert len(wide) == 6, sorted(res)
+    for k, v in wide.items():
+        assert v["vgpr_spill_count"] <= 16 and v["private_segment_fixed_size"] <= 256, (k, v)
+        assert v["agpr_count"] > 128, (k, v)          # the accumulator tile lives in the AccVGPR half
+    # the kernels for two workgroups per compute unit have 256 registers: their chain phases do spill (recorded, not bounded)
+    narrow = {k: v for k, v in res.items() if k.startswith("k_chol_dag") and not k.endswith(",wide>")}
+    assert all(v["agpr_count"] == 0 and v["vgpr_count"] == 256 for v in narrow.values()), narrow
+    # ... but the headline kernels (throughput scheme, SB1 / SB2) stay clean
+    for k in ("k_chol_dag<1,false,false>", "k_chol_dag<2,false,false>", "k_chol_dag<1,false,false,stream>", "k_chol_dag<2,false,false,stream>"):
+        assert narrow[k]["vgpr_spill_count"] <= 4 and narrow[k]["private_segment_fixed_size"] <= 32, (k, narrow[k])
 
 
 @needs_hipcc
