@@ -2264,12 +2264,17 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
 // Round 3 (following scheme): several matrices -- 2.0e9 instead of 3.3e9: their strip solves hold workgroups while they
 // follow the factorisation, which a second workgroup per compute unit makes up for earlier (N = 6000, B = 2: 4.29 -> 3.99
 // ms; N = 4096, B = 4: 2.87 -> 2.70 ms; N = 4096, B = 2 stays with one: 1.92 against 2.15 ms).
+// Round 4: one workgroup per compute unit now means the kernels compiled for one wave per SIMD (512 registers per lane,
+// nothing of the chain phases in scratch memory: 3-7 % faster), which moves the crossover for several matrices back to
+// 3.3e9: N = 4096, 3 / 4 matrices 2.39 -> 2.16 / 2.74 -> 2.62 ms, N = 6000, 2 matrices 3.94 -> 3.83 ms; beyond (N = 4096:
+// 6, N = 6000: 3, N = 8192: 2 matrices) two per compute unit stay 5-12 % ahead.
 inline int dag_pick_workers(double flops, int Pmax, int compute_units, int max_workers, int n_mats = 1)
 {
     if (const char* e = getenv("PSOAP_DAG_WORKERS"))      // experiments
         if (atoi(e) > 0) return atoi(e);
     if (max_workers <= compute_units) return max_workers;
-    return flops <= (n_mats > 1 ? 2.0e9 : 3.3e9) * (double)Pmax ? compute_units : max_workers;
+    (void)n_mats;
+    return flops <= 3.3e9 * (double)Pmax ? compute_units : max_workers;
 }
 inline double dag_batch_flops(const std::vector<int>& Ps, int Mt = 0)
 {

@@ -224,9 +224,9 @@ def test_sparse_rows_are_split_and_diagonal_is_preaccumulated():
 
 
 def test_chain_bound_batches_get_one_workgroup_per_compute_unit():
-    """dag_pick_workers: one persistent workgroup per compute unit while the batch's algorithmic flops stay below
-    3.3e9 (one matrix) / 2.0e9 (several) x the block rows of its largest matrix (single evaluations, small batches of
-    small matrices), all the device admits otherwise; measured crossovers of DESIGN.md 3.3."""
+    """dag_pick_workers: one persistent workgroup per compute unit -- the kernels compiled for one wave per SIMD -- while the
+    batch's algorithmic flops stay below 3.3e9 x the block rows of its largest matrix (single evaluations, small batches of
+    small matrices), all the device admits otherwise; measured crossovers of DESIGN.md 3.3 and round 4's."""
     from psoap_amd import _lib
     L = _lib.load()
 
@@ -236,10 +236,9 @@ def test_chain_bound_batches_get_one_workgroup_per_compute_unit():
         assert L.psoap_dag_pick_workers(len(Ps), arr, Mt, cus, mx, ctypes.byref(w)) == 0
         return w.value
 
-    # (several matrices: 2.0e9 -- their following strip solves hold workgroups)
-    assert pick([47]) == 256 and pick([47] * 2) == 512 and pick([47] * 3) == 512 and pick([47] * 32) == 512   # N = 6000
-    assert pick([16] * 8) == 256 and pick([16] * 16) == 512 and pick([16] * 32) == 512                         # N = 2000
-    assert pick([32] * 2) == 256 and pick([32] * 3) == 512 and pick([32] * 6) == 512                           # N = 4096
+    assert pick([47]) == 256 and pick([47] * 2) == 256 and pick([47] * 3) == 512 and pick([47] * 32) == 512   # N = 6000
+    assert pick([16] * 8) == 256 and pick([16] * 32) == 512                                                    # N = 2000
+    assert pick([32] * 2) == 256 and pick([32] * 4) == 256 and pick([32] * 6) == 512                           # N = 4096
     assert pick([64]) == 256 and pick([64] * 2) == 512                                                         # N = 8192
     assert pick([64], Mt=24) == 512                      # predict at the retrieve shape: the appended columns are work
     assert pick([5], cus=256, mx=256) == 256             # a device that admits one workgroup per CU anyway
