@@ -80,7 +80,14 @@ old.update(fetch_size_kb_raw=fetch_kb, write_size_kb_raw=write_kb, fetch_correct
            hbm_bytes_per_launch=(2.0 * fetch_kb + write_kb) * 1024.0,
            hbm_bytes_per_evaluation=(2.0 * fetch_kb + write_kb) * 1024.0 / EVALS_PER_DISPATCH)
 json.dump(old, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=2)
-for a, b in ((f"latency_{tag}.jsonl", f"{tag}_latency_table.jsonl"), (f"bench_{tag}.json", f"{tag}_bench.json")):
+for a, b in ((f"latency_{tag}.jsonl", f"{tag}_latency_table.jsonl"), (f"bench_{tag}.json", f"{tag}_bench.json"),
+             (f"gputests_{tag}.txt", f"{tag}_gputests.txt"), (f"soak_{tag}.txt", f"{tag}_soak.txt"),
+             (f"stream_table_{tag}.jsonl", f"{tag}_stream_table.jsonl"), (f"timeline_{tag}.txt", f"{tag}_timeline.txt"),
+             (f"timeline_launch_per_step_{tag}.txt", f"{tag}_timeline_launch_per_step.txt"), (f"fill_{tag}.jsonl", f"{tag}_fill_table.jsonl"),
+             (f"follow_table_{tag}.txt", f"{tag}_follow_table.txt"), (f"row_periods_{tag}.txt", f"{tag}_row_periods.txt"),
+             (f"wg_occupancy_{tag}.txt", f"{tag}_wg_occupancy.txt"), (f"lib_sha256_{tag}.txt", f"{tag}_lib_sha256.txt"),
+             (f"scheme_table_{tag}.txt", f"{tag}_scheme_table.txt"), (f"queue_sweep_final_{tag}.txt", f"{tag}_queue_sweep_final.txt"),
+             (f"shared_gpu_probe_{tag}.txt", f"{tag}_shared_gpu_probe.txt"), (f"evidence_status_{tag}.txt", f"{tag}_evidence_status.txt")):
     p = os.path.join(ROOT, "gpurun_out", a)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, b))
