@@ -7,6 +7,7 @@ of the dominant kernel from the counter passes, and rewrites profiles/<tag>_traf
 FETCH_SIZE / WRITE_SIZE passes (gfx950 correction: FETCH_SIZE x 2, MI355X_MICROARCH.md).
 """
 import csv
+import re
 import glob
 import json
 import os
@@ -25,7 +26,9 @@ EVALS_PER_DISPATCH = 160
 
 def is_stream(name):
     head = name.split("(")[0].replace(" ", "")
-    return "k_chol_dag" in head and head.endswith(",true>")
+    # template arguments <C, AUG, LAT, STREAM, WPE>: the fourth one (rounds 1-3 had three, the start of round 4 four)
+    m = re.search(r"k_chol_dag<([^>]*)>", head)
+    return bool(m) and len(m.group(1).split(",")) >= 4 and m.group(1).split(",")[3] == "true"
 
 
 def newest(pattern):
@@ -72,7 +75,7 @@ old = json.load(open(tpath)) if os.path.exists(tpath) else {
     "round": int(tag[1:]) if tag[1:].isdigit() else tag,
     "source": f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, "
               "bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-extras --no-strong)",
-    "kernel": "k_chol_dag<2, false, false, true> (the resident launch of bench.py --mode stream)",
+    "kernel": "k_chol_dag<2, false, false, true, 2> (the resident launch of bench.py --mode stream)",
     "workload": {"N": 6000, "components": 2, "walkers": 32, "mode": "stream", "evaluations_per_launch": EVALS_PER_DISPATCH},
     "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16 B/lane coalesced reads); "
             "WRITE_SIZE taken as is"}

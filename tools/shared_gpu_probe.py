@@ -1,6 +1,6 @@
 """How safe is ONE GPU under several processes?  W worker processes (the reference's fork-then-INIT model, sample_parallel.py:
 258-278), each with its own chunk, evaluate the same proposal over and over through the drop-in call; every value is compared
-with the process's first.  Prints mismatches per worker.      python tools/shared_gpu_probe.py [workers reps cfg lock]
+with the process's first.  Prints mismatches per worker (-1: the worker's series ended in an error).      python tools/shared_gpu_probe.py [workers reps cfg lock]
 lock: 0 = none (PSOAP_DEVICE_LOCK=0: the hazard itself), 1 = psoap_amd.ensemble.SharedDeviceLock around each call and the
 library's own lock off, 2 = the library's device lock (the default behaviour of libpsoap_gp.so)."""
 import multiprocessing as mp
@@ -26,11 +26,16 @@ def worker(k, q):
         first = fn(*call)
     bad = 0
     t0 = time.time()
-    for _ in range(reps):
-        with guard:
-            v = fn(*call)
-        bad += (v != first)
-    q.put((k, int(bad), first, time.time() - t0))
+    err = ""
+    try:
+        for _ in range(reps):
+            with guard:
+                v = fn(*call)
+            bad += (v != first)
+    except Exception as e:          # (without a lock: a dependency wait that timed out ends the worker's series)
+        err = str(e)[:160]
+        bad = -1
+    q.put((k, int(bad), first, time.time() - t0, err))
 
 
 if __name__ == "__main__":
@@ -44,4 +49,7 @@ if __name__ == "__main__":
         p.join()
     print(f"{W} workers x {reps} evaluations (cfg {cfg}, lock {lock}): mismatches per worker {[r[1] for r in res]}, "
           f"seconds {max(r[3] for r in res):.1f}")
+    for r in res:
+        if r[4]:
+            print(f"  worker {r[0]} ended with: {r[4]}")
     sys.exit(1 if lock and any(r[1] for r in res) else 0)

@@ -1,5 +1,5 @@
 """Turn the rocprofv3 CSVs collected by tools/profile_round.sh into a small markdown summary."""
-import csv, glob, sys, collections, os
+import csv, glob, sys, collections, os, re
 out, tag = sys.argv[1], sys.argv[2]
 
 def one(pattern):
@@ -40,7 +40,9 @@ f = one("trace/**/*kernel_trace.csv")
 if f:
     def is_stream(name):
         head = name.split("(")[0].replace(" ", "")
-        return "k_chol_dag" in head and head.endswith(",true>")
+        # template arguments <C, AUG, LAT, STREAM, WPE>: the fourth one (rounds 1-3 had three, the start of round 4 four)
+        m = re.search(r"k_chol_dag<([^>]*)>", head)
+        return bool(m) and len(m.group(1).split(",")) >= 4 and m.group(1).split(",")[3] == "true"
     rows = [r for r in csv.DictReader(open(f)) if is_stream(r["Kernel_Name"])]
     if rows:
         print("## every dispatch of the resident (stream) kernel, from the kernel trace\n")
