@@ -223,6 +223,16 @@ def test_sparse_rows_are_split_and_diagonal_is_preaccumulated():
     assert np.all(late["pb"] - late["pa"] == 1) and np.all(late["S"] >= 2)
 
 
+@pytest.mark.parametrize("B,nq", [(1, 1), (5, 5), (8, 8), (9, 1), (10, 2), (12, 4), (13, 1), (16, 8), (17, 1), (20, 4), (24, 8),
+                                  (25, 1), (28, 4), (31, 1), (32, 8), (256, 8)])
+def test_ticket_queues_in_use_follow_the_batch_size(B, nq):
+    """dag_queue_count: of 8, 4, 2, 1 queues the number that leaves the fullest queue relatively emptiest (ceil(B / n) x n),
+    the larger on a tie; up to eight matrices a queue each."""
+    plan(B, 6, 512)
+    first = plan.queue_first
+    assert sum(first[g + 1] > first[g] for g in range(8)) == nq
+
+
 def test_chain_bound_batches_get_one_workgroup_per_compute_unit():
     """dag_pick_workers: one persistent workgroup per compute unit -- the kernels compiled for one wave per SIMD -- while the
     batch's algorithmic flops stay below 3.3e9 x the block rows of its largest matrix (single evaluations, small batches of

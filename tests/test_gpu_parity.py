@@ -1,5 +1,7 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the
 golden vectors generated from the reference.  Run with `-m gpu` on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -175,6 +177,57 @@ def test_batch_matches_singles_and_oracle(golden, oracle):
         assert np.array_equal(prof, results[("dag", 1)])
         assert h.timings()["dag"]["launches"] == 1
         h.set_profiling(False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nw", [9, 12, 13, 17, 25])
+def test_batches_that_are_not_a_multiple_of_eight(oracle, nw):
+    """dag_queue_count: 9, 13, 17 and 25 matrices go through ONE ticket queue, 12 through four -- every value against the
+    oracle, the same bits on every repetition, and the same values (parity tolerance) whichever number of queues is forced."""
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_chunk(2, 7, 100, seed=77)           # N = 700: 6 block rows
+    gps = syn.make_walkers(2, nw, seed=5)
+    gps[nw // 2, 2] = -0.5                            # one rejected proposal inside the batch
+    lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, nw, seed=6))
+    want = np.array([oracle.lnlike(lw[w], ch.fl, ch.sigma, gps[w]) for w in range(nw)])
+    got = {}
+    try:
+        for nq in ("", "8", "4", "2", "1"):
+            if nq:
+                os.environ["PSOAP_DAG_QUEUES"] = nq
+            else:
+                os.environ.pop("PSOAP_DAG_QUEUES", None)
+            with ChunkHandle(ch.fl, ch.sigma, max_batch=nw) as h:
+                got[nq] = h.lnlike_batch(lw, gps)
+                for _ in range(3):
+                    assert np.array_equal(h.lnlike_batch(lw, gps), got[nq])
+            assert got[nq][nw // 2] == -np.inf and want[nw // 2] == -np.inf
+            for w in range(nw):
+                assert w == nw // 2 or lnp_close(got[nq][w], want[w]), (nq, w, got[nq][w], want[w])
+    finally:
+        os.environ.pop("PSOAP_DAG_QUEUES", None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,ne,npx,nw", [(1, 8, 250, 1), (2, 10, 300, 1), (3, 4, 128, 1), (1, 4, 128, 4), (2, 6, 100, 8)])
+def test_single_evaluation_kernels_give_the_same_bits_in_512_and_in_256_registers(c, ne, npx, nw):
+    """Launches with at most one workgroup per compute unit run the LAT kernels compiled for one wave per SIMD
+    (k_chol_dag<.., WPE = 1>); PSOAP_DAG_WIDE=0 keeps them on the 256-register forms: the same source, the same arithmetic,
+    bit-identical results."""
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_chunk(c, ne, npx, seed=31 + c)
+    gps = syn.make_walkers(c, nw, seed=9)
+    lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, nw, seed=10))
+    got = {}
+    try:
+        for wide in ("1", "0"):
+            os.environ["PSOAP_DAG_WIDE"] = wide
+            with ChunkHandle(ch.fl, ch.sigma, max_batch=nw) as h:
+                got[wide] = h.lnlike_batch(lw, gps)
+                assert np.array_equal(h.lnlike_batch(lw, gps), got[wide])
+    finally:
+        os.environ.pop("PSOAP_DAG_WIDE", None)
+    assert np.all(np.isfinite(got["1"])) and np.array_equal(got["1"], got["0"])
 
 
 @pytest.mark.parametrize("mode", ["dag", "staged"])
