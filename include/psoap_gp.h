@@ -21,11 +21,14 @@
  *
  * Several processes on one GPU (that reference's worker-per-chunk model with
  * more chunks than GPUs): the library serves them in turn -- an advisory lock
- * on /tmp/psoap_gpu_<PCI bus id>.lock is held from an evaluation's launch to
- * the fetch / sync that sees it complete, by every predict call, and by a
- * stream while it has tickets outstanding (the persistent kernels of several
- * processes must not be time-sliced against each other: DESIGN.md 5).  Within
- * a process it is counted.  PSOAP_DEVICE_LOCK=0 switches it off.
+ * on /tmp/psoap_gpu_<PCI bus id>.lock is held from an upload to the fetch /
+ * sync of the evaluation that reads it, by every other call that touches the
+ * device for its duration, and by a stream while it has tickets outstanding
+ * (persistent kernels of several processes must not share the device, and the
+ * device must not have to swap processes under them: DESIGN.md 5).  Within a
+ * process it is counted.  At most 8 processes per GPU: the library counts
+ * them (slot files beside the lock) and warns from the ninth.
+ * PSOAP_DEVICE_LOCK=0 switches lock and count off.
  */
 #ifndef PSOAP_GP_H
 #define PSOAP_GP_H

@@ -112,6 +112,58 @@ static void device_lock_release(int device)
     if (--it->second.refs == 0) (void)flock(it->second.fd, LOCK_UN);
 }
 
+// Everything else that touches the device (uploads, fills, handle set-up and tear-down) takes the lock for the duration of
+// the call: such work is harmless by itself, but queued beside ANOTHER process's persistent launch it makes the device
+// switch between the two (measured with the lock around launches only: one wrong value in 36,000 single evaluations of eight
+// workers, against one in a few hundred without any lock).
+// How many cooperating processes use a device: each holds one of 64 slot files (/tmp/psoap_gpu_<bus>.slot<k>, locked for
+// the life of the process).  The device keeps up to eight processes' address spaces mapped; a ninth makes the scheduler swap
+// processes in and out under running kernels, which the lock above cannot prevent (measured with 12 and 16 workers: 3-8
+// wrong values in 24,000 single evaluations, 5-7 ms per evaluation).  Warn once; PSOAP_DEVICE_LOCK=0 disables the count too.
+static std::map<int, int> g_slot_fd;
+static void device_slot_take(int device)
+{
+    if (!device_lock_enabled()) return;
+    std::lock_guard<std::mutex> g(g_devlock_mu);
+    static pid_t owner = 0;
+    if (owner != getpid()) {          // (descriptors inherited through fork() share their locks with the parent)
+        g_slot_fd.clear();
+        owner = getpid();
+    }
+    if (g_slot_fd.count(device)) return;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) snprintf(bus, sizeof bus, "index%d", device);
+    for (char* c = bus; *c; ++c)
+        if (!((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z'))) *c = '_';
+    int taken = -1;
+    const mode_t old = umask(0);
+    for (int k = 0; k < 64 && taken < 0; ++k) {
+        const std::string path = std::string("/tmp/psoap_gpu_") + bus + ".slot" + std::to_string(k);
+        const int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        if (fd < 0) break;
+        if (flock(fd, LOCK_EX | LOCK_NB) == 0) {
+            g_slot_fd[device] = fd;
+            taken = k;
+        } else {
+            (void)close(fd);
+        }
+    }
+    (void)umask(old);
+    if (taken >= 8)
+        fprintf(stderr,
+                "psoap: %d processes share GPU %s.  Beyond 8 the device swaps process contexts under running kernels: slower, "
+                "and results were observed to be corrupted now and then (DESIGN.md 5).  Use at most 8 worker processes per GPU.\n",
+                taken + 1, bus);
+}
+
+struct DeviceScope {
+    int dev;
+    explicit DeviceScope(int d) : dev(d) { device_lock_acquire(d); }
+    ~DeviceScope() { device_lock_release(dev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 // Owning device / pinned-host pointer: early returns free whatever was allocated so far.
 template <class T>
 struct DevBuf {
@@ -373,7 +425,18 @@ static int chunk_alloc(psoap_chunk* h, const double* fl, const double* sigma)
     // use, so that the streams of several handles spread over the runtime's hardware queues (handles that
     // evaluate concurrently must not share one).  Uploads run on a stream of their own.
     HIP_TRY(hipStreamCreateWithFlags(&h->streams[0], hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking));
+    // The uploads share the evaluation's stream.  (Rounds 1-3 gave them a stream of their own; the copies of the next
+    // proposals are blit kernels that get compute units only when the persistent launch leaves, so nothing overlapped
+    // anyway -- and every stream is a hardware queue: with three per process, eight worker processes on one GPU
+    // oversubscribe the device's queue slots, and the scheduler then rotates its run list under running kernels: 5.6-10 ms
+    // per single evaluation instead of 2.6, and a wrong value in 1-2 of 36,000 even with the device lock.  With two queues
+    // per process: 2.64 ms, none in 36,000.  A handle that uploads WHILE it evaluates -- the pipelined loops of bench.py and
+    // EnsembleEvaluator, one process per GPU -- gets its copy stream then (upload_begin: 0.6 % on a 32-walker step);
+    // PSOAP_COPY_STREAM=1 creates it here, =0 never.)
+    if (getenv("PSOAP_COPY_STREAM") && getenv("PSOAP_COPY_STREAM")[0] == '1')
+        HIP_TRY(hipStreamCreateWithFlags(&h->copy, hipStreamNonBlocking));
+    else
+        h->copy = h->streams[0];
     for (int g = 0; g < MAX_GROUPS; ++g) HIP_TRY(hipEventCreateWithFlags(&h->evDone[g], hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->evStaging, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&h->evLast, hipEventDisableTiming));
@@ -387,7 +450,9 @@ extern "C" int psoap_chunk_create(psoap_chunk** out, int device, int N, const do
 {
     if (!out || N <= 0 || max_batch <= 0 || !fl || !sigma) FAIL("psoap_chunk_create: bad arguments");
     *out = nullptr;
+    DeviceScope scope_(device);
     if (int rc = enter_device(device)) return rc;
+    device_slot_take(device);
     psoap_chunk* h = new psoap_chunk();
     h->device = device;
     h->N = N;
@@ -414,6 +479,7 @@ extern "C" int psoap_stream_close(psoap_chunk* h);
 extern "C" int psoap_chunk_destroy(psoap_chunk* h)
 {
     if (!h) return 0;
+    DeviceScope scope_(h->device);
     (void)hipSetDevice(h->device);
     if (h->stream.open) (void)psoap_stream_close(h);
     (void)hipDeviceSynchronize();
@@ -434,7 +500,7 @@ extern "C" int psoap_chunk_destroy(psoap_chunk* h)
         if (h->streams[g]) (void)hipStreamDestroy(h->streams[g]);
         if (h->evDone[g]) (void)hipEventDestroy(h->evDone[g]);
     }
-    if (h->copy) (void)hipStreamDestroy(h->copy);
+    if (h->copy && h->copy != h->streams[0]) (void)hipStreamDestroy(h->copy);
     if (h->evStaging) (void)hipEventDestroy(h->evStaging);
     if (h->evLast) (void)hipEventDestroy(h->evLast);
     for (auto e : h->evPool) (void)hipEventDestroy(e);
@@ -446,6 +512,7 @@ extern "C" int psoap_chunk_destroy(psoap_chunk* h)
 extern "C" int psoap_chunk_set_data(psoap_chunk* h, const double* fl, const double* sigma)
 {
     if (!h || !fl || !sigma) FAIL("psoap_chunk_set_data: bad arguments");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h->dFl, fl, sizeof(double) * h->N, hipMemcpyHostToDevice));
@@ -458,6 +525,7 @@ extern "C" int psoap_chunk_set_grid(psoap_chunk* h, const double* lwl, const int
     if (!h || !lwl || !epoch || n_epochs <= 0) FAIL("psoap_chunk_set_grid: bad arguments");
     for (int i = 0; i < h->N; ++i)
         if (epoch[i] < 0 || epoch[i] >= n_epochs) FAIL("psoap_chunk_set_grid: epoch index out of range");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     HIP_TRY(hipDeviceSynchronize());
     if (!h->dGrid) HIP_TRY(hipMalloc(&h->dGrid, sizeof(double) * h->N));
@@ -484,6 +552,7 @@ extern "C" int psoap_chunk_set_stream_groups(psoap_chunk* h, int groups)
 extern "C" int psoap_chunk_dag_tasklog(psoap_chunk* h, unsigned long long* out, long long max_tasks)
 {
     if (!h) FAIL("null handle");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     const long long tasks = 9ll * h->max_batch * h->P * (h->P + 1) / 2 + 1024;   // <= 8 parts per tile + early DIAG parts
     if (!h->dTlog) {
@@ -592,6 +661,7 @@ extern "C" int psoap_dag_pick_workers(int B, const int* Ps, int Mt, int compute_
 extern "C" int psoap_chunk_dag_tasks(psoap_chunk* h, void* out, long long max_tasks, long long* n_tasks)
 {
     if (!h || !n_tasks) FAIL("bad arguments");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     *n_tasks = h->plan_tasks;
     if (out && h->dTasks) {
@@ -627,6 +697,18 @@ static int upload_begin(psoap_chunk* h, int B, int c, const double* gp, double m
     // the staging buffers are free once the previous upload's copies have run (they were queued one
     // evaluation ago: normally long finished)
     HIP_TRY(hipEventSynchronize(h->evStaging));
+    // an upload under a running evaluation: from now on the copies have a stream of their own (see psoap_chunk_create)
+    if (h->copy == h->streams[0] && h->last_recorded && !(getenv("PSOAP_COPY_STREAM") && getenv("PSOAP_COPY_STREAM")[0] == '0')) {
+        const hipError_t q = hipEventQuery(h->evLast);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            hipStream_t cs = nullptr;
+            HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            h->copy = cs;
+        } else if (q != hipSuccess) {
+            HIP_TRY(q);
+        }
+    }
     // the slot's device arrays: the evaluation that last read them must be over before they are rewritten
     HIP_TRY(hipStreamWaitEvent(h->copy, sl.evEval, 0));
     sl.B = B;
@@ -639,6 +721,9 @@ static int upload_begin(psoap_chunk* h, int B, int c, const double* gp, double m
     memcpy(h->hGp, gp, sizeof(double) * (size_t)B * 2 * c);
     h->pend = target;
     *out = &sl;
+    // the copies queued behind this call run beside whatever else is on the device: the handle keeps the device from here
+    // to the fetch of the evaluation that reads them (psoap_lnlike: the whole call)
+    handle_lock(h);
     return 0;
 }
 
@@ -664,6 +749,7 @@ static int upload_end(psoap_chunk* h, BatchSlot& sl)
 extern "C" int psoap_batch_upload(psoap_chunk* h, int B, int c, const double* lwl, const double* gp, double mu_GP)
 {
     if (!h || !lwl || !gp) FAIL("psoap_batch_upload: bad arguments");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     BatchSlot* sl = nullptr;
     if (int rc = upload_begin(h, B, c, gp, mu_GP, &sl)) return rc;
@@ -679,6 +765,7 @@ extern "C" int psoap_batch_upload_velocities(psoap_chunk* h, int B, int c, const
 {
     if (!h || !vel || !gp) FAIL("psoap_batch_upload_velocities: bad arguments");
     if (!h->dGrid) FAIL("psoap_batch_upload_velocities: call psoap_chunk_set_grid first");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     BatchSlot* sl = nullptr;
     if (int rc = upload_begin(h, B, c, gp, mu_GP, &sl)) return rc;
@@ -698,6 +785,7 @@ extern "C" int psoap_chunk_set_dates(psoap_chunk* h, const double* dates, int n_
 {
     if (!h || !dates) FAIL("psoap_chunk_set_dates: bad arguments");
     if (!h->dGrid || n_epochs != h->n_epochs) FAIL("psoap_chunk_set_dates: call psoap_chunk_set_grid first (same n_epochs)");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     HIP_TRY(hipDeviceSynchronize());
     if (h->dDates) HIP_TRY(hipFree(h->dDates));
@@ -730,6 +818,7 @@ extern "C" int psoap_batch_upload_orbits(psoap_chunk* h, int B, int model, const
 {
     if (!h || !p_orb || !gp) FAIL("psoap_batch_upload_orbits: bad arguments");
     if (!h->dGrid || !h->dDates) FAIL("psoap_batch_upload_orbits: call psoap_chunk_set_grid and psoap_chunk_set_dates first");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     if (B < 1 || B > h->max_batch) FAIL("batch size outside [1, max_batch]");
     if (int rc = check_orbits(model, B, p_orb)) return rc;
@@ -757,6 +846,7 @@ extern "C" int psoap_orbit_velocities(int device, int model, int B, const double
 {
     if (B < 1 || n_dates < 1 || !p_orb || !dates || !vel_out) FAIL("psoap_orbit_velocities: bad arguments");
     if (int rc = check_orbits(model, B, p_orb)) return rc;
+    DeviceScope scope_(device);
     HIP_TRY(hipSetDevice(device));
     const int c = orbit_n_components(model), np = orbit_n_params(model);
     DevBuf<double> dP, dD, dV;
@@ -952,6 +1042,7 @@ static int eval_dag(psoap_chunk* h)
 extern "C" int psoap_batch_eval(psoap_chunk* h)
 {
     if (!h) FAIL("psoap_batch_eval: null handle");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     if (int rc = promote_slot(h, "psoap_batch_eval")) return rc;
     // the persistent kernel indexes block rows with 8 bits; beyond N = 32640 use the staged path
@@ -1102,6 +1193,7 @@ extern "C" int psoap_group_create(psoap_group** out, psoap_chunk* const* handles
         if (handles[k]->P > 255) FAIL("psoap_group_create: N too large for the persistent kernel (N <= 32640)");
     }
     *out = nullptr;
+    DeviceScope scope_(handles[0]->device);
     HIP_TRY(hipSetDevice(handles[0]->device));
     psoap_group* g = new psoap_group();
     g->device = handles[0]->device;
@@ -1120,6 +1212,7 @@ extern "C" int psoap_group_create(psoap_group** out, psoap_chunk* const* handles
 extern "C" int psoap_group_destroy(psoap_group* g)
 {
     if (!g) return 0;
+    DeviceScope scope_(g->device);
     (void)hipSetDevice(g->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(g->dDag); (void)hipFree(g->dMats); (void)hipFree(g->dTasks); (void)hipFree(g->dWs);
@@ -1443,6 +1536,7 @@ extern "C" int psoap_stream_open(psoap_chunk* h, int c, int lanes, int scheme)
     if (scheme < -1 || scheme > 2) FAIL("psoap_stream_open: scheme must be -1 (automatic), 0, 1 or 2");
     if (h->P > 255) FAIL("psoap_stream_open: N too large for the persistent kernel (N <= 32640)");
     if (h->stream.open) FAIL("psoap_stream_open: the handle already has an open stream");
+    DeviceScope scope_(h->device);
     if (int rc = enter_device(h->device)) return rc;
     if (int rc = psoap_chunk_sync(h)) return rc;         // batch evaluations of this handle use the same workspaces
     // the lanes' proposal arrays are those of proposal slot 0: whatever batch was uploaded is gone
@@ -1464,6 +1558,7 @@ static int stream_submit_impl(psoap_chunk* h, int n, int kind, int model, const 
 {
     StreamState& st = h->stream;
     if (!st.open) { g_err = std::string(who) + ": no open stream (psoap_stream_open)"; return 2; }
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     if (st.hHost->error != 0u) { g_err = std::string(who) + ": the stream has failed (a dependency wait timed out); close it"; return 2; }
     int free_lanes = 0;
@@ -1554,6 +1649,7 @@ extern "C" int psoap_stream_wait_any(psoap_chunk* h, int n, const long long* tic
     if (!h || !tickets || !which || n < 1) FAIL("psoap_stream_wait_any: bad arguments");
     StreamState& st = h->stream;
     if (!st.open) FAIL("psoap_stream_wait_any: no open stream");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     for (int k = 0; k < n; ++k)
         if (tickets[k] < 0 || (unsigned long long)tickets[k] >= st.head) FAIL("psoap_stream_wait_any: unknown ticket");
@@ -1586,6 +1682,7 @@ extern "C" int psoap_stream_fetch(psoap_chunk* h, int n, const long long* ticket
     if (!h || !tickets || !out || n < 1) FAIL("psoap_stream_fetch: bad arguments");
     StreamState& st = h->stream;
     if (!st.open) FAIL("psoap_stream_fetch: no open stream");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     for (int k = 0; k < n; ++k) {
         const long long t = tickets[k];
@@ -1628,6 +1725,7 @@ extern "C" int psoap_stream_stats(psoap_chunk* h, long long* launches, long long
                                   int* scheme, long long* tasks_per_matrix)
 {
     if (!h || !h->stream.open) FAIL("psoap_stream_stats: no open stream");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     const StreamState& st = h->stream;
     if (launches) *launches = st.launches;
@@ -1649,6 +1747,7 @@ extern "C" int psoap_stream_tasklog(psoap_chunk* h, int cap, unsigned long long*
 {
     if (!h || !h->stream.open || cap < 1) FAIL("psoap_stream_tasklog: bad arguments / no open stream");
     StreamState& st = h->stream;
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     const size_t words = (size_t)cap * st.n_tasks * 8;
     if (!out) {
@@ -1672,6 +1771,7 @@ extern "C" int psoap_stream_tasklog(psoap_chunk* h, int cap, unsigned long long*
 extern "C" int psoap_stream_tasks(psoap_chunk* h, void* out, long long max_tasks, long long* n_tasks)
 {
     if (!h || !h->stream.open || !n_tasks) FAIL("psoap_stream_tasks: bad arguments / no open stream");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     const StreamState& st = h->stream;
     *n_tasks = st.n_tasks;
@@ -1707,6 +1807,7 @@ extern "C" int psoap_stream_pause(psoap_chunk* h)
     if (!h) FAIL("psoap_stream_pause: null handle");
     StreamState& st = h->stream;
     if (!st.open) FAIL("psoap_stream_pause: no open stream");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     if (!st.launched) return 0;
     __atomic_store_n(&st.hHost->close, 1u, __ATOMIC_RELEASE);
@@ -1733,6 +1834,7 @@ extern "C" int psoap_stream_close(psoap_chunk* h)
     if (!h) FAIL("psoap_stream_close: null handle");
     StreamState& st = h->stream;
     if (!st.open) return 0;
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     int rc = 0;
     // what is in flight completes; what was published but never opened needs a launch to be consumed
@@ -1752,10 +1854,11 @@ extern "C" int psoap_stream_close(psoap_chunk* h)
 extern "C" int psoap_batch_fetch(psoap_chunk* h, double* out)
 {
     if (!h || !out || h->act < 0 || h->slot[h->act].B < 1) FAIL("psoap_batch_fetch: nothing evaluated");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     const BatchSlot& sl = h->slot[h->act];
     const hipError_t e_sync = hipStreamSynchronize(h->streams[0]);
-    handle_unlock(h);
+    if (h->pend < 0) handle_unlock(h);      // (an upload queued for the next evaluation keeps the device)
     HIP_TRY(e_sync);
     if (collect_timings(h)) return 1;
     if (h->mode == 1 && h->P <= 255 && h->hDagErr[0] != 0) {
@@ -1778,6 +1881,7 @@ extern "C" int psoap_batch_fetch(psoap_chunk* h, double* out)
 extern "C" int psoap_chunk_sync(psoap_chunk* h)
 {
     if (!h) FAIL("null handle");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     hipError_t e = hipSuccess;
     for (int g = 0; g < MAX_GROUPS; ++g)
@@ -1803,6 +1907,8 @@ extern "C" int psoap_lnlike_batch(psoap_chunk* h, int B, int c, const double* lw
     for (int b = 0; b < B; ++b) all_neg = all_neg && h->slot[h->pend].neg[b];
     if (all_neg) {  // covariance.py:317-318: -inf before any work
         for (int b = 0; b < B; ++b) out[b] = -INFINITY;
+        (void)hipStreamSynchronize(h->copy);      // (the upload's copies; nothing else was queued)
+        handle_unlock(h);
         return 0;
     }
     if (int rc = psoap_batch_eval(h)) return rc;
@@ -1819,6 +1925,7 @@ extern "C" int psoap_fill_sym(int device, int c, int N, const double* lwl, const
                               double* out)
 {
     if (c < 1 || c > 3 || N <= 0 || !lwl || !gp || !out) FAIL("psoap_fill_sym: bad arguments");
+    DeviceScope scope_(device);
     HIP_TRY(hipSetDevice(device));
     const int Npad = round_up(N, NB), P = Npad / NB;
     DevBuf<double> dK, dLwl, dGp, dSig;
@@ -1848,6 +1955,7 @@ extern "C" int psoap_fill_cross(int device, int M, int N, const double* lwl_row,
                                 double l, double* out)
 {
     if (M <= 0 || N <= 0 || !lwl_row || !lwl_col || !out) FAIL("psoap_fill_cross: bad arguments");
+    DeviceScope scope_(device);
     HIP_TRY(hipSetDevice(device));
     const int ld = round_up(N, 2);
     DevBuf<double> dO, dRow, dCol;
@@ -1881,6 +1989,7 @@ extern "C" int psoap_predict(int device, int mode, int c, int N, int M, const do
 {
     if (!fl || !sigma) FAIL("psoap_predict: bad arguments");
     if (int rc = predict_check(mode, c, N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
+    DeviceScope scope_(device);
     if (int rc = enter_device(device)) return rc;
     PredictWs ws;
     if (int rc = dag_workers(device, &ws.workers, &ws.n_cus)) return rc;
@@ -1915,6 +2024,7 @@ extern "C" int psoap_predictor_create(psoap_predictor** out, int device)
 {
     if (!out) FAIL("psoap_predictor_create: bad arguments");
     *out = nullptr;
+    DeviceScope scope_(device);
     if (int rc = enter_device(device)) return rc;
     psoap_predictor* p = new psoap_predictor();
     p->device = device;
@@ -1929,6 +2039,7 @@ extern "C" int psoap_predictor_create(psoap_predictor** out, int device)
 extern "C" int psoap_predictor_destroy(psoap_predictor* p)
 {
     if (!p) return 0;
+    DeviceScope scope_(p->device);
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
     delete p;
@@ -1941,6 +2052,7 @@ extern "C" int psoap_predictor_run(psoap_predictor* p, int mode, int c, int N, i
 {
     if (!p || !fl || !sigma) FAIL("psoap_predictor_run: bad arguments");
     if (int rc = predict_check(mode, c, N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
+    DeviceScope scope_(p->device);
     if (int rc = enter_device(p->device)) return rc;
     int status = 0;
     device_lock_acquire(p->device);
@@ -1958,6 +2070,7 @@ extern "C" int psoap_predictor_run_var(psoap_predictor* p, int mode, int c, int 
 {
     if (!p || !fl || !sigma || !var_out) FAIL("psoap_predictor_run_var: bad arguments");
     if (int rc = predict_check(mode, c, N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
+    DeviceScope scope_(p->device);
     if (int rc = enter_device(p->device)) return rc;
     int status = 0;
     device_lock_acquire(p->device);
@@ -2003,6 +2116,7 @@ static int chunk_predict(psoap_chunk* h, int mode, int c, int M, const double* l
 {
     if (!h) FAIL("psoap_chunk_predict: null handle");
     if (int rc = predict_check(mode, c, h->N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
+    DeviceScope scope_(h->device);
     if (int rc = enter_device(h->device)) return rc;
     if (!h->pws) {
         h->pws = new PredictWs();
@@ -2030,6 +2144,7 @@ extern "C" int psoap_chunk_predict_timings(psoap_chunk* h, psoap_predict_timings
 extern "C" int psoap_chunk_predict_release(psoap_chunk* h)
 {
     if (!h) FAIL("psoap_chunk_predict_release: null handle");
+    DeviceScope scope_(h->device);
     if (set_dev(h)) return 1;
     delete h->pws;
     h->pws = nullptr;
@@ -2052,6 +2167,7 @@ extern "C" int psoap_calibrate(int device, int c, int M, int N, int order, doubl
     if (c < 1 || c > 3 || calibrate_check(M, N, order, lwl0, lwl1) || !lwl_cal || !lwls_cal || !fl_cal || !sigma_cal ||
         !lwls_fixed || !fl_fixed || !sigma_fixed || !gp || !fl_cor || !X)
         FAIL("psoap_calibrate: bad arguments");
+    DeviceScope scope_(device);
     if (int rc = enter_device(device)) return rc;
     CalibInputs in{};
     in.M = M; in.N = N; in.order = order; in.lwl0 = lwl0; in.lwl1 = lwl1; in.mu = mu_GP;
@@ -2071,6 +2187,7 @@ extern "C" int psoap_calibrate_explicit(int device, int M, int N, int order, dou
 {
     if (calibrate_check(M, N, order, lwl0, lwl1) || !lwl_cal || !fl_cal || !fl_fixed || !A || !B || !C || !fl_cor || !X)
         FAIL("psoap_calibrate_explicit: bad arguments");
+    DeviceScope scope_(device);
     if (int rc = enter_device(device)) return rc;
     CalibInputs in{};
     in.M = M; in.N = N; in.order = order; in.lwl0 = lwl0; in.lwl1 = lwl1; in.mu = mu_GP;

@@ -1,4 +1,4 @@
-"""Phase stamps of the fused diagonal tasks (matrix 0, block rows 18..26): python tools/diag_phases.py CFG B"""
+"""Phase stamps of the fused diagonal tasks (matrix 0, block rows Q0..Q1, default 18..26): python tools/diag_phases.py CFG B [Q0 Q1]"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -6,6 +6,8 @@ from psoap_amd import synthetic as syn
 from psoap_amd.chunk import ChunkHandle
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+Q0 = int(sys.argv[3]) if len(sys.argv) > 3 else 18
+Q1 = int(sys.argv[4]) if len(sys.argv) > 4 else 26
 ch = syn.make_config_chunk(cfg)
 gps = syn.make_walkers(ch.n_components, B, seed=1); lw = np.repeat(ch.lwls[None], B, axis=0)
 task_dt = np.dtype([("type", "u1"), ("q", "u1"), ("j", "u1"), ("S", "u1"), ("b", "<u2"), ("pa", "u1"), ("pb", "u1"), ("slot", "<u4"), ("ctr", "<u4")])
@@ -19,7 +21,7 @@ with ChunkHandle(ch.fl, ch.sigma, max_batch=B) as h:
     log = np.zeros(nt * 8, dtype=np.uint64)
     h._L.psoap_chunk_dag_tasklog(h._h, log.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), nt)
 log = log.reshape(nt, 8).astype(np.float64) / 100.0
-d = np.where(((tasks["type"] & 0x0F) == 1) & (tasks["q"] >= 18) & (tasks["q"] <= 26) & (tasks["b"] == 0))[0]
+d = np.where(((tasks["type"] & 0x0F) == 1) & (tasks["q"] >= Q0) & (tasks["q"] <= Q1) & (tasks["b"] == 0))[0]
 d = d[np.argsort(tasks["q"][d])]
 base = log[d, 4].min()
 prev_end = None
