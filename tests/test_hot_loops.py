@@ -97,6 +97,17 @@ def test_build_falls_back_when_the_default_flags_show_the_defect(tmp_path, monke
         calls.append(len(text))
         return asmcheck.scan_exec_restore(faulty if len(calls) == 1 else text)
 
+    # (rung 0 is the library in the tree -- built from these sources with these flags, test above -- so only the fallback
+    # rung is compiled here: it has to keep compiling, and one compilation of the library is two and a half minutes)
+    build.build()
+    real_compile = build.compile_once
+
+    def compile_rung(flags, out_dir):
+        if flags == []:
+            return build.LIB_PATH, build.ASM_PATH
+        return real_compile(flags, out_dir)
+
+    monkeypatch.setattr(build, "compile_once", compile_rung)
     so, asm, rec = build.compile_checked([], str(tmp_path), scan=scan_first_rung_faulty)
     assert len(calls) == 2 and rec["fallback_rung"] == 1
     assert rec["rejected"] == [{"flags": [], "kernels": ["k_chol_dag<3,true,true>"]}]
