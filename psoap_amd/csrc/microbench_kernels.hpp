@@ -495,6 +495,17 @@ inline int microbench_hbm(double* write_gbs, double* copy_gbs, std::string& err)
             const double gbs = 5.0 * bytes / (ms * 1e-3) / 1e9;
             if (gbs > *write_gbs) *write_gbs = gbs;
         }
+    // (8 bytes per lane is the fastest store width on this part: PSOAP_WRITE_SWEEP below)
+    for (int g : {16384, 65536}) {
+        MB_TRY(hipEventRecord(e0, 0));
+        for (int r = 0; r < 5; ++r)
+            hipLaunchKernelGGL(k_stream_write_narrow<2>, dim3(g), dim3(256), 0, 0, (unsigned int*)b, bytes / 4, 7u);
+        MB_TRY(hipEventRecord(e1, 0));
+        MB_TRY(hipEventSynchronize(e1));
+        MB_TRY(hipEventElapsedTime(&ms, e0, e1));
+        const double gbs = 5.0 * bytes / (ms * 1e-3) / 1e9;
+        if (gbs > *write_gbs) *write_gbs = gbs;
+    }
     if (getenv("PSOAP_WRITE_SWEEP")) {
         const int grids[] = {1024, 2048, 4096, 8192, 16384};
         for (int variant = 0; variant < 3; ++variant)
