@@ -230,6 +230,9 @@ def main():
                     help="stream: the timed steps through ONE resident launch (two half-ensembles in flight); dag / staged: "
                          "one launch (three per panel) per step")
     ap.add_argument("--stream-groups", type=int, default=2, help="sub-ensembles in flight in --mode stream")
+    ap.add_argument("--stream-reserve", type=int, default=-1,
+                    help="workgroup slots the resident launch leaves free for the gather's kernels (-1: 8 with several ranks "
+                         "over RCCL, else 0)")
     ap.add_argument("--allow-fallback", action="store_true",
                     help="print `value` even if the library was built from the fallback flag rung (psoap_amd/build.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -345,7 +348,22 @@ def main():
     if args.mode == "stream":
         if B % args.stream_groups:
             raise SystemExit("--walkers must be a multiple of --stream-groups")
+        # several ranks over RCCL: the gather's kernels (staging copies, all_gather) run on another stream while the launch
+        # is resident -- it leaves a few workgroup slots free for them (tests/test_gpu_workers.py measures it)
+        stream_reserve = args.stream_reserve if args.stream_reserve >= 0 else (8 if (world > 1 and args.backend == "nccl") else 0)
+        if stream_reserve:
+            h.set_stream_reserve(stream_reserve)
         pipe = StreamPipeline(h, c, B, args.stream_groups)
+        half = {"table": np.zeros((world, B)), "total": np.zeros(B)}
+
+        def gather_half(g, rows, lnp_rows):
+            """a sub-ensemble's lnprobs over the ranks BEFORE its successor is submitted: a sampler's next proposals
+            depend on the chunk sum (sample_parallel.py:378-390)"""
+            t = gather_chunk_lnprobs(lnp_rows[None, :], world, world, rank, local_rank)
+            if world > 1:
+                collectives["n"] += 1
+            half["table"][:, rows] = t
+            half["total"][rows] = sum_over_chunks(t)
 
         def run_stream_shared(n_steps):
             """the dry-run form: a step's sub-ensembles go through the stream together and the resident launch leaves
@@ -363,14 +381,12 @@ def main():
             if shared_gpu:
                 return run_stream_shared(n_steps)
             pipe.start(*sets[0])
-            lnp = None
             for k in range(1, n_steps):
-                lnp = pipe.step(*sets[k & 1])          # results of step k - 1, proposals of step k submitted
-                table, total = gather(lnp)
-            lnp = pipe.drain()
-            table, total = gather(lnp)
+                # per sub-ensemble: results of step k - 1 -> gather over the ranks -> proposals of step k submitted
+                pipe.step(*sets[k & 1], between=gather_half)
+            pipe.drain(between=gather_half)
             h.stream_pause()                           # the resident launch leaves: the device is free again
-            return table, total, (n_steps - 1) & 1
+            return half["table"].copy(), half["total"].copy(), (n_steps - 1) & 1
 
         if args.warmup > 0:
             # the warm-up steps also give the period the timed region's start-up stagger is set from (they start in
@@ -531,11 +547,12 @@ def main():
                                    f"one chunk per GPU (BASELINE.json configs[2]; configs[3] at 8 GPUs); " +
                                    (f"the {args.steps} timed steps through ONE resident launch, {args.stream_groups} sub-ensembles "
                                     f"of {B // args.stream_groups} walkers in flight (proposals pulled from pinned host memory, "
-                                    f"{B} lnprobs per step written to it), gather per step"
+                                    f"{B} lnprobs per step written to it), every sub-ensemble gathered over the ranks before its successor is submitted"
                                     if args.mode == "stream" else
                                     f"timed step = H2D of next proposals || eval, D2H of {B} lnprobs, gather"),
                        "N": N, "components": c, "walkers": B, "chunks_per_gpu": 1, "mode": args.mode,
                        "stream_groups": args.stream_groups if args.mode == "stream" else args.groups,
+                       "stream_reserve": stream_reserve if args.mode == "stream" else 0,
                        "parallelism": f"chunk-sharded x{world}, RCCL all_gather of walker lnprobs"},
             "timing_boundary": ("pcie_inclusive (every proposal is pulled from pinned host memory by the resident launch, "
                                 "every result written to it; the timed region starts and ends with nothing in flight and "

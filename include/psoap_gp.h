@@ -20,15 +20,28 @@
  * fork(), as psoap/sample_parallel.py:258-278 requires).
  *
  * Several processes on one GPU (that reference's worker-per-chunk model with
- * more chunks than GPUs): the library serves them in turn -- an advisory lock
- * on /tmp/psoap_gpu_<PCI bus id>.lock is held from an upload to the fetch /
- * sync of the evaluation that reads it, by every other call that touches the
- * device for its duration, and by a stream while it has tickets outstanding
- * (persistent kernels of several processes must not share the device, and the
- * device must not have to swap processes under them: DESIGN.md 5).  Within a
- * process it is counted.  At most 8 processes per GPU: the library counts
- * them (slot files beside the lock) and warns from the ninth.
- * PSOAP_DEVICE_LOCK=0 switches lock and count off.
+ * more chunks than GPUs, psoap/sample_parallel.py:258-278):
+ *   - the library serves them in turn: an advisory lock on
+ *     <dir>/gpu_<PCI bus id>.lock is held from an upload to the fetch / sync of
+ *     the evaluation that reads it, by every other call that touches the device
+ *     for its duration, and by a stream while it has tickets outstanding
+ *     (released only once its resident launch has left the device when other
+ *     processes are there).  <dir> = $PSOAP_LOCK_DIR, else
+ *     $XDG_RUNTIME_DIR/psoap, else /tmp/psoap-<uid>: per user, 0700.  Within a
+ *     process the lock is counted.  A wait longer than
+ *     PSOAP_DEVICE_LOCK_TIMEOUT_S (300) is an error that names the holder.
+ *   - the processes are counted (slot files beside the lock);
+ *   - every persistent launch reports workgroups that the device's scheduler
+ *     moved between compute units while a task ran (the one disturbance its
+ *     hand-off protocol does not survive): such an evaluation is
+ *     run again (PSOAP_SHARE_RETRIES, 3; bit-identical when clean), then by the
+ *     staged path (kernel boundaries only).  A result is never silently wrong;
+ *   - with PSOAP_DEVICE_LOCK=0 and several processes on the device, or more
+ *     than PSOAP_SHARE_DAG_MAX (8) of them, evaluations take the staged path
+ *     from the start and without the lock (kernel boundaries only: immune, and
+ *     the device interleaves the processes' kernels); psoap_stream_open is
+ *     refused there.  PSOAP_SHARE_POLICY=dag|staged pins the path.
+ *   psoap_share_stats reports what all this cost.
  */
 #ifndef PSOAP_GP_H
 #define PSOAP_GP_H
@@ -45,6 +58,25 @@ typedef struct psoap_chunk psoap_chunk; /* opaque per-chunk device state */
 int psoap_version(void);
 const char *psoap_last_error(void);
 int psoap_device_count(int *count);
+
+/* What sharing a device with other processes has cost THIS process so far
+ * (process-wide counters; out[k], k < min(n, PSOAP_SHARE_N)). */
+enum {
+    PSOAP_SHARE_PROCS = 0,            /* processes with a slot on the device now (this one included) */
+    PSOAP_SHARE_DAG_LAUNCHES = 1,     /* persistent launches issued */
+    PSOAP_SHARE_TAINTED = 2,          /* ... that reported a moved workgroup (results withheld) */
+    PSOAP_SHARE_RETRIES = 3,          /* evaluations issued again because of that */
+    PSOAP_SHARE_STAGED_FALLBACKS = 4, /* evaluations that went to the staged path after the retries */
+    PSOAP_SHARE_STAGED_POLICY = 5,    /* evaluations sent down the staged path from the start */
+    PSOAP_SHARE_MOVED_TASKS = 6,      /* tasks that ended on another compute unit than they started on */
+    PSOAP_SHARE_MOVED_XCD = 7,        /* ... on another XCD */
+    PSOAP_SHARE_LOCK_ACQUISITIONS = 8,
+    PSOAP_SHARE_LOCK_WAIT_US = 9,
+    PSOAP_SHARE_STREAM_RESUBMITS = 10,
+    PSOAP_SHARE_LOCK_ENABLED = 11,
+    PSOAP_SHARE_N = 12
+};
+int psoap_share_stats(int device, long long *out, int n);
 
 /* ---- per-chunk handle ---------------------------------------------------------
  * Replaces the per-chunk state of Worker.initialize (psoap/sample_parallel.py:
@@ -292,6 +324,11 @@ int psoap_stream_pause(psoap_chunk *h);
 int psoap_stream_last_launch(psoap_chunk *h, double *ms, long long *matrices);
 /* waits for what is in flight, ends the resident launch, frees the stream */
 int psoap_stream_close(psoap_chunk *h);
+/* Workgroup slots (of the 2 x compute-units a resident launch would occupy) that the stream's launch leaves free, so that
+ * kernels of OTHER streams -- the RCCL all_gather of the walker lnprobs (psoap/sample_parallel.py:378-387) and its
+ * staging copies -- run beside it instead of waiting for it to leave.  Call before psoap_stream_open; 0 (default): the
+ * launch takes the whole device.  Results do not depend on it. */
+int psoap_chunk_set_stream_reserve(psoap_chunk *h, int workgroups);
 /* counters: launches of the resident kernel so far (> 1 after an idle time-out), submissions, completed results, the
  * scheme of the lanes' task list and its length; any pointer may be NULL */
 int psoap_stream_stats(psoap_chunk *h, long long *launches, long long *submitted, long long *completed, int *scheme,

@@ -42,6 +42,7 @@ SIGNATURES = {
     "psoap_version": (ctypes.c_int, []),
     "psoap_last_error": (ctypes.c_char_p, []),
     "psoap_device_count": (ctypes.c_int, [_ip]),
+    "psoap_share_stats": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), ctypes.c_int]),
     "psoap_chunk_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, _dp, _dp, ctypes.c_int]),
     "psoap_chunk_destroy": (ctypes.c_int, [_vp]),
     "psoap_chunk_set_data": (ctypes.c_int, [_vp, _dp, _dp]),
@@ -93,6 +94,7 @@ SIGNATURES = {
     "psoap_stream_wait_any": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), _ip]),
     "psoap_stream_ready": (ctypes.c_int, [_vp, ctypes.c_longlong, _ip]),
     "psoap_stream_close": (ctypes.c_int, [_vp]),
+    "psoap_chunk_set_stream_reserve": (ctypes.c_int, [_vp, ctypes.c_int]),
     "psoap_stream_pause": (ctypes.c_int, [_vp]),
     "psoap_stream_last_launch": (ctypes.c_int, [_vp, _dp, ctypes.POINTER(ctypes.c_longlong)]),
     "psoap_stream_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong),
@@ -194,6 +196,20 @@ def as_f64(a, shape=None) -> np.ndarray:
     if shape is not None and out.shape != tuple(shape):
         raise ValueError(f"expected shape {tuple(shape)}, got {out.shape}")
     return out
+
+
+SHARE_NAMES = ("procs", "dag_launches", "tainted", "retries", "staged_fallbacks", "staged_policy", "moved_tasks", "moved_xcd",
+               "lock_acquisitions", "lock_wait_us", "stream_resubmits", "lock_enabled")
+
+
+def share_stats(device: int | None = None) -> dict:
+    """What sharing the GPU with other processes has cost this process so far (include/psoap_gp.h: PSOAP_SHARE_*):
+    persistent launches, how many were disturbed by the device's scheduler (``tainted``) and run again (``retries``) or
+    sent down the staged path (``staged_fallbacks``; ``staged_policy``: from the start), time spent waiting for the device."""
+    out = (ctypes.c_longlong * len(SHARE_NAMES))()
+    check(load().psoap_share_stats(default_device() if device is None else int(device), out, len(SHARE_NAMES)),
+          "psoap_share_stats")
+    return dict(zip(SHARE_NAMES, (int(v) for v in out)))
 
 
 def default_device() -> int:

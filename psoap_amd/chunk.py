@@ -73,6 +73,11 @@ class ChunkHandle:
         m = {"staged": 0, "dag": 1}.get(mode, mode)
         check(self._L.psoap_chunk_set_mode(self._h, int(m)), "psoap_chunk_set_mode")
 
+    def set_stream_reserve(self, workgroups: int):
+        """Workgroup slots a resident stream launch leaves free for kernels of other streams -- the RCCL gather of
+        ``psoap_amd.ensemble`` runs beside the launch instead of behind it.  Before ``stream_open``."""
+        check(self._L.psoap_chunk_set_stream_reserve(self._h, int(workgroups)), "psoap_chunk_set_stream_reserve")
+
     def set_profiling(self, enabled: bool):
         check(self._L.psoap_chunk_set_profiling(self._h, int(bool(enabled))), "psoap_chunk_set_profiling")
 
@@ -166,6 +171,10 @@ class ChunkHandle:
         """orbital parameters (n, n_orb): Kepler solve, |v| >= c rule and Doppler shift inside the resident launch"""
         p_orb = as_f64(np.atleast_2d(p_orb))
         n = p_orb.shape[0]
+        from .utils import MODEL_ID, n_params_orb
+        width = {MODEL_ID[m]: n_params_orb[m] for m in MODEL_ID}.get(int(model_id))
+        if width is None or p_orb.shape[1] != width:       # (the library copies exactly that many doubles per proposal)
+            raise ValueError(f"p_orb must have shape (n, {width}) for orbit model {model_id}")
         gps = as_f64(gps, (n, 2 * self._stream_c))
         tickets = np.empty(n, dtype=np.int64)
         check(self._L.psoap_stream_submit_orbits(self._h, n, int(model_id), dptr(p_orb), dptr(gps), float(mu_GP),
@@ -321,10 +330,15 @@ class StreamPipeline:
                 pass
             self._go(g, arrays, mu_GP)
 
-    def step(self, *arrays, mu_GP: float = 1.0) -> np.ndarray:
+    def step(self, *arrays, mu_GP: float = 1.0, between=None) -> np.ndarray:
+        """``between(g, rows, lnp_rows)``: called for every group after its results are in and BEFORE its successor is
+        submitted -- where a sampler decides accept / reject, and where several ranks exchange the group's lnprobs
+        (the gather of /root/reference/psoap/sample_parallel.py:378-387: the next proposals depend on the chunk sum)."""
         out = np.empty(self.walkers)
         for g, r in enumerate(self.rows):
             out[r] = self.h.stream_fetch(self.tickets[g])
+            if between is not None:
+                between(g, r, out[r])
             self._go(g, arrays, mu_GP)
         return out
 
@@ -343,10 +357,12 @@ class StreamPipeline:
             self._go(g, arrays, mu_GP)
         return out
 
-    def drain(self) -> np.ndarray:
+    def drain(self, between=None) -> np.ndarray:
         out = np.empty(self.walkers)
         for g, r in enumerate(self.rows):
             out[r] = self.h.stream_fetch(self.tickets[g])
+            if between is not None:
+                between(g, r, out[r])
             self.tickets[g] = None
         return out
 

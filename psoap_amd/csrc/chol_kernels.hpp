@@ -103,7 +103,7 @@ __device__ __forceinline__ void potrf_phase(double (&R)[8][8], double (*rowbuf)[
 
 __global__ __launch_bounds__(512, 2) void k_potrf_diag(double* __restrict__ Kbase, size_t mat_stride, int ld, int k0,
                                                       double* __restrict__ Wt, double* __restrict__ Rbase, int Npad,
-                                                      MatAcc* __restrict__ acc)
+                                                      MatAcc* __restrict__ acc, size_t wt_stride = (size_t)NB * NB)
 {
     __shared__ double rowbuf[2][256];
     __shared__ double rk[NB];
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void k_potrf_diag(double* __restrict__ Kbas
     __syncthreads();
 
     // outputs: U11, Wt, z, accumulators
-    double* Wm = Wt + (size_t)bidx * NB * NB;
+    double* Wm = Wt + (size_t)bidx * wt_stride;     // (a chunk handle: the persistent kernel's spacing, tile 0 of each matrix)
     double logpart = 0.0, quadpart = 0.0;
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
@@ -188,7 +188,8 @@ __global__ __launch_bounds__(512, 2) void k_potrf_diag(double* __restrict__ Kbas
 // right-hand side  r[j0:j0+128] -= X^T z_k  so the triangular solve costs no extra pass.
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trsm_strip(double* __restrict__ Kbase, size_t mat_stride,
                                                                int ld, int k0, const double* __restrict__ Wt,
-                                                               double* __restrict__ Rbase, int Npad)
+                                                               double* __restrict__ Rbase, int Npad,
+                                                               size_t wt_stride = (size_t)NB * NB)
 {
     __shared__ double zk[NB];
     __shared__ double colsum[NB];
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trsm_strip(double* __restri
     if (tid < NB) zk[tid] = Rv[k0 + tid];
     Tile t;
     t.zero();
-    tile_gemm_tn_lower(t, Wt + (size_t)bidx * NB * NB, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld);
+    tile_gemm_tn_lower(t, Wt + (size_t)bidx * wt_stride, (size_t)NB, Km + (size_t)k0 * ld + j0, (size_t)ld);
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     double part[4] = {0.0, 0.0, 0.0, 0.0};

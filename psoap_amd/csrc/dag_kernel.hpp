@@ -87,7 +87,9 @@ constexpr int DAG_QUEUES = 8;   // one ticket queue per XCD (MI355X: 8 XCDs, eac
 struct alignas(64) DagCtl {
     unsigned int reserved;
     unsigned int error;
-    unsigned int pad[14];                 // pad[0..2]: diagnostics of the first timed-out wait
+    unsigned int pad[14];                 // pad[0..2]: diagnostics of the first timed-out wait; pad[3]: tasks whose workgroup
+                                          // MOVED to another compute unit while they ran (dag_where: the launch is tainted
+                                          // and the host evaluates again); pad[4]: those that changed the XCD as well
     struct alignas(64) {
         unsigned int next;                // next ticket of this queue
         unsigned int fill[15];
@@ -99,6 +101,29 @@ struct DagQueues {
     unsigned int first[DAG_QUEUES + 1];
     unsigned int follow_first;      // scheme 2: the first block row whose strip solves follow (0, or 2: PSOAP_FOLLOW_ROW0=0)
 };
+// Ready-only hand-out of the PART tasks (round 5; the latency schemes' plain launches: k_chol_dag<.., LAT = true, STREAM =
+// false>).  With ONE in-order ticket list a workgroup that draws a PART whose panels or predecessor are not there yet holds
+// it and waits -- 80-130 of the 256 workgroups of a single N = 6000 evaluation at any time (profiles/r3_wg_occupancy.txt),
+// while ready PARTs further down the list wait for a workgroup.  The list is therefore handed out in two parts per queue:
+//   main  the finals (DIAG / OFF / SCHUR), in the list's order, from a ticket counter as before -- but a final with a chain
+//         is only handed out once the chain's LAST part has been taken (so whoever holds a final waits for running work only);
+//   pool  the PARTs, in the list's order, each with a `taken` word: a workgroup that finds no final to take scans a window
+//         of the pool from its first untaken entry and takes the first part that is READY -- its panels' block rows
+//         complete (rows_done >= pb) and its predecessor's tile there (arrive[ctr] >= S) -- so a part never waits.
+// Every wait still targets a task somebody is running: finals wait for finals with smaller main tickets (all handed out)
+// and for their chain (all taken); parts wait for nothing.  And something can always be taken: when nothing runs, either
+// the head final's chain is taken (it can be handed out) or the pool's first untaken part is ready (its predecessors are
+// done, the rows it reads belong to finals ahead of the head) -- tests/test_dag_plan.py plays it through.
+// order[first[g] .. first[g+1]) of queue g: n_main[g] task ids of finals, then the ids of its PARTs; dep[] (main entries):
+// position in order[] of the last part of the final's chain, DAG_POOL_NONE without one.
+constexpr unsigned int DAG_POOL_NONE = 0xffffffffu;
+struct DagPool {
+    const unsigned int* order;      // nullptr: the launch hands its tasks out in list order (schemes 0, streams)
+    const unsigned int* dep;
+    int* taken;                     // one word per entry of order[] (those of pool entries are used), zeroed per launch
+    unsigned int n_main[DAG_QUEUES];
+};
+
 // Scheme 0 (the kernels without the latency paths, LAT = false; round 4): updates wait for the TILES they read -- the
 // per-column progress words MatFlags::rvrow -- instead of whole block rows (dag_update).  Compile-time: a run-time switch
 // around a one-lane poll is the code shape on which hipcc parks values under the poll's exec mask (the
@@ -148,6 +173,50 @@ constexpr long long DAG_MAX_SPINS = 2000000;  // x (s_sleep + atomic round trip)
 // indefinitely once the line is resident there; a read-modify-write executes at the memory side and
 // always observes the latest value, so the poll is an atomic add of zero.
 __device__ __forceinline__ int dag_peek(int* flag) { return __hip_atomic_fetch_add(flag, 0, PSOAP_RLX_AGENT); }
+
+// A tile element other workgroups will read (the two store routines every tile goes through: dag_store_updated, dag_trsm)
+// is WRITTEN THROUGH (sc0 sc1) instead of left dirty in the writing XCD's L2 for the release fence to write back: what the
+// consumer reads is in memory when the storing wave's vmcnt reaches zero, wherever the workgroup is when its release
+// fence runs (round 5; measured performance-neutral in round 4: 848.1 against 847.3 evals/s).  -DPSOAP_NO_WT_STORES: plain.
+__device__ __forceinline__ void dag_st(double* p, double v)
+{
+#ifdef PSOAP_NO_WT_STORES
+    *p = v;
+#else
+    __hip_atomic_store((__attribute__((address_space(1))) double*)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+}
+
+// Where this workgroup runs: XCC_ID[3:0] and HW_ID[15:8] (compute unit, shader array, shader engine).  A workgroup normally
+// stays where it was started.  When several processes share the device its scheduler suspends running workgroups (compute
+// wave save / restore) and may resume them on ANOTHER compute unit -- whose vector L1 was not invalidated by the acquire
+// the workgroup ran before it was suspended, so a tile that was rewritten since that compute unit last read it (the
+// updated tile -> the solved tile, the ping-pong slots of a chain, the W tiles) can come back stale: the silent wrong
+// lnprob of DESIGN.md 5 (1e-4 per evaluation with 12-16 worker processes).  Every task samples its place when it starts
+// and again before it retires; a task that MOVED marks the launch (DagCtl::pad[3]) -- and its lane in a stream -- as
+// tainted, and the host evaluates again (psoap_gp.hip: share_*).  One s_getreg pair per task.
+__device__ __forceinline__ unsigned int dag_where()
+{
+    const unsigned int hw = __builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11));      // HW_REG_HW_ID[15:8]: CU_ID, SH_ID, SE_ID
+    const unsigned int xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));               // HW_REG_XCC_ID[3:0]
+    return hw | (xcc << 8);
+}
+
+// thread 0, behind a task's last store and before it retires: did the workgroup move since the task started?
+// (lane_taint: the word of the task's lane in a stream, nullptr otherwise)
+__device__ __forceinline__ void dag_moved_check(unsigned int w0, DagCtl* ctl, unsigned int* lane_taint)
+{
+#ifdef PSOAP_NO_MOVE_CHECK            // (A/B builds only: what the check costs)
+    (void)w0; (void)ctl; (void)lane_taint;
+    return;
+#endif
+    const unsigned int w1 = dag_where();
+    if (w1 != w0) {
+        __hip_atomic_fetch_add(&ctl->pad[3], 1u, PSOAP_RLX_AGENT);
+        if ((w1 ^ w0) >> 8) __hip_atomic_fetch_add(&ctl->pad[4], 1u, PSOAP_RLX_AGENT);      // ... to another XCD (diagnostics)
+        if (lane_taint) __hip_atomic_store(lane_taint, 1u, PSOAP_RLX_AGENT);
+    }
+}
 
 // consumer side: one lane polls, one acquire, drain, barrier
 __device__ __forceinline__ void dag_wait_ge(int* flag, int target, DagCtl* ctl, unsigned int code = 0)
@@ -439,7 +508,7 @@ __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ 
                         mirror[(size_t)jc * ldd + (size_t)ic] = out;
                     }
                 } else {
-                    dest[(size_t)ic * ldd + (size_t)jc] = out;
+                    dag_st(&dest[(size_t)ic * ldd + (size_t)jc], out);
                 }
             }
         }
@@ -527,7 +596,7 @@ __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, in
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const double x = t.acc[m][n][r];
-                Km[(size_t)(k0 + row) * ld + j0 + tile_col(wc, n, lane)] = x;
+                dag_st(&Km[(size_t)(k0 + row) * ld + j0 + tile_col(wc, n, lane)], x);
                 part[n] = fma(x, z, part[n]);
             }
         }
@@ -780,7 +849,7 @@ __device__ __forceinline__ void dag_pss(Tile& t, double* Km, int ld, int k0, int
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
-                    Km[(size_t)(k0 + row_of(m, r)) * ld + j0 + tile_col(wc, n, lane)] = t.acc[m][n][r];
+                    dag_st(&Km[(size_t)(k0 + row_of(m, r)) * ld + j0 + tile_col(wc, n, lane)], t.acc[m][n][r]);
     }
     dag_wait_ge(&f->potrf_done, q + 1, ctl, 7u);
     // (rv_wait -- the row above is a following one: its strip solve of this column has applied ITS contribution to the
@@ -988,7 +1057,8 @@ struct alignas(64) StreamLane {
     unsigned int retired;           // tasks of the matrix that have RETIRED (their last store is out): the one that makes it
                                     // n_tasks reports the result -- see stream_retire
     unsigned int too_fast;          // an orbit submission with |v| >= c somewhere: the result is -inf (sample_parallel.py:186)
-    unsigned int pad[8];
+    unsigned int tainted;           // a task of that matrix ran on a workgroup that moved (dag_moved_check): the host resubmits
+    unsigned int pad[7];
 };
 constexpr unsigned short STREAM_BURST_END = 0x8000;   // DagTask::b of a lane's task list (the matrix index is the lane):
                                                       // the last ticket of a burst -- the next one starts a block row
@@ -1025,6 +1095,7 @@ struct StreamEntry {
 struct StreamResult {
     double lnp;
     unsigned long long seq1;        // submission number + 1 once lnp is valid
+    unsigned long long tainted;     // != 0: a workgroup moved under one of the matrix's tasks -- lnp is not to be trusted
 };
 struct StreamHost {                 // pinned, host-coherent memory
     unsigned long long head;        // host -> device: entries [0, head) are published
@@ -1215,8 +1286,10 @@ __device__ __forceinline__ void stream_complete(const StreamArgs& st, int lane, 
     const double info = __hip_atomic_load(&acc->info, PSOAP_RLX_AGENT);
     const unsigned long long seq = __hip_atomic_load(&st.lanes[lane].seq, PSOAP_RLX_AGENT);
     const unsigned int fast = __hip_atomic_load(&st.lanes[lane].too_fast, PSOAP_RLX_AGENT);
+    const unsigned int taint = __hip_atomic_load(&st.lanes[lane].tainted, PSOAP_RLX_AGENT);
     StreamResult* res = &st.host->result[seq % STREAM_RING];
     __hip_atomic_store(&res->lnp, stream_lnp(lh, qd, info != 0.0 || fast != 0u), PSOAP_RLX_SYSTEM);
+    __hip_atomic_store(&res->tainted, (unsigned long long)taint, PSOAP_RLX_SYSTEM);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&res->seq1, seq + 1ull, PSOAP_RLX_SYSTEM);
@@ -1246,7 +1319,17 @@ __device__ __forceinline__ void stream_dispatch(const StreamArgs& st, const DagM
     const int tid = threadIdx.x;
     unsigned long long opened = __hip_atomic_load(&st.dev->opened, PSOAP_RLX_AGENT);
     unsigned long long last_busy = __builtin_amdgcn_s_memrealtime();
+    unsigned int sweep = 0;
     for (;;) {
+        // A lane nobody submits to rests at next = 0x40000000 and every failed take of a worker whose cursor points at it
+        // adds one: long before the word could wrap (2e7 matrices at N = 6000) it is put back.  Only this workgroup opens
+        // lanes, so the exchange cannot undo an opening; a worker's add in between makes it fail, and the next sweep retries.
+        if ((++sweep & 4095u) == 0u && tid < (int)st.n_lanes) {
+            unsigned int v = __hip_atomic_fetch_add(&st.lanes[tid].next, 0u, PSOAP_RLX_AGENT);
+            if (v >= 0x60000000u)
+                (void)__hip_atomic_compare_exchange_strong(&st.lanes[tid].next, &v, 0x40000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (tid == 0) {
             box[0] = __hip_atomic_load(&st.host->head, PSOAP_RLX_SYSTEM);
             box[1] = (unsigned long long)__hip_atomic_load(&st.host->close, PSOAP_RLX_SYSTEM);
@@ -1367,6 +1450,7 @@ __device__ __forceinline__ void stream_dispatch(const StreamArgs& st, const DagM
                     __hip_atomic_store(&st.lanes[lane].stamp, 0ull, PSOAP_RLX_AGENT);
                     __hip_atomic_store(&st.lanes[lane].retired, 0u, PSOAP_RLX_AGENT);
                     __hip_atomic_store(&st.lanes[lane].too_fast, (unsigned int)fastv[k], PSOAP_RLX_AGENT);
+                    __hip_atomic_store(&st.lanes[lane].tainted, 0u, PSOAP_RLX_AGENT);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 for (unsigned int k = 0; k < nb; ++k) {
@@ -1497,6 +1581,8 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             ticket = queues.first[g] + local;
         }
         if (__hip_atomic_fetch_or(&ctl->error, 0u, PSOAP_RLX_AGENT) != 0u) return;
+        // the compute unit this task starts on (compared before it retires: dag_moved_check)
+        const unsigned int where0 = dag_where();
         // (ticket and matrix index are loop-carried since round 4 -- a strip solve continues into the next record, a stream
         // keeps its lane: said to be wave-uniform HERE, so that the records below are scalar loads and the pointers in them
         // scalars -- as loop-carried values the compiler kept copies of them in vector registers and spilled those)
@@ -1584,8 +1670,9 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
                 dag_special<C, AUG, WPE>((lds_special_args*)(uintptr_t)aa);
             }
             if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-            if constexpr (STREAM) {
-                if (threadIdx.x == 0) stream_retire(st, b, mat.acc);
+            if (threadIdx.x == 0) {
+                dag_moved_check(where0, ctl, STREAM ? &st.lanes[b].tainted : nullptr);
+                if constexpr (STREAM) stream_retire(st, b, mat.acc);
             }
             continue;
         }
@@ -1594,8 +1681,9 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             dag_diag_fast(Km, ld, k0, Wm, Rv, mat.acc, prev, Npad, f, ctl, q, ntasks_row, (task.type & DAG_FUSED) != 0,
                           &arrive_l[task.ctr], n_wait, dag_opaque_lds(psoap_smem), dag_opaque_lds(vec1), dag_opaque_lds(vec2),
                           tlog_l ? tlog_l + ticket * 8 : nullptr);
-            if constexpr (STREAM) {
-                if (threadIdx.x == 0) stream_retire(st, b, mat.acc);
+            if (threadIdx.x == 0) {
+                dag_moved_check(where0, ctl, STREAM ? &st.lanes[b].tainted : nullptr);
+                if constexpr (STREAM) stream_retire(st, b, mat.acc);
             }
             continue;
         }
@@ -1648,12 +1736,16 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
                 __hip_atomic_fetch_add(&arrive_l[task.ctr], 1, PSOAP_RLX_AGENT);
             }
             if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-            if constexpr (STREAM) {
-                if (threadIdx.x == 0) stream_retire(st, b, mat.acc);
+            if (threadIdx.x == 0) {
+                dag_moved_check(where0, ctl, STREAM ? &st.lanes[b].tainted : nullptr);
+                if constexpr (STREAM) stream_retire(st, b, mat.acc);
             }
             continue;
         }
-        if (AUG && ttype == DAG_SCHUR) continue;     // nobody inside the launch reads Sigma: no drain, no counter
+        if (AUG && ttype == DAG_SCHUR) {             // nobody inside the launch reads Sigma: no drain, no counter
+            if (threadIdx.x == 0) dag_moved_check(where0, ctl, nullptr);
+            continue;
+        }
         dag_drain();  // the tile is re-read below in another layout by other waves of this block
         if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 1] = __builtin_amdgcn_s_memrealtime();
         if (ttype == DAG_DIAG) {
@@ -1711,8 +1803,9 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             if constexpr (CONT) cont = (task.type & DAG_FUSED) != 0;
         }
         if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-        if constexpr (STREAM) {
-            if (threadIdx.x == 0) stream_retire(st, b, mat.acc);
+        if (threadIdx.x == 0) {
+            dag_moved_check(where0, ctl, STREAM ? &st.lanes[b].tainted : nullptr);
+            if constexpr (STREAM) stream_retire(st, b, mat.acc);
         }
     }
 }
@@ -1727,6 +1820,9 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
 // ---------------------------------------------------------------------------------------------
 struct DagPlan {
     std::vector<DagTask> tasks;
+    // ready-only hand-out (DagPool): filled for the latency schemes by dag_build_tasks
+    std::vector<unsigned int> order, dep;
+    unsigned int n_main[DAG_QUEUES] = {};
     DagQueues queues{};
     unsigned int n_slots = 0;
     unsigned int n_ctrs = 0;
@@ -2091,6 +2187,32 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
 }
 
 
+// The two hand-out orders of a latency-scheme list (DagPool): per queue the finals in list order, then the PARTs in list
+// order; for a final with a chain the position of the chain's last part.
+inline void dag_build_pool(DagPlan& plan)
+{
+    const size_t n = plan.tasks.size();
+    plan.order.assign(n, 0u);
+    plan.dep.assign(n, DAG_POOL_NONE);
+    for (int g = 0; g < DAG_QUEUES; ++g) {
+        const unsigned int lo = plan.queues.first[g], hi = plan.queues.first[g + 1];
+        unsigned int pos = lo;
+        for (unsigned int t = lo; t < hi; ++t)
+            if ((plan.tasks[t].type & DAG_TYPE_MASK) != DAG_PART) plan.order[pos++] = t;
+        plan.n_main[g] = pos - lo;
+        std::vector<unsigned int> last_part(plan.n_ctrs + 1, DAG_POOL_NONE);      // per arrival counter: its last part's position
+        for (unsigned int t = lo; t < hi; ++t)
+            if ((plan.tasks[t].type & DAG_TYPE_MASK) == DAG_PART) {
+                last_part[plan.tasks[t].ctr] = pos;        // (a chain's parts are in list order: the last one wins)
+                plan.order[pos++] = t;
+            }
+        for (unsigned int m = lo; m < lo + plan.n_main[g]; ++m) {
+            const DagTask& f = plan.tasks[plan.order[m]];
+            if (f.S > 1) plan.dep[m] = last_part[f.ctr];   // S - 1 parts
+        }
+    }
+}
+
 // scheme: 0 throughput, 1 latency (dag_emit), -1 automatic: latency while the row-to-row dependency chain,
 // not the MFMA work, bounds the run time -- i.e. while a queue has too few block rows in flight to hide the
 // wait for the row above.  Measured on MI355X (tools/scheme_table.py; N = 2000 .. 8192, B = 1 .. 32, round 2,
@@ -2248,6 +2370,7 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
     }
     plan.queues.first[DAG_QUEUES] = (unsigned int)plan.tasks.size();
     plan.queues.follow_first = (unsigned int)dag_follow_first_row();
+    if (scheme >= 1) dag_build_pool(plan);
     return plan;
 }
 

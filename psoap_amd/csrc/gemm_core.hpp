@@ -170,6 +170,15 @@ __device__ __forceinline__ int hw_lane()
     return l;
 }
 
+// cache policy of the operand loads (the aux immediate of global_load_lds: 16 = sc1, past the compute unit's vector L1 and
+// served by the XCD's L2).  -DPSOAP_SC1_LOADS: experiments on what a workgroup that the device's scheduler moved to
+// another compute unit reads there; default 0, plain loads.
+#ifdef PSOAP_SC1_LOADS
+#define PSOAP_GLDS_AUX 16
+#else
+#define PSOAP_GLDS_AUX 0
+#endif
+
 // LDS-DMA staging: one global_load_lds_dwordx4 per wave moves one 1 KiB operand row (128 doubles)
 // straight into its padded LDS row -- no staging VGPRs, no ds_write pass.  Wave w fills rows
 // w, w+4, w+8, w+12 of both operand chunks.
@@ -184,9 +193,9 @@ __device__ __forceinline__ void stage_glds(const double* __restrict__ A, size_t 
     for (int it = 0; it < 4; ++it) {
         const int row = wave + 4 * it;
         const int off = buf * LDS_BUFFER + row * LDS_LD;
-        __builtin_amdgcn_global_load_lds((glb_ptr)(A + (size_t)(k + row) * lda + 2 * lane), (lds_ptr)sm.ptr(off), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(A + (size_t)(k + row) * lda + 2 * lane), (lds_ptr)sm.ptr(off), 16, 0, PSOAP_GLDS_AUX);
         __builtin_amdgcn_global_load_lds((glb_ptr)(B + (size_t)(k + row) * ldb + 2 * lane),
-                                         (lds_ptr)sm.ptr(off + LDS_OPERAND), 16, 0, 0);
+                                         (lds_ptr)sm.ptr(off + LDS_OPERAND), 16, 0, PSOAP_GLDS_AUX);
     }
 }
 
@@ -203,9 +212,9 @@ __device__ __forceinline__ void stage_glds_w(const double* __restrict__ A, size_
     for (int it = 0; it < 4; ++it) {
         const int row = wave + 4 * it;
         const int off = buf * LDS_BUFFER + row * LDS_LD;
-        __builtin_amdgcn_global_load_lds((glb_ptr)(A + (size_t)(k + row) * lda + 2 * lane), (lds_ptr)sm.ptr(off), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr)(A + (size_t)(k + row) * lda + 2 * lane), (lds_ptr)sm.ptr(off), 16, 0, PSOAP_GLDS_AUX);
         __builtin_amdgcn_global_load_lds((glb_ptr)(B + (size_t)(k + row) * ldb + 2 * lane),
-                                         (lds_ptr)sm.ptr(off + LDS_OPERAND), 16, 0, 0);
+                                         (lds_ptr)sm.ptr(off + LDS_OPERAND), 16, 0, PSOAP_GLDS_AUX);
     }
 }
 
@@ -222,7 +231,7 @@ __device__ __forceinline__ void stage_glds_one(const double* __restrict__ A, siz
     for (int it = 0; it < 4; ++it) {
         const int row = wave + 4 * it;
         __builtin_amdgcn_global_load_lds((glb_ptr)(A + (size_t)(k + row) * lda + 2 * lane),
-                                         (lds_ptr)sm.ptr(buf * LDS_BUFFER + row * LDS_LD), 16, 0, 0);
+                                         (lds_ptr)sm.ptr(buf * LDS_BUFFER + row * LDS_LD), 16, 0, PSOAP_GLDS_AUX);
     }
 }
 

@@ -395,7 +395,7 @@ struct SigmaPin {
 inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const double* lwl, const double* fl,
                        const double* sigma, const double* dFl_res, const double* dSig_res, const double* lwl_pred,
                        const double* mu_c, const double* gp, double* mu_out, double* Sigma_out, int* status,
-                       std::string& err, double* var_out = nullptr)
+                       std::string& err, double* var_out = nullptr, bool force_staged = false)
 {
     const auto t_begin = std::chrono::steady_clock::now();
     SigmaPin pin;         // declared first: its destructor joins the helper thread and drops the registration on every return path
@@ -418,7 +418,9 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
     // the appended columns as extra column tiles (k_chol_dag<C, true>: the cross-covariances are
     // evaluated on the fly like B itself).  The transposed-mean variant (covariance.py:294) needs a
     // block whose ROW abscissae are the prediction grid and keeps the staged three-kernel loop.
-    const bool use_dag = !transposed_mean && (P + Mt) <= 255;
+    // (force_staged: several processes share the device and the persistent launch is not to be used, or was disturbed --
+    // psoap_gp.hip: predict_settled)
+    const bool use_dag = !force_staged && !transposed_mean && (P + Mt) <= 255;
     // Sigma = A - W^T W is the Schur complement of the appended columns: with the persistent kernel its tiles are tasks
     // of the same launch (DAG_SCHUR), left-looking updates that need no critical path and fill the workgroups the
     // factorisation's row-to-row chain leaves idle.  PSOAP_PREDICT_FUSED=0: the separate product (k_syrk_sub_sym).
@@ -660,11 +662,18 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
     if (!Sigma_out) PR_TRY(hipEventRecord(ws.ev[3], st));
     PR_TRY(hipStreamSynchronize(st));
     if (use_dag) {
-        unsigned int dag_err = 0;
-        PR_TRY(hipMemcpy(&dag_err, ws.Dag.p + offsetof(DagCtl, error), sizeof(dag_err), hipMemcpyDeviceToHost));
-        if (dag_err != 0) {
+        unsigned int dag_err[6] = {0, 0, 0, 0, 0, 0};      // DagCtl::error, pad[0..4]
+        PR_TRY(hipMemcpy(dag_err, ws.Dag.p + offsetof(DagCtl, error), sizeof(dag_err), hipMemcpyDeviceToHost));
+        if (dag_err[0] != 0) {
             err = "predict: dependency wait timed out inside the persistent kernel";
             return 1;
+        }
+        if (dag_err[4] != 0) {
+            // a workgroup moved between compute units under one of the launch's tasks (dag_where): the outputs are not
+            // handed out -- the caller runs the call again
+            err = "predict: the persistent launch was disturbed by the device's scheduler";
+            pin.release();
+            return 3;
         }
     }
     if (Sigma_out && !sigma_direct)

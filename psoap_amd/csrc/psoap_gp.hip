@@ -8,12 +8,16 @@
 #include <stddef.h>
 #include <string.h>
 
+#include <errno.h>
 #include <fcntl.h>
+#include <time.h>
 #include <sys/file.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
@@ -50,119 +54,318 @@ static thread_local std::string g_err;
 
 static const int MAX_GROUPS = 8;
 
-// ---- one process at a time on a device while a persistent launch is in flight ------------------------------------------
+// ---- several processes on one device ------------------------------------------------------------------------------
 // The reference forks one worker PROCESS per chunk (psoap/sample_parallel.py:258-278); with more chunks than GPUs several
-// of them share a device.  The device then time-slices their persistent kernels (compute wave save / restore), and the
-// cross-workgroup hand-offs of k_chol_dag do not survive a workgroup being suspended between the stores
-// and the fences that publish / acquire them: measured with 8 forked workers on one MI355X, N = 6000, one evaluation per
-// call -- 3 wrong values in 800 evaluations (tools/shared_gpu_probe.py), and with 8 ranks in bench.py's dry run a wrong
-// value in every second run, round 3's library included.  So an evaluation holds an advisory lock on the device
-// (flock on /tmp/psoap_gpu_<PCI bus id>.lock) from its launch to the fetch that sees it complete; a stream holds it
-// while it has tickets outstanding.  Uncontended that is two system calls per evaluation; contended, the processes take
-// turns -- which is what the device does with persistent kernels anyway, minus the wrong answers.  Within one process the
-// lock is counted (its own launches never exclude each other).  PSOAP_DEVICE_LOCK=0 switches it off.
+// of them share a device.  Two things then go wrong with persistent kernels:
+//   * two persistent launches of different processes on the device at once starve each other (every workgroup that holds
+//     a ticket is assumed to run): bounded waits time out, values come back wrong;
+//   * the device suspends running workgroups (compute wave save / restore) when more than eight processes or too many
+//     hardware queues share it, and resumes them on other compute units: see dag_where() in dag_kernel.hpp.
+// What the library does (round 5):
+//   1. an advisory per-device lock between the processes of ONE user -- flock on <dir>/gpu_<PCI bus id>.lock, <dir> =
+//      $PSOAP_LOCK_DIR, else $XDG_RUNTIME_DIR/psoap, else /tmp/psoap-<uid> (0700, owner checked, never followed through a
+//      symlink) -- held from an upload to the fetch of the evaluation that reads it, counted within a process, with a
+//      time-out (PSOAP_DEVICE_LOCK_TIMEOUT_S, default 300) that ends in an error naming the holder instead of a hang;
+//   2. a count of the cooperating processes per device (slot files beside the lock, locked for the life of the process,
+//      re-counted a few times per second): share_procs();
+//   3. every persistent launch reports workgroups that MOVED while they ran (DagCtl::pad[3]); a tainted evaluation is
+//      run again (PSOAP_SHARE_RETRIES, default 3, same task list: bit-identical results), then evaluated by the staged
+//      path (chol_kernels.hpp: kernel boundaries instead of hand-offs inside a kernel -- immune to both failures);
+//   4. where the persistent kernel cannot be made safe -- several processes on the device WITHOUT the lock
+//      (PSOAP_DEVICE_LOCK=0), or more of them than PSOAP_SHARE_DAG_MAX (8: the process contexts the device keeps mapped) --
+//      evaluations take the staged path from the start, and take it WITHOUT the lock: kernels that synchronise at their
+//      boundaries only have nothing to keep apart, and the device interleaves them (16 processes, N = 6000: 143
+//      evaluations per second in all, against 91 with persistent launches taking turns under the lock -- one of 38,400 of
+//      those still wrong despite the retries -- and 16 with staged evaluations taking turns: profiles/r5_share_*.txt).
+//      Streams (resident launches) are refused in that regime.
+// PSOAP_SHARE_POLICY=dag|staged pins the path whatever the count (experiments, tools/shared_gpu_probe.py).
 struct DeviceLock {
+    std::mutex mu;                    // guards the fields below (one per device: a wait on one device never blocks another)
+    std::condition_variable cv;
     int fd = -1;
     int refs = 0;
+    bool held = false, acquiring = false, broken = false;
     pid_t pid = 0;
+    std::string path;
 };
-static std::mutex g_devlock_mu;
-static std::map<int, DeviceLock> g_devlocks;
+static std::mutex g_devlock_mu;        // guards the maps only
+static std::map<int, DeviceLock*> g_devlocks;
 
 static bool device_lock_enabled()
 {
     static const bool on = !(getenv("PSOAP_DEVICE_LOCK") && getenv("PSOAP_DEVICE_LOCK")[0] == '0');
     return on;
 }
-
-static void device_lock_acquire(int device)
+static double device_lock_timeout_s()
 {
-    if (!device_lock_enabled()) return;
-    std::lock_guard<std::mutex> g(g_devlock_mu);
-    DeviceLock& L = g_devlocks[device];
+    const char* e = getenv("PSOAP_DEVICE_LOCK_TIMEOUT_S");
+    return (e && atof(e) > 0.0) ? atof(e) : 300.0;
+}
+
+// process-wide counters of what sharing cost (psoap_share_stats)
+struct ShareStats {
+    std::atomic<long long> dag_launches{0}, tainted{0}, retries{0}, staged_fallbacks{0}, staged_policy{0}, moved_tasks{0},
+        moved_xcd{0}, lock_acquisitions{0}, lock_wait_us{0}, stream_resubmits{0};
+};
+static ShareStats g_share;
+
+// The per-user directory of the lock and slot files; empty when none can be had (the caller then runs unserialised and
+// says so once).  Created 0700; refused when it is a symlink, not a directory, or somebody else's.
+static const std::string& share_dir()
+{
+    static std::string dir;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::string d;
+        if (const char* e = getenv("PSOAP_LOCK_DIR")) d = e;
+        else if (const char* x = getenv("XDG_RUNTIME_DIR")) d = std::string(x) + "/psoap";
+        else d = std::string("/tmp/psoap-") + std::to_string((long long)geteuid());
+        if (mkdir(d.c_str(), 0700) != 0 && errno != EEXIST) return;
+        struct stat sb;
+        if (lstat(d.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode) || sb.st_uid != geteuid()) {
+            fprintf(stderr, "psoap: %s is not a directory of this user: several processes on one GPU are not serialised\n", d.c_str());
+            return;
+        }
+        dir = d;
+    });
+    return dir;
+}
+
+static std::string device_file(int device, const char* suffix)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) snprintf(bus, sizeof bus, "index%d", device);
+    for (char* c = bus; *c; ++c)
+        if (!((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z'))) *c = '_';
+    return share_dir() + "/gpu_" + bus + suffix;
+}
+
+static int open_share_file(const std::string& path, bool create)
+{
+    return open(path.c_str(), (create ? O_CREAT : 0) | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
+}
+
+// 0: the device is this process's (*took), or no lock is needed -- switched off / unavailable, or this process runs the
+// staged path on a device too many processes share (share_wants_staged: kernel boundaries only, nothing to keep apart, and
+// 16 processes interleaving their kernels measured 143 evaluations per second at N = 6000 against 16 taking turns);
+// 2: timed out (g_err says who holds it)
+static bool share_wants_staged(int device);
+static int device_lock_acquire(int device, bool* took = nullptr)
+{
+    if (took) *took = false;
+    if (!device_lock_enabled()) return 0;
+    if (share_wants_staged(device)) return 0;
+    DeviceLock* Lp;
+    {
+        std::lock_guard<std::mutex> g(g_devlock_mu);
+        DeviceLock*& slot = g_devlocks[device];
+        if (!slot) slot = new DeviceLock();
+        Lp = slot;
+    }
+    DeviceLock& L = *Lp;
+    std::unique_lock<std::mutex> lk(L.mu);
     if (L.pid != getpid()) {          // first use in this process (a descriptor inherited through fork() shares its lock)
         if (L.fd >= 0) (void)close(L.fd);
-        char bus[64] = {0};
-        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) snprintf(bus, sizeof bus, "index%d", device);
-        for (char* c = bus; *c; ++c)
-            if (!((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z'))) *c = '_';
-        const std::string path = std::string("/tmp/psoap_gpu_") + bus + ".lock";
-        const mode_t old = umask(0);
-        L.fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-        (void)umask(old);
-        L.pid = getpid();
+        L.fd = -1;
         L.refs = 0;
-        if (L.fd < 0) {
-            static bool warned = false;
-            if (!warned) fprintf(stderr, "psoap: cannot open %s: several processes on this GPU are not serialised\n", path.c_str());
-            warned = true;
+        L.held = L.acquiring = false;
+        L.pid = getpid();
+        if (!share_dir().empty()) {
+            L.path = device_file(device, ".lock");
+            L.fd = open_share_file(L.path, true);
+        }
+        if (L.fd < 0 && !L.broken) {
+            L.broken = true;
+            fprintf(stderr, "psoap: cannot open the device lock %s: several processes on this GPU are not serialised\n",
+                    L.path.empty() ? "(no lock directory)" : L.path.c_str());
         }
     }
-    if (L.fd >= 0 && L.refs++ == 0) {
-        while (flock(L.fd, LOCK_EX) != 0 && errno == EINTR) {}
+    if (L.fd < 0) return 0;
+    ++L.refs;
+    if (took) *took = true;
+    if (L.held) return 0;
+    if (L.acquiring) {                 // another thread of this process is at it: wait for its verdict
+        L.cv.wait(lk, [&] { return !L.acquiring; });
+        if (L.held) return 0;
+        if (took) *took = false;
+        --L.refs;
+        g_err = "psoap: the device lock could not be taken (see the other thread's error)";
+        return 2;
     }
+    L.acquiring = true;
+    const int fd = L.fd;
+    lk.unlock();
+    // (polled, not blocking: a wait that never ends must become an error.  20 us steps at first -- the holder's evaluation
+    // takes milliseconds -- then 200 us.)
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = device_lock_timeout_s();
+    bool got = false;
+    long long polls = 0;
+    for (;;) {
+        if (flock(fd, LOCK_EX | LOCK_NB) == 0) {
+            got = true;
+            break;
+        }
+        if (errno != EWOULDBLOCK && errno != EINTR) break;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) break;
+        struct timespec ts = {0, (++polls < 200) ? 20000L : 200000L};
+        (void)nanosleep(&ts, nullptr);
+    }
+    const long long waited_us =
+        (long long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    if (got) {
+        char buf[32];
+        const int n = snprintf(buf, sizeof buf, "%ld\n", (long)getpid());
+        if (pwrite(fd, buf, (size_t)n, 0) == n) (void)ftruncate(fd, n);      // who holds it (diagnostics of a time-out elsewhere)
+        g_share.lock_acquisitions += 1;
+        g_share.lock_wait_us += waited_us;
+    }
+    lk.lock();
+    L.acquiring = false;
+    L.held = got;
+    if (!got) --L.refs;
+    L.cv.notify_all();
+    if (!got) {
+        if (took) *took = false;
+        char who[32] = {0};
+        const ssize_t n = pread(fd, who, sizeof who - 1, 0);
+        for (ssize_t i = 0; i < n; ++i)
+            if (who[i] == '\n') who[i] = 0;
+        g_err = "psoap: the device lock " + L.path + " was not released within " + std::to_string((int)limit) +
+                " s (PSOAP_DEVICE_LOCK_TIMEOUT_S); last holder: pid " + (n > 0 ? who : "unknown");
+        return 2;
+    }
+    return 0;
 }
 
 static void device_lock_release(int device)
 {
     if (!device_lock_enabled()) return;
-    std::lock_guard<std::mutex> g(g_devlock_mu);
-    auto it = g_devlocks.find(device);
-    if (it == g_devlocks.end() || it->second.fd < 0 || it->second.pid != getpid() || it->second.refs <= 0) return;
-    if (--it->second.refs == 0) (void)flock(it->second.fd, LOCK_UN);
+    DeviceLock* Lp = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_devlock_mu);
+        auto it = g_devlocks.find(device);
+        if (it == g_devlocks.end()) return;
+        Lp = it->second;
+    }
+    std::lock_guard<std::mutex> lk(Lp->mu);
+    if (Lp->fd < 0 || Lp->pid != getpid() || Lp->refs <= 0) return;
+    if (--Lp->refs == 0 && Lp->held) {
+        (void)flock(Lp->fd, LOCK_UN);
+        Lp->held = false;
+    }
 }
 
-// Everything else that touches the device (uploads, fills, handle set-up and tear-down) takes the lock for the duration of
-// the call: such work is harmless by itself, but queued beside ANOTHER process's persistent launch it makes the device
-// switch between the two (measured with the lock around launches only: one wrong value in 36,000 single evaluations of eight
-// workers, against one in a few hundred without any lock).
-// How many cooperating processes use a device: each holds one of 64 slot files (/tmp/psoap_gpu_<bus>.slot<k>, locked for
-// the life of the process).  The device keeps up to eight processes' address spaces mapped; a ninth makes the scheduler swap
-// processes in and out under running kernels, which the lock above cannot prevent (measured with 12 and 16 workers: 3-8
-// wrong values in 24,000 single evaluations, 5-7 ms per evaluation).  Warn once; PSOAP_DEVICE_LOCK=0 disables the count too.
-static std::map<int, int> g_slot_fd;
+// How many cooperating processes use a device: each holds one of 64 slot files (<dir>/gpu_<bus>.slot<k>, locked for the
+// life of the process; PSOAP_DEVICE_SLOTS=0: no count).  Counted whether or not the lock is on: without the lock the count
+// is what sends evaluations down the staged path.
+struct SlotState {
+    int fd = -1;
+    pid_t pid = 0;
+    int procs = 1;
+    std::chrono::steady_clock::time_point counted{};
+    bool warned = false;
+};
+static std::map<int, SlotState> g_slots;
+static bool device_slots_enabled()
+{
+    static const bool on = !(getenv("PSOAP_DEVICE_SLOTS") && getenv("PSOAP_DEVICE_SLOTS")[0] == '0');
+    return on;
+}
 static void device_slot_take(int device)
 {
-    if (!device_lock_enabled()) return;
+    if (!device_slots_enabled() || share_dir().empty()) return;
     std::lock_guard<std::mutex> g(g_devlock_mu);
-    static pid_t owner = 0;
-    if (owner != getpid()) {          // (descriptors inherited through fork() share their locks with the parent)
-        g_slot_fd.clear();
-        owner = getpid();
-    }
-    if (g_slot_fd.count(device)) return;
-    char bus[64] = {0};
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) snprintf(bus, sizeof bus, "index%d", device);
-    for (char* c = bus; *c; ++c)
-        if (!((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z'))) *c = '_';
-    int taken = -1;
-    const mode_t old = umask(0);
-    for (int k = 0; k < 64 && taken < 0; ++k) {
-        const std::string path = std::string("/tmp/psoap_gpu_") + bus + ".slot" + std::to_string(k);
-        const int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    SlotState& S = g_slots[device];
+    if (S.pid == getpid() && S.fd >= 0) return;
+    if (S.fd >= 0) (void)close(S.fd);       // (inherited through fork(): shares its lock with the parent)
+    S = SlotState();
+    S.pid = getpid();
+    for (int k = 0; k < 64; ++k) {
+        const int fd = open_share_file(device_file(device, (".slot" + std::to_string(k)).c_str()), true);
         if (fd < 0) break;
         if (flock(fd, LOCK_EX | LOCK_NB) == 0) {
-            g_slot_fd[device] = fd;
-            taken = k;
-        } else {
-            (void)close(fd);
+            S.fd = fd;
+            break;
         }
+        (void)close(fd);
     }
-    (void)umask(old);
-    if (taken >= 8)
-        fprintf(stderr,
-                "psoap: %d processes share GPU %s.  Beyond 8 the device swaps process contexts under running kernels: slower, "
-                "and results were observed to be corrupted now and then (DESIGN.md 5).  Use at most 8 worker processes per GPU.\n",
-                taken + 1, bus);
+}
+// processes with a slot on this device (this one included); re-counted at most four times a second
+static int share_procs(int device)
+{
+    if (const char* e = getenv("PSOAP_SHARE_PROCS"))      // tests: pretend
+        if (atoi(e) > 0) return atoi(e);
+    if (!device_slots_enabled() || share_dir().empty()) return 1;
+    std::lock_guard<std::mutex> g(g_devlock_mu);
+    SlotState& S = g_slots[device];
+    if (S.pid != getpid() || S.fd < 0) return 1;
+    const auto now = std::chrono::steady_clock::now();
+    if (S.counted.time_since_epoch().count() != 0 && std::chrono::duration<double>(now - S.counted).count() < 0.25) return S.procs;
+    int n = 0;
+    for (int k = 0; k < 64; ++k) {
+        const int fd = open_share_file(device_file(device, (".slot" + std::to_string(k)).c_str()), false);
+        if (fd < 0) break;                              // slot files are created in order and never removed
+        if (flock(fd, LOCK_EX | LOCK_NB) == 0) (void)flock(fd, LOCK_UN);
+        else ++n;                                       // held: by another process, or by this one's own descriptor
+        (void)close(fd);
+    }
+    S.procs = n > 0 ? n : 1;
+    S.counted = now;
+    return S.procs;
+}
+
+// Which path an evaluation takes on a device that `procs` processes share.
+static int share_dag_max()
+{
+    const char* e = getenv("PSOAP_SHARE_DAG_MAX");
+    return (e && atoi(e) > 0) ? atoi(e) : 8;
+}
+static int share_retries()
+{
+    const char* e = getenv("PSOAP_SHARE_RETRIES");
+    return (e && atoi(e) >= 0) ? atoi(e) : 3;
+}
+// experiments (tools/shared_gpu_probe.py): disturbed launches are counted but their values handed out all the same -- is
+// every wrong value one of a launch that reported a moved workgroup?
+static bool share_detect_only()
+{
+    static const bool on = getenv("PSOAP_SHARE_DETECT_ONLY") && getenv("PSOAP_SHARE_DETECT_ONLY")[0] == '1';
+    return on;
+}
+static bool share_wants_staged(int device)
+{
+    static const int pinned = [] {
+        const char* e = getenv("PSOAP_SHARE_POLICY");
+        return !e ? 0 : (!strcmp(e, "dag") ? 1 : (!strcmp(e, "staged") ? 2 : 0));
+    }();
+    if (pinned) return pinned == 2;
+    const int procs = share_procs(device);
+    if (procs <= 1) return false;
+    if (!device_lock_enabled()) return true;            // nobody keeps two persistent launches apart
+    return procs > share_dag_max();
+}
+// tests: every k-th launch is treated as tainted (PSOAP_TEST_TAINT_EVERY=k), to drive the retry / fallback logic on a
+// device nobody shares
+static bool share_inject_taint()
+{
+    static const int every = getenv("PSOAP_TEST_TAINT_EVERY") ? atoi(getenv("PSOAP_TEST_TAINT_EVERY")) : 0;
+    static std::atomic<long long> n{0};
+    return every > 0 && (++n % every) == 0;
 }
 
 struct DeviceScope {
     int dev;
-    explicit DeviceScope(int d) : dev(d) { device_lock_acquire(d); }
-    ~DeviceScope() { device_lock_release(dev); }
+    bool ok, took = false;
+    explicit DeviceScope(int d) : dev(d) { ok = device_lock_acquire(d, &took) == 0; }
+    ~DeviceScope() { if (took) device_lock_release(dev); }
     DeviceScope(const DeviceScope&) = delete;
     DeviceScope& operator=(const DeviceScope&) = delete;
 };
+// every entry point that touches the device: the lock for the duration of the call, an error when it cannot be had
+#define DEVICE_SCOPE(d)      \
+    DeviceScope scope_(d);   \
+    if (!scope_.ok) return 2
 
 // Owning device / pinned-host pointer: early returns free whatever was allocated so far.
 template <class T>
@@ -222,12 +425,22 @@ struct StreamState {
     double last_launch_ms = 0.0;                 // the launch that ended last (psoap_stream_pause / close measure it)
     long long last_launch_matrices = 0;
     unsigned long long head = 0;                 // submissions published
-    std::vector<long long> lane_ticket;          // ticket held by each lane, -1: free
+    std::vector<long long> lane_ticket;          // ticket held by each lane (what the caller knows it by), -1: free
+    std::vector<unsigned long long> lane_seq;    // submission number the lane's matrix runs under NOW: the ticket, until a
+                                                 // tainted result made the library submit the lane again (stream_lane_result)
+    std::vector<int> lane_tries;                 // resubmissions of the lane's current ticket
+    std::vector<int> lane_kind;                  // StreamEntry::kind and ::mu of the lane's submission (for a resubmission)
+    std::vector<double> lane_mu;
     std::vector<char> neg;                       // per ring entry: a hyper-parameter was negative -> -inf
     long long launches = 0;
     double idle_ms = 20.0;
 };
+// Workgroup slots a resident launch leaves FREE (psoap_chunk_set_stream_reserve): a kernel of another stream -- the RCCL
+// all_gather of the walker lnprobs and its staging copies, psoap_amd/ensemble.py -- gets compute units only where the
+// resident grid does not hold every register file; with `reserve` of the 2 x CUs slots unoccupied it runs BESIDE the
+// launch instead of behind it.  The lanes' task list does not depend on it (results stay bit-identical).
 
+struct psoap_group;
 struct psoap_chunk {
     int device = 0;
     int N = 0, Npad = 0, ld = 0, P = 0;
@@ -297,15 +510,20 @@ struct psoap_chunk {
     psoap::PredictWs* pws = nullptr;
     // streamed evaluation (psoap_stream_*)
     StreamState stream;
+    int stream_reserve = 0;      // psoap_chunk_set_stream_reserve
     bool dev_locked = false;     // this handle holds a reference on the device's inter-process lock (device_lock_acquire)
+    int last_path = 1;           // what the evaluation in flight runs on: 1 the persistent kernel, 0 the staged path
+    struct psoap_group* last_group = nullptr;   // the group launch that evaluation belongs to (nullptr: the handle's own)
 };
 
-static void handle_lock(psoap_chunk* h)
+static int handle_lock(psoap_chunk* h)
 {
     if (!h->dev_locked) {
-        device_lock_acquire(h->device);
-        h->dev_locked = true;
+        bool took = false;
+        if (int rc = device_lock_acquire(h->device, &took)) return rc;
+        h->dev_locked = took;
     }
+    return 0;
 }
 static void handle_unlock(psoap_chunk* h, bool force = false)
 {
@@ -326,6 +544,19 @@ extern "C" const char* psoap_last_error(void) { return g_err.c_str(); }
 extern "C" int psoap_device_count(int* count)
 {
     HIP_TRY(hipGetDeviceCount(count));
+    return 0;
+}
+
+// What sharing the device with other processes has cost this process so far (include/psoap_gp.h: PSOAP_SHARE_*).
+extern "C" int psoap_share_stats(int device, long long* out, int n)
+{
+    if (!out || n < 1) FAIL("psoap_share_stats: bad arguments");
+    const long long v[PSOAP_SHARE_N] = {
+        (long long)share_procs(device), g_share.dag_launches.load(), g_share.tainted.load(), g_share.retries.load(),
+        g_share.staged_fallbacks.load(), g_share.staged_policy.load(), g_share.moved_tasks.load(), g_share.moved_xcd.load(),
+        g_share.lock_acquisitions.load(), g_share.lock_wait_us.load(), g_share.stream_resubmits.load(),
+        (long long)(device_lock_enabled() ? 1 : 0)};
+    for (int k = 0; k < n && k < PSOAP_SHARE_N; ++k) out[k] = v[k];
     return 0;
 }
 
@@ -450,7 +681,7 @@ extern "C" int psoap_chunk_create(psoap_chunk** out, int device, int N, const do
 {
     if (!out || N <= 0 || max_batch <= 0 || !fl || !sigma) FAIL("psoap_chunk_create: bad arguments");
     *out = nullptr;
-    DeviceScope scope_(device);
+    DEVICE_SCOPE(device);
     if (int rc = enter_device(device)) return rc;
     device_slot_take(device);
     psoap_chunk* h = new psoap_chunk();
@@ -479,7 +710,7 @@ extern "C" int psoap_stream_close(psoap_chunk* h);
 extern "C" int psoap_chunk_destroy(psoap_chunk* h)
 {
     if (!h) return 0;
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     (void)hipSetDevice(h->device);
     if (h->stream.open) (void)psoap_stream_close(h);
     (void)hipDeviceSynchronize();
@@ -512,7 +743,8 @@ extern "C" int psoap_chunk_destroy(psoap_chunk* h)
 extern "C" int psoap_chunk_set_data(psoap_chunk* h, const double* fl, const double* sigma)
 {
     if (!h || !fl || !sigma) FAIL("psoap_chunk_set_data: bad arguments");
-    DeviceScope scope_(h->device);
+    if (h->stream.open) FAIL("psoap_chunk_set_data: the handle has an open stream (psoap_stream_close first)");
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h->dFl, fl, sizeof(double) * h->N, hipMemcpyHostToDevice));
@@ -523,9 +755,10 @@ extern "C" int psoap_chunk_set_data(psoap_chunk* h, const double* fl, const doub
 extern "C" int psoap_chunk_set_grid(psoap_chunk* h, const double* lwl, const int32_t* epoch, int n_epochs)
 {
     if (!h || !lwl || !epoch || n_epochs <= 0) FAIL("psoap_chunk_set_grid: bad arguments");
+    if (h->stream.open) FAIL("psoap_chunk_set_grid: the handle has an open stream (psoap_stream_close first)");
     for (int i = 0; i < h->N; ++i)
         if (epoch[i] < 0 || epoch[i] >= n_epochs) FAIL("psoap_chunk_set_grid: epoch index out of range");
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     HIP_TRY(hipDeviceSynchronize());
     if (!h->dGrid) HIP_TRY(hipMalloc(&h->dGrid, sizeof(double) * h->N));
@@ -552,7 +785,7 @@ extern "C" int psoap_chunk_set_stream_groups(psoap_chunk* h, int groups)
 extern "C" int psoap_chunk_dag_tasklog(psoap_chunk* h, unsigned long long* out, long long max_tasks)
 {
     if (!h) FAIL("null handle");
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     const long long tasks = 9ll * h->max_batch * h->P * (h->P + 1) / 2 + 1024;   // <= 8 parts per tile + early DIAG parts
     if (!h->dTlog) {
@@ -661,7 +894,7 @@ extern "C" int psoap_dag_pick_workers(int B, const int* Ps, int Mt, int compute_
 extern "C" int psoap_chunk_dag_tasks(psoap_chunk* h, void* out, long long max_tasks, long long* n_tasks)
 {
     if (!h || !n_tasks) FAIL("bad arguments");
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     *n_tasks = h->plan_tasks;
     if (out && h->dTasks) {
@@ -675,6 +908,14 @@ extern "C" int psoap_chunk_set_mode(psoap_chunk* h, int mode)
 {
     if (!h || mode < 0 || mode > 1) FAIL("psoap_chunk_set_mode: mode must be 0 (staged) or 1 (dag)");
     h->mode = mode;
+    return 0;
+}
+
+extern "C" int psoap_chunk_set_stream_reserve(psoap_chunk* h, int workgroups)
+{
+    if (!h || workgroups < 0 || workgroups > 64) FAIL("psoap_chunk_set_stream_reserve: 0 <= workgroups <= 64");
+    if (h->stream.open) FAIL("psoap_chunk_set_stream_reserve: set it before psoap_stream_open");
+    h->stream_reserve = workgroups;
     return 0;
 }
 
@@ -723,8 +964,7 @@ static int upload_begin(psoap_chunk* h, int B, int c, const double* gp, double m
     *out = &sl;
     // the copies queued behind this call run beside whatever else is on the device: the handle keeps the device from here
     // to the fetch of the evaluation that reads them (psoap_lnlike: the whole call)
-    handle_lock(h);
-    return 0;
+    return handle_lock(h);
 }
 
 // The |v| >= c flags of a slot are zero unless an orbit upload used it: only then a memset is queued (it runs
@@ -749,7 +989,7 @@ static int upload_end(psoap_chunk* h, BatchSlot& sl)
 extern "C" int psoap_batch_upload(psoap_chunk* h, int B, int c, const double* lwl, const double* gp, double mu_GP)
 {
     if (!h || !lwl || !gp) FAIL("psoap_batch_upload: bad arguments");
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     BatchSlot* sl = nullptr;
     if (int rc = upload_begin(h, B, c, gp, mu_GP, &sl)) return rc;
@@ -765,7 +1005,7 @@ extern "C" int psoap_batch_upload_velocities(psoap_chunk* h, int B, int c, const
 {
     if (!h || !vel || !gp) FAIL("psoap_batch_upload_velocities: bad arguments");
     if (!h->dGrid) FAIL("psoap_batch_upload_velocities: call psoap_chunk_set_grid first");
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     BatchSlot* sl = nullptr;
     if (int rc = upload_begin(h, B, c, gp, mu_GP, &sl)) return rc;
@@ -785,7 +1025,8 @@ extern "C" int psoap_chunk_set_dates(psoap_chunk* h, const double* dates, int n_
 {
     if (!h || !dates) FAIL("psoap_chunk_set_dates: bad arguments");
     if (!h->dGrid || n_epochs != h->n_epochs) FAIL("psoap_chunk_set_dates: call psoap_chunk_set_grid first (same n_epochs)");
-    DeviceScope scope_(h->device);
+    if (h->stream.open) FAIL("psoap_chunk_set_dates: the handle has an open stream (psoap_stream_close first)");
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     HIP_TRY(hipDeviceSynchronize());
     if (h->dDates) HIP_TRY(hipFree(h->dDates));
@@ -818,7 +1059,7 @@ extern "C" int psoap_batch_upload_orbits(psoap_chunk* h, int B, int model, const
 {
     if (!h || !p_orb || !gp) FAIL("psoap_batch_upload_orbits: bad arguments");
     if (!h->dGrid || !h->dDates) FAIL("psoap_batch_upload_orbits: call psoap_chunk_set_grid and psoap_chunk_set_dates first");
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     if (B < 1 || B > h->max_batch) FAIL("batch size outside [1, max_batch]");
     if (int rc = check_orbits(model, B, p_orb)) return rc;
@@ -846,7 +1087,7 @@ extern "C" int psoap_orbit_velocities(int device, int model, int B, const double
 {
     if (B < 1 || n_dates < 1 || !p_orb || !dates || !vel_out) FAIL("psoap_orbit_velocities: bad arguments");
     if (int rc = check_orbits(model, B, p_orb)) return rc;
-    DeviceScope scope_(device);
+    DEVICE_SCOPE(device);
     HIP_TRY(hipSetDevice(device));
     const int c = orbit_n_components(model), np = orbit_n_params(model);
     DevBuf<double> dP, dD, dV;
@@ -1034,24 +1275,40 @@ static int eval_dag(psoap_chunk* h)
     HIP_TRY(hipEventRecord(h->evLast, s));
     h->last_recorded = true;
     HIP_TRY(hipMemcpyAsync(h->hOut, h->dOut, sizeof(double) * B, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(h->hDagErr, h->dDag + offsetof(DagCtl, error), 4 * sizeof(unsigned int),
+    HIP_TRY(hipMemcpyAsync(h->hDagErr, h->dDag + offsetof(DagCtl, error), 6 * sizeof(unsigned int),
                            hipMemcpyDeviceToHost, s));
+    h->last_path = 1;
+    g_share.dag_launches += 1;
     return 0;
 }
+
+static int eval_staged(psoap_chunk* h);
 
 extern "C" int psoap_batch_eval(psoap_chunk* h)
 {
     if (!h) FAIL("psoap_batch_eval: null handle");
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     if (int rc = promote_slot(h, "psoap_batch_eval")) return rc;
-    // the persistent kernel indexes block rows with 8 bits; beyond N = 32640 use the staged path
-    if (h->mode == 1 && h->P <= 255) {
-        handle_lock(h);                   // released by the fetch / sync that sees the launch complete
-        const int rc = eval_dag(h);
-        if (rc) handle_unlock(h);
-        return rc;
+    h->last_group = nullptr;
+    if (int rc = handle_lock(h)) return rc;      // released by the fetch / sync that sees the evaluation complete
+    // the persistent kernel indexes block rows with 8 bits (beyond N = 32640: the staged path), and it is not used where
+    // it cannot be made safe among several processes (share_wants_staged)
+    int rc;
+    if (h->mode == 1 && h->P <= 255 && !share_wants_staged(h->device)) {
+        rc = eval_dag(h);
+    } else {
+        if (h->mode == 1 && h->P <= 255) g_share.staged_policy += 1;
+        rc = eval_staged(h);
     }
+    if (rc) handle_unlock(h);
+    return rc;
+}
+
+// The staged path: three kernels per block row, synchronised by kernel boundaries.
+static int eval_staged(psoap_chunk* h)
+{
+    h->last_path = 0;
     BatchSlot& sl = h->slot[h->act];
     const int B = sl.B, C = sl.C, N = h->N, P = h->P;
     const int G = h->profiling ? 1 : (h->groups < B ? h->groups : B);
@@ -1099,14 +1356,15 @@ extern "C" int psoap_batch_eval(psoap_chunk* h)
             }
             if (prof_begin(h, s, PSOAP_K_POTRF, 0.0, 0.0)) return 1;
             hipLaunchKernelGGL(k_potrf_diag, dim3(nb), dim3(512), 0, s, Kg, h->mat_stride, h->ld, k0,
-                               h->dWt + (size_t)b0 * NB * NB, h->dR + (size_t)b0 * h->Npad, h->Npad, h->dAcc + b0);
+                               h->dWt + (size_t)b0 * WT_STRIDE, h->dR + (size_t)b0 * h->Npad, h->Npad, h->dAcc + b0,
+                               (size_t)WT_STRIDE);
             HIP_TRY(hipGetLastError());
             if (prof_end(h, s)) return 1;
             if (ntile > 1) {
                 if (prof_begin(h, s, PSOAP_K_TRSM, 2.0 * NB * NB * (double)NB * (ntile - 1) * nb, 0.0)) return 1;
                 hipLaunchKernelGGL(k_trsm_strip, dim3(ntile - 1, nb), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, Kg,
-                                   h->mat_stride, h->ld, k0, h->dWt + (size_t)b0 * NB * NB,
-                                   h->dR + (size_t)b0 * h->Npad, h->Npad);
+                                   h->mat_stride, h->ld, k0, h->dWt + (size_t)b0 * WT_STRIDE,
+                                   h->dR + (size_t)b0 * h->Npad, h->Npad, (size_t)WT_STRIDE);
                 HIP_TRY(hipGetLastError());
                 if (prof_end(h, s)) return 1;
             }
@@ -1193,7 +1451,7 @@ extern "C" int psoap_group_create(psoap_group** out, psoap_chunk* const* handles
         if (handles[k]->P > 255) FAIL("psoap_group_create: N too large for the persistent kernel (N <= 32640)");
     }
     *out = nullptr;
-    DeviceScope scope_(handles[0]->device);
+    DEVICE_SCOPE(handles[0]->device);
     HIP_TRY(hipSetDevice(handles[0]->device));
     psoap_group* g = new psoap_group();
     g->device = handles[0]->device;
@@ -1212,7 +1470,7 @@ extern "C" int psoap_group_create(psoap_group** out, psoap_chunk* const* handles
 extern "C" int psoap_group_destroy(psoap_group* g)
 {
     if (!g) return 0;
-    DeviceScope scope_(g->device);
+    DEVICE_SCOPE(g->device);
     (void)hipSetDevice(g->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(g->dDag); (void)hipFree(g->dMats); (void)hipFree(g->dTasks); (void)hipFree(g->dWs);
@@ -1224,25 +1482,43 @@ extern "C" int psoap_group_destroy(psoap_group* g)
 
 // Launch the uploaded batches of all member handles; afterwards psoap_batch_fetch on each handle returns
 // its results (every handle's stream waits for the group launch).
-static int group_eval_locked(psoap_group* g);
+static int group_eval_locked(psoap_group* g, bool promote);
 
 extern "C" int psoap_group_eval(psoap_group* g)
 {
     if (!g) FAIL("psoap_group_eval: null group");
     HIP_TRY(hipSetDevice(g->device));
-    for (psoap_chunk* h : g->hs) handle_lock(h);      // each member's fetch releases its own reference
-    const int rc = group_eval_locked(g);
+    for (psoap_chunk* h : g->hs)                      // each member's fetch releases its own reference
+        if (int rc = handle_lock(h)) {
+            for (psoap_chunk* k : g->hs) handle_unlock(k);
+            return rc;
+        }
+    int rc = 0;
+    if (share_wants_staged(g->device)) {
+        // several processes on the device and no safe persistent launch: every member by the staged path, one after the other
+        for (psoap_chunk* h : g->hs) {
+            if (!rc) rc = promote_slot(h, "psoap_group_eval (every member needs an uploaded batch)");
+            h->last_group = nullptr;
+            if (!rc) g_share.staged_policy += 1;
+            if (!rc) rc = eval_staged(h);
+        }
+    } else {
+        rc = group_eval_locked(g, true);
+    }
     if (rc)
         for (psoap_chunk* h : g->hs) handle_unlock(h);
     return rc;
 }
 
-static int group_eval_locked(psoap_group* g)
+// promote == false: the launch of the slots that are active now, again (settle_evaluation) -- an upload queued meanwhile
+// for the NEXT step stays pending
+static int group_eval_locked(psoap_group* g, bool promote)
 {
     std::vector<int> key, acts;
     int total = 0;
-    for (psoap_chunk* h : g->hs)
-        if (int rc = promote_slot(h, "psoap_group_eval (every member needs an uploaded batch)")) return rc;
+    if (promote)
+        for (psoap_chunk* h : g->hs)
+            if (int rc = promote_slot(h, "psoap_group_eval (every member needs an uploaded batch)")) return rc;
     const int C = g->hs[0]->slot[g->hs[0]->act].C;
     for (psoap_chunk* h : g->hs) {
         const BatchSlot& sl = h->slot[h->act];
@@ -1350,9 +1626,12 @@ static int group_eval_locked(psoap_group* g)
         HIP_TRY(hipEventRecord(h->evLast, s));
         h->last_recorded = true;
         HIP_TRY(hipMemcpyAsync(h->hOut, h->dOut, sizeof(double) * sl.B, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(h->hDagErr, g->dDag + offsetof(DagCtl, error), 4 * sizeof(unsigned int),
+        HIP_TRY(hipMemcpyAsync(h->hDagErr, g->dDag + offsetof(DagCtl, error), 6 * sizeof(unsigned int),
                                hipMemcpyDeviceToHost, s));
+        h->last_path = 1;
+        h->last_group = g;
     }
+    g_share.dag_launches += 1;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(g->evDone, s));
     for (psoap_chunk* h : g->hs) HIP_TRY(hipStreamWaitEvent(h->streams[0], g->evDone, 0));
@@ -1408,7 +1687,7 @@ static int stream_launch(psoap_chunk* h)
     a.tlog_cap = st.tlog_cap;
     MatFlags* fl_ = reinterpret_cast<MatFlags*>(st.dDag + sizeof(DagCtl));
     DagCtl* ctl_ = reinterpret_cast<DagCtl*>(st.dDag);
-    const int grid = h->dag_grid;
+    const int grid = h->dag_grid - h->stream_reserve > 2 ? h->dag_grid - h->stream_reserve : 2;
 #define PSOAP_LAUNCH_STREAM(CC, LAT)                                                                              \
     hipLaunchKernelGGL((k_chol_dag<CC, false, LAT, true>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s,      \
                        st.dMats, st.dTasks, st.queues, fl_, reinterpret_cast<int*>(st.dDag + st.arrive_off), st.dWs, \
@@ -1521,6 +1800,10 @@ static int stream_open_impl(psoap_chunk* h, int c, int lanes, int scheme)
     HIP_TRY(hipEventCreate(&st.evExit));
     HIP_TRY(hipEventCreate(&st.evStart));
     st.lane_ticket.assign((size_t)lanes, -1);
+    st.lane_seq.assign((size_t)lanes, 0ull);
+    st.lane_tries.assign((size_t)lanes, 0);
+    st.lane_kind.assign((size_t)lanes, 0);
+    st.lane_mu.assign((size_t)lanes, 1.0);
     st.neg.assign(STREAM_RING, 0);
     st.head = 0;
     st.open = true;
@@ -1536,7 +1819,14 @@ extern "C" int psoap_stream_open(psoap_chunk* h, int c, int lanes, int scheme)
     if (scheme < -1 || scheme > 2) FAIL("psoap_stream_open: scheme must be -1 (automatic), 0, 1 or 2");
     if (h->P > 255) FAIL("psoap_stream_open: N too large for the persistent kernel (N <= 32640)");
     if (h->stream.open) FAIL("psoap_stream_open: the handle already has an open stream");
-    DeviceScope scope_(h->device);
+    // the dispatcher keeps 3 x n_epochs velocities, 16 parameters and one flag per lane in the tile engine's LDS array
+    if (h->n_epochs > 0 && (3 * (size_t)h->n_epochs + 16) * sizeof(double) + sizeof(int) * (size_t)lanes > GEMM_LDS_BYTES)
+        FAIL("psoap_stream_open: too many epochs for the dispatcher's staging (3 n_epochs + 16 doubles + one int per lane must "
+             "fit 18432 bytes)");
+    if (share_wants_staged(h->device))
+        FAIL("psoap_stream_open: too many processes share this GPU for a resident launch (more than PSOAP_SHARE_DAG_MAX, or "
+             "several without the device lock): use the batch calls");
+    DEVICE_SCOPE(h->device);
     if (int rc = enter_device(h->device)) return rc;
     if (int rc = psoap_chunk_sync(h)) return rc;         // batch evaluations of this handle use the same workspaces
     // the lanes' proposal arrays are those of proposal slot 0: whatever batch was uploaded is gone
@@ -1558,15 +1848,22 @@ static int stream_submit_impl(psoap_chunk* h, int n, int kind, int model, const 
 {
     StreamState& st = h->stream;
     if (!st.open) { g_err = std::string(who) + ": no open stream (psoap_stream_open)"; return 2; }
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     if (st.hHost->error != 0u) { g_err = std::string(who) + ": the stream has failed (a dependency wait timed out); close it"; return 2; }
     int free_lanes = 0;
     for (long long t : st.lane_ticket) free_lanes += (t < 0);
     if (n > free_lanes) { g_err = std::string(who) + ": not enough free lanes (fetch outstanding results first)"; return 2; }
+    if (per > st.h_stride) { g_err = std::string(who) + ": the payload of one submission exceeds the lane's pinned buffer"; return 2; }
+    // a result waits in the ring entry of its submission number: an unfetched one must not be lapped
+    for (size_t l = 0; l < st.lane_ticket.size(); ++l)
+        if (st.lane_ticket[l] >= 0 && st.lane_seq[l] + STREAM_RING <= st.head + (unsigned long long)n + (unsigned long long)st.lanes) {
+            g_err = std::string(who) + ": a result submitted more than 192 submissions ago has not been fetched (fetch it first)";
+            return 2;
+        }
     // the device is this process's while the stream has tickets outstanding (taken BEFORE the head moves: a resident
     // dispatcher starts on the proposals at once); the fetch that takes the last result gives it back
-    handle_lock(h);
+    if (int rc = handle_lock(h)) return rc;
     const int c = st.C;
     int lane = 0;
     for (int k = 0; k < n; ++k) {
@@ -1584,6 +1881,10 @@ static int stream_submit_impl(psoap_chunk* h, int n, int kind, int model, const 
         e.mu = mu_GP;
         st.hHost->result[seq % STREAM_RING].seq1 = 0ull;
         st.lane_ticket[lane] = (long long)seq;
+        st.lane_seq[lane] = seq;
+        st.lane_tries[lane] = 0;
+        st.lane_kind[lane] = e.kind;
+        st.lane_mu[lane] = mu_GP;
         tickets[k] = (long long)seq;
     }
     // publish: everything above is visible before the new head (the device reads head, then the entries and proposals)
@@ -1624,14 +1925,69 @@ extern "C" int psoap_stream_submit_orbits(psoap_chunk* h, int n, int model, cons
                               "psoap_stream_submit_orbits");
 }
 
+static int stream_pause_locked(psoap_chunk* h);
+
+static int stream_lane_of(const StreamState& st, long long ticket)
+{
+    for (int l = 0; l < st.lanes; ++l)
+        if (st.lane_ticket[l] == ticket) return l;
+    return -1;
+}
+
+// Is the result of the matrix in `lane` there?  *ready = 1 and *lnp on yes.  A result whose matrix had a task on a
+// workgroup that MOVED between compute units (StreamResult::tainted; dag_where in dag_kernel.hpp) is not handed out: the
+// lane is submitted again -- its proposal still sits in the lane's pinned buffer -- under a new submission number, the
+// caller's ticket stays what it was.  A stream has no staged path to fall back to: after 4 x PSOAP_SHARE_RETRIES (at least
+// 4) resubmissions of one ticket the call fails loudly.
+static int stream_lane_result(psoap_chunk* h, int lane, double* lnp, int* ready)
+{
+    StreamState& st = h->stream;
+    const unsigned long long seq = st.lane_seq[lane];
+    const size_t idx = (size_t)(seq % STREAM_RING);
+    *ready = 0;
+    if (__atomic_load_n(&st.hHost->result[idx].seq1, __ATOMIC_ACQUIRE) != seq + 1ull) return 0;
+    bool tainted = __atomic_load_n(&st.hHost->result[idx].tainted, __ATOMIC_RELAXED) != 0ull;
+    if (share_inject_taint()) tainted = true;
+    if (!tainted) {
+        if (lnp) *lnp = st.neg[idx] ? -INFINITY : st.hHost->result[idx].lnp;
+        *ready = 1;
+        return 0;
+    }
+    g_share.tainted += 1;
+    const int max_tries = 4 * (share_retries() > 0 ? share_retries() : 1);
+    if (st.lane_tries[lane] >= max_tries)
+        FAIL("psoap_stream: a matrix was disturbed by the device's scheduler in every one of its resubmissions (too many processes "
+             "share this GPU for a resident launch: use batch calls, or fewer processes)");
+    ++st.lane_tries[lane];
+    g_share.stream_resubmits += 1;
+    const unsigned long long nseq = st.head;
+    const size_t nidx = (size_t)(nseq % STREAM_RING);
+    st.neg[nidx] = st.neg[idx];
+    StreamEntry& e = st.hHost->entry[nidx];
+    e.lane = lane;
+    e.kind = st.lane_kind[lane];
+    e.mu = st.lane_mu[lane];
+    st.hHost->result[nidx].seq1 = 0ull;
+    st.hHost->result[nidx].tainted = 0ull;
+    st.lane_seq[lane] = nseq;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    st.head += 1ull;
+    __atomic_store_n(&st.hHost->head, st.head, __ATOMIC_RELEASE);
+    return stream_ensure_running(h);
+}
+
 // 1: the result of `ticket` is there, 0: not yet (never blocks)
 extern "C" int psoap_stream_ready(psoap_chunk* h, long long ticket, int* ready)
 {
     if (!h || !ready || !h->stream.open) FAIL("psoap_stream_ready: bad arguments / no open stream");
-    const StreamState& st = h->stream;
+    StreamState& st = h->stream;
     if (ticket < 0 || (unsigned long long)ticket >= st.head) FAIL("psoap_stream_ready: unknown ticket");
-    *ready = __atomic_load_n(&st.hHost->result[(unsigned long long)ticket % STREAM_RING].seq1, __ATOMIC_ACQUIRE) ==
-             (unsigned long long)ticket + 1ull;
+    const int lane = stream_lane_of(st, ticket);
+    if (lane < 0) FAIL("psoap_stream_ready: the ticket was fetched before (or is too old)");
+    if (set_dev(h)) return 1;
+    if (int rc = stream_lane_result(h, lane, nullptr, ready)) return rc;
+    // (a caller that only ever polls must still get the launch back after an idle exit)
+    if (!*ready) return stream_ensure_running(h);
     return 0;
 }
 
@@ -1643,30 +1999,43 @@ static double stream_fetch_timeout_s()
     return (e && atof(e) > 0.0) ? atof(e) : 120.0;
 }
 
+static int stream_error_message(const StreamState& st, const char* who)
+{
+    char buf[320];
+    snprintf(buf, sizeof buf,
+             "%s: a dependency wait in the resident kernel timed out (results invalid); first failing wait: code=%u target=%u "
+             "seen=%u", who, st.hHost->err_code, st.hHost->err_target, st.hHost->err_seen);
+    FAIL(buf);
+}
+
 // blocks until ONE of the n tickets has its result; *which = its index in `tickets` (the lowest ready one)
 extern "C" int psoap_stream_wait_any(psoap_chunk* h, int n, const long long* tickets, int* which)
 {
     if (!h || !tickets || !which || n < 1) FAIL("psoap_stream_wait_any: bad arguments");
     StreamState& st = h->stream;
     if (!st.open) FAIL("psoap_stream_wait_any: no open stream");
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
-    for (int k = 0; k < n; ++k)
+    std::vector<int> lanes((size_t)n);
+    for (int k = 0; k < n; ++k) {
         if (tickets[k] < 0 || (unsigned long long)tickets[k] >= st.head) FAIL("psoap_stream_wait_any: unknown ticket");
+        lanes[k] = stream_lane_of(st, tickets[k]);
+        if (lanes[k] < 0) FAIL("psoap_stream_wait_any: a ticket was fetched before (or is too old)");
+    }
     long long spins = 0;
     const auto t_begin = std::chrono::steady_clock::now();
     const double limit = stream_fetch_timeout_s();
     for (;;) {
         for (int k = 0; k < n; ++k) {
-            const unsigned long long t = (unsigned long long)tickets[k];
-            if (__atomic_load_n(&st.hHost->result[t % STREAM_RING].seq1, __ATOMIC_ACQUIRE) == t + 1ull) {
+            int ready = 0;
+            if (int rc = stream_lane_result(h, lanes[k], nullptr, &ready)) return rc;
+            if (ready) {
                 *which = k;
                 return 0;
             }
         }
         if ((++spins & 255) == 0) {
-            if (__atomic_load_n(&st.hHost->error, __ATOMIC_ACQUIRE) != 0u)
-                FAIL("psoap_stream_wait_any: a dependency wait in the resident kernel timed out (results invalid)");
+            if (__atomic_load_n(&st.hHost->error, __ATOMIC_ACQUIRE) != 0u) return stream_error_message(st, "psoap_stream_wait_any");
             if (int rc = stream_ensure_running(h)) return rc;
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > limit)
                 FAIL("psoap_stream_wait_any: no result within PSOAP_STREAM_FETCH_TIMEOUT_S");
@@ -1682,31 +2051,24 @@ extern "C" int psoap_stream_fetch(psoap_chunk* h, int n, const long long* ticket
     if (!h || !tickets || !out || n < 1) FAIL("psoap_stream_fetch: bad arguments");
     StreamState& st = h->stream;
     if (!st.open) FAIL("psoap_stream_fetch: no open stream");
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     for (int k = 0; k < n; ++k) {
         const long long t = tickets[k];
         if (t < 0 || (unsigned long long)t >= st.head) FAIL("psoap_stream_fetch: unknown ticket");
-        const size_t idx = (size_t)((unsigned long long)t % STREAM_RING);
-        int lane = -1;
-        for (int l = 0; l < st.lanes; ++l)
-            if (st.lane_ticket[l] == t) lane = l;
+        const int lane = stream_lane_of(st, t);
         if (lane < 0) FAIL("psoap_stream_fetch: the ticket was fetched before (or is too old)");
         long long spins = 0;
         const auto t_begin = std::chrono::steady_clock::now();
         const double limit = stream_fetch_timeout_s();
-        while (__atomic_load_n(&st.hHost->result[idx].seq1, __ATOMIC_ACQUIRE) != (unsigned long long)t + 1ull) {
+        for (;;) {
+            int ready = 0;
+            if (int rc = stream_lane_result(h, lane, &out[k], &ready)) return rc;
+            if (ready) break;
             if ((++spins & 1023) == 0) {
                 if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() > limit)
                     FAIL("psoap_stream_fetch: no result within PSOAP_STREAM_FETCH_TIMEOUT_S (the stream is unusable: close it)");
-                if (__atomic_load_n(&st.hHost->error, __ATOMIC_ACQUIRE) != 0u) {
-                    char buf[256];
-                    snprintf(buf, sizeof buf,
-                             "psoap_stream_fetch: a dependency wait in the resident kernel timed out (results invalid); "
-                             "first failing wait: code=%u target=%u seen=%u", st.hHost->err_code, st.hHost->err_target,
-                             st.hHost->err_seen);
-                    FAIL(buf);
-                }
+                if (__atomic_load_n(&st.hHost->error, __ATOMIC_ACQUIRE) != 0u) return stream_error_message(st, "psoap_stream_fetch");
                 // the launch may have ended (idle time-out) between this ticket's submission and its opening
                 if (int rc = stream_ensure_running(h)) return rc;
             }
@@ -1714,9 +2076,15 @@ extern "C" int psoap_stream_fetch(psoap_chunk* h, int n, const long long* ticket
             __builtin_ia32_pause();
 #endif
         }
-        out[k] = st.neg[idx] ? -INFINITY : st.hHost->result[idx].lnp;
         st.lane_ticket[lane] = -1;
     }
+    // Nothing outstanding any more: the device goes back to the other processes.  When there ARE others the resident
+    // launch must have LEFT before the lock is given up -- it would otherwise sit on every compute unit for its idle
+    // time-out while another process starts its own persistent launch (the first failure of DESIGN.md 5).
+    bool outstanding = false;
+    for (long long t : st.lane_ticket) outstanding = outstanding || t >= 0;
+    if (!outstanding && h->dev_locked && st.launched && share_procs(h->device) > 1)
+        if (int rc = stream_pause_locked(h)) return rc;
     handle_unlock(h);                     // (only if nothing is outstanding any more)
     return 0;
 }
@@ -1725,7 +2093,7 @@ extern "C" int psoap_stream_stats(psoap_chunk* h, long long* launches, long long
                                   int* scheme, long long* tasks_per_matrix)
 {
     if (!h || !h->stream.open) FAIL("psoap_stream_stats: no open stream");
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     const StreamState& st = h->stream;
     if (launches) *launches = st.launches;
@@ -1747,7 +2115,7 @@ extern "C" int psoap_stream_tasklog(psoap_chunk* h, int cap, unsigned long long*
 {
     if (!h || !h->stream.open || cap < 1) FAIL("psoap_stream_tasklog: bad arguments / no open stream");
     StreamState& st = h->stream;
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     const size_t words = (size_t)cap * st.n_tasks * 8;
     if (!out) {
@@ -1771,7 +2139,7 @@ extern "C" int psoap_stream_tasklog(psoap_chunk* h, int cap, unsigned long long*
 extern "C" int psoap_stream_tasks(psoap_chunk* h, void* out, long long max_tasks, long long* n_tasks)
 {
     if (!h || !h->stream.open || !n_tasks) FAIL("psoap_stream_tasks: bad arguments / no open stream");
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     const StreamState& st = h->stream;
     *n_tasks = st.n_tasks;
@@ -1807,8 +2175,14 @@ extern "C" int psoap_stream_pause(psoap_chunk* h)
     if (!h) FAIL("psoap_stream_pause: null handle");
     StreamState& st = h->stream;
     if (!st.open) FAIL("psoap_stream_pause: no open stream");
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
+    return stream_pause_locked(h);
+}
+
+static int stream_pause_locked(psoap_chunk* h)
+{
+    StreamState& st = h->stream;
     if (!st.launched) return 0;
     __atomic_store_n(&st.hHost->close, 1u, __ATOMIC_RELEASE);
     const hipError_t e = hipStreamSynchronize(h->streams[0]);
@@ -1834,14 +2208,14 @@ extern "C" int psoap_stream_close(psoap_chunk* h)
     if (!h) FAIL("psoap_stream_close: null handle");
     StreamState& st = h->stream;
     if (!st.open) return 0;
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     int rc = 0;
     // what is in flight completes; what was published but never opened needs a launch to be consumed
     bool pending = false;
-    for (long long t : st.lane_ticket)
-        if (t >= 0 && __atomic_load_n(&st.hHost->result[(unsigned long long)t % STREAM_RING].seq1, __ATOMIC_ACQUIRE) !=
-                          (unsigned long long)t + 1ull)
+    for (size_t l = 0; l < st.lane_ticket.size(); ++l)
+        if (st.lane_ticket[l] >= 0 &&
+            __atomic_load_n(&st.hHost->result[st.lane_seq[l] % STREAM_RING].seq1, __ATOMIC_ACQUIRE) != st.lane_seq[l] + 1ull)
             pending = true;
     __atomic_store_n(&st.hHost->close, 1u, __ATOMIC_RELEASE);
     if (pending && st.hHost->error == 0u) rc = stream_ensure_running(h);
@@ -1851,17 +2225,58 @@ extern "C" int psoap_stream_close(psoap_chunk* h)
     return rc;
 }
 
+static int group_eval_locked(psoap_group* g, bool promote);
+
+// The evaluation in flight has completed on the handle's stream: was it clean?  A persistent launch in which a workgroup
+// MOVED between compute units while a task ran (DagCtl::pad[3], see dag_where) may have read a stale tile: the same launch
+// is issued again -- same task list, so a clean run returns the bits an undisturbed one would have -- up to
+// PSOAP_SHARE_RETRIES times, then the batch goes down the staged path (kernel boundaries only).  Never silently wrong.
+static int settle_evaluation(psoap_chunk* h)
+{
+    for (int attempt = 0;; ++attempt) {
+        HIP_TRY(hipStreamSynchronize(h->streams[0]));
+        if (h->last_path != 1) return 0;
+        if (h->hDagErr[0] != 0) return 0;                 // a timed-out wait: reported by the caller
+        unsigned int moved = h->hDagErr[4];
+        const unsigned int moved_xcd = h->hDagErr[5];
+        if (share_inject_taint()) moved = moved ? moved : 1u;
+        if (moved == 0u) return 0;
+        g_share.tainted += 1;
+        g_share.moved_tasks += (long long)moved;
+        g_share.moved_xcd += (long long)moved_xcd;
+        h->hDagErr[4] = h->hDagErr[5] = 0;
+        if (share_detect_only()) return 0;
+        if (attempt < share_retries()) {
+            g_share.retries += 1;
+            if (h->last_group) {
+                if (int rc = group_eval_locked(h->last_group, false)) return rc;
+            } else if (int rc = eval_dag(h)) {
+                return rc;
+            }
+            continue;
+        }
+        g_share.staged_fallbacks += 1;
+        h->last_group = nullptr;          // (the other members of a group launch settle for themselves: same flags)
+        if (int rc = eval_staged(h)) return rc;
+    }
+}
+
 extern "C" int psoap_batch_fetch(psoap_chunk* h, double* out)
 {
     if (!h || !out || h->act < 0 || h->slot[h->act].B < 1) FAIL("psoap_batch_fetch: nothing evaluated");
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     const BatchSlot& sl = h->slot[h->act];
-    const hipError_t e_sync = hipStreamSynchronize(h->streams[0]);
-    if (h->pend < 0) handle_unlock(h);      // (an upload queued for the next evaluation keeps the device)
-    HIP_TRY(e_sync);
+    const int rc_settle = settle_evaluation(h);
+    // The device goes back to the other processes here, whatever is queued for this handle's NEXT evaluation: with an
+    // upload pending (the pipelined loops) its copies are waited for first when the device is shared -- they are small, and
+    // a collective or another process's launch must never find this process holding the lock (ranks that share a GPU
+    // would wait for each other: one in the gather, one in flock)
+    if (h->pend >= 0 && share_procs(h->device) > 1) (void)hipStreamSynchronize(h->copy);
+    handle_unlock(h);
+    if (rc_settle) return rc_settle;
     if (collect_timings(h)) return 1;
-    if (h->mode == 1 && h->P <= 255 && h->hDagErr[0] != 0) {
+    if (h->last_path == 1 && h->hDagErr[0] != 0) {
         char buf[512];
         int dbg[32] = {0};
         (void)hipMemcpy(dbg, h->dDag, 16 * sizeof(int), hipMemcpyDeviceToHost);
@@ -1881,7 +2296,7 @@ extern "C" int psoap_batch_fetch(psoap_chunk* h, double* out)
 extern "C" int psoap_chunk_sync(psoap_chunk* h)
 {
     if (!h) FAIL("null handle");
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     hipError_t e = hipSuccess;
     for (int g = 0; g < MAX_GROUPS; ++g)
@@ -1925,7 +2340,7 @@ extern "C" int psoap_fill_sym(int device, int c, int N, const double* lwl, const
                               double* out)
 {
     if (c < 1 || c > 3 || N <= 0 || !lwl || !gp || !out) FAIL("psoap_fill_sym: bad arguments");
-    DeviceScope scope_(device);
+    DEVICE_SCOPE(device);
     HIP_TRY(hipSetDevice(device));
     const int Npad = round_up(N, NB), P = Npad / NB;
     DevBuf<double> dK, dLwl, dGp, dSig;
@@ -1955,7 +2370,7 @@ extern "C" int psoap_fill_cross(int device, int M, int N, const double* lwl_row,
                                 double l, double* out)
 {
     if (M <= 0 || N <= 0 || !lwl_row || !lwl_col || !out) FAIL("psoap_fill_cross: bad arguments");
-    DeviceScope scope_(device);
+    DEVICE_SCOPE(device);
     HIP_TRY(hipSetDevice(device));
     const int ld = round_up(N, 2);
     DevBuf<double> dO, dRow, dCol;
@@ -1982,6 +2397,31 @@ static int predict_check(int mode, int c, int N, int M, const void* lwl, const v
     return 0;
 }
 
+// predict_run until its persistent launch came through undisturbed (return code 3: a workgroup moved, see dag_where), then
+// -- or at once where share_wants_staged says so -- by the staged loop of the transposed-mean variant
+static int predict_settled(PredictWs& ws, int device, int mode, int c, int N, int M, const double* lwl, const double* fl,
+                           const double* sigma, const double* dFl, const double* dSig, const double* lwl_pred,
+                           const double* mu_c, const double* gp, double* mu_out, double* Sigma_out, int* status,
+                           double* var_out)
+{
+    bool staged = share_wants_staged(device);
+    if (staged) g_share.staged_policy += 1;
+    for (int attempt = 0;; ++attempt) {
+        if (!staged) g_share.dag_launches += 1;
+        int rc = predict_run(ws, mode, c, N, M, lwl, fl, sigma, dFl, dSig, lwl_pred, mu_c, gp, mu_out, Sigma_out, status, g_err,
+                             var_out, staged);
+        if (rc == 0 && !staged && share_inject_taint()) rc = 3;
+        if (rc != 3) return rc;
+        g_share.tainted += 1;
+        if (attempt < share_retries()) {
+            g_share.retries += 1;
+        } else {
+            g_share.staged_fallbacks += 1;
+            staged = true;
+        }
+    }
+}
+
 // handle-less form: a workspace for this one call (freed on every path by its destructor)
 extern "C" int psoap_predict(int device, int mode, int c, int N, int M, const double* lwl, const double* fl,
                              const double* sigma, const double* lwl_pred, const double* mu_c, const double* gp,
@@ -1989,16 +2429,14 @@ extern "C" int psoap_predict(int device, int mode, int c, int N, int M, const do
 {
     if (!fl || !sigma) FAIL("psoap_predict: bad arguments");
     if (int rc = predict_check(mode, c, N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
-    DeviceScope scope_(device);
+    DEVICE_SCOPE(device);
     if (int rc = enter_device(device)) return rc;
     PredictWs ws;
     if (int rc = dag_workers(device, &ws.workers, &ws.n_cus)) return rc;
     int status = 0;
-    device_lock_acquire(device);
-    const int rc = predict_run(ws, mode, c, N, M, lwl, fl, sigma, nullptr, nullptr, lwl_pred, mu_c, gp, mu_out,
-                               Sigma_out, &status, g_err);
+    const int rc = predict_settled(ws, device, mode, c, N, M, lwl, fl, sigma, nullptr, nullptr, lwl_pred, mu_c, gp, mu_out,
+                                   Sigma_out, &status, nullptr);
     (void)hipDeviceSynchronize();
-    device_lock_release(device);
     if (status_out) *status_out = status;
     return rc;
 }
@@ -2024,7 +2462,7 @@ extern "C" int psoap_predictor_create(psoap_predictor** out, int device)
 {
     if (!out) FAIL("psoap_predictor_create: bad arguments");
     *out = nullptr;
-    DeviceScope scope_(device);
+    DEVICE_SCOPE(device);
     if (int rc = enter_device(device)) return rc;
     psoap_predictor* p = new psoap_predictor();
     p->device = device;
@@ -2039,7 +2477,7 @@ extern "C" int psoap_predictor_create(psoap_predictor** out, int device)
 extern "C" int psoap_predictor_destroy(psoap_predictor* p)
 {
     if (!p) return 0;
-    DeviceScope scope_(p->device);
+    DEVICE_SCOPE(p->device);
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
     delete p;
@@ -2052,13 +2490,11 @@ extern "C" int psoap_predictor_run(psoap_predictor* p, int mode, int c, int N, i
 {
     if (!p || !fl || !sigma) FAIL("psoap_predictor_run: bad arguments");
     if (int rc = predict_check(mode, c, N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
-    DeviceScope scope_(p->device);
+    DEVICE_SCOPE(p->device);
     if (int rc = enter_device(p->device)) return rc;
     int status = 0;
-    device_lock_acquire(p->device);
-    const int rc = predict_run(p->ws, mode, c, N, M, lwl, fl, sigma, nullptr, nullptr, lwl_pred, mu_c, gp, mu_out,
-                               Sigma_out, &status, g_err);
-    device_lock_release(p->device);
+    const int rc = predict_settled(p->ws, p->device, mode, c, N, M, lwl, fl, sigma, nullptr, nullptr, lwl_pred, mu_c, gp,
+                                   mu_out, Sigma_out, &status, nullptr);
     if (status_out) *status_out = status;
     return rc;
 }
@@ -2070,13 +2506,11 @@ extern "C" int psoap_predictor_run_var(psoap_predictor* p, int mode, int c, int 
 {
     if (!p || !fl || !sigma || !var_out) FAIL("psoap_predictor_run_var: bad arguments");
     if (int rc = predict_check(mode, c, N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
-    DeviceScope scope_(p->device);
+    DEVICE_SCOPE(p->device);
     if (int rc = enter_device(p->device)) return rc;
     int status = 0;
-    device_lock_acquire(p->device);
-    const int rc = predict_run(p->ws, mode, c, N, M, lwl, fl, sigma, nullptr, nullptr, lwl_pred, mu_c, gp, mu_out,
-                               nullptr, &status, g_err, var_out);
-    device_lock_release(p->device);
+    const int rc = predict_settled(p->ws, p->device, mode, c, N, M, lwl, fl, sigma, nullptr, nullptr, lwl_pred, mu_c, gp,
+                                   mu_out, nullptr, &status, var_out);
     if (status_out) *status_out = status;
     return rc;
 }
@@ -2116,7 +2550,7 @@ static int chunk_predict(psoap_chunk* h, int mode, int c, int M, const double* l
 {
     if (!h) FAIL("psoap_chunk_predict: null handle");
     if (int rc = predict_check(mode, c, h->N, M, lwl, lwl_pred, mu_c, gp, mu_out)) return rc;
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (int rc = enter_device(h->device)) return rc;
     if (!h->pws) {
         h->pws = new PredictWs();
@@ -2124,10 +2558,8 @@ static int chunk_predict(psoap_chunk* h, int mode, int c, int M, const double* l
         h->pws->n_cus = h->n_cus;
     }
     int status = 0;
-    device_lock_acquire(h->device);
-    const int rc = predict_run(*h->pws, mode, c, h->N, M, lwl, nullptr, nullptr, h->dFl, h->dSigma, lwl_pred, mu_c, gp,
-                               mu_out, Sigma_out, &status, g_err, var_out);
-    device_lock_release(h->device);
+    const int rc = predict_settled(*h->pws, h->device, mode, c, h->N, M, lwl, nullptr, nullptr, h->dFl, h->dSigma, lwl_pred,
+                                   mu_c, gp, mu_out, Sigma_out, &status, var_out);
     if (status_out) *status_out = status;
     return rc;
 }
@@ -2144,7 +2576,7 @@ extern "C" int psoap_chunk_predict_timings(psoap_chunk* h, psoap_predict_timings
 extern "C" int psoap_chunk_predict_release(psoap_chunk* h)
 {
     if (!h) FAIL("psoap_chunk_predict_release: null handle");
-    DeviceScope scope_(h->device);
+    DEVICE_SCOPE(h->device);
     if (set_dev(h)) return 1;
     delete h->pws;
     h->pws = nullptr;
@@ -2167,7 +2599,7 @@ extern "C" int psoap_calibrate(int device, int c, int M, int N, int order, doubl
     if (c < 1 || c > 3 || calibrate_check(M, N, order, lwl0, lwl1) || !lwl_cal || !lwls_cal || !fl_cal || !sigma_cal ||
         !lwls_fixed || !fl_fixed || !sigma_fixed || !gp || !fl_cor || !X)
         FAIL("psoap_calibrate: bad arguments");
-    DeviceScope scope_(device);
+    DEVICE_SCOPE(device);
     if (int rc = enter_device(device)) return rc;
     CalibInputs in{};
     in.M = M; in.N = N; in.order = order; in.lwl0 = lwl0; in.lwl1 = lwl1; in.mu = mu_GP;
@@ -2187,7 +2619,7 @@ extern "C" int psoap_calibrate_explicit(int device, int M, int N, int order, dou
 {
     if (calibrate_check(M, N, order, lwl0, lwl1) || !lwl_cal || !fl_cal || !fl_fixed || !A || !B || !C || !fl_cor || !X)
         FAIL("psoap_calibrate_explicit: bad arguments");
-    DeviceScope scope_(device);
+    DEVICE_SCOPE(device);
     if (int rc = enter_device(device)) return rc;
     CalibInputs in{};
     in.M = M; in.N = N; in.order = order; in.lwl0 = lwl0; in.lwl1 = lwl1; in.mu = mu_GP;

@@ -140,9 +140,79 @@ class Posterior:
     def lnprob(self, p):
         return float(self.lnprob_batch(np.atleast_2d(p))[0])
 
+    # -- streamed form: the sampler's iterations through ONE resident launch per GPU (samplers.sample_streamed) ----------
+    def can_stream(self) -> bool:
+        """One chunk on this rank, and a worker that has the stream entry points: two resident launches cannot share a
+        device (each takes every compute unit), so a rank with several chunks keeps the launch-per-step group path."""
+        return len(self.mine) == 1 and all(hasattr(w, "stream_submit") for w in self.workers.values())
+
+    def stream_open(self, scheme: int = -1, reserve: int | None = None):
+        """``reserve``: workgroup slots the resident launch leaves free for the gather's kernels (default: 8 when the
+        gather is a device collective -- several ranks over RCCL -- else 0)."""
+        if not self.can_stream():
+            raise RuntimeError("Posterior.stream_open: needs exactly one chunk on this rank (see can_stream)")
+        w = self.workers[self.mine[0]]
+        if reserve is None:
+            reserve = 8 if (self.world > 1 and _collective_on_device()) else 0
+        if reserve and hasattr(w, "handle"):
+            w.handle.set_stream_reserve(reserve)
+        w.stream_open(self.max_batch, scheme)
+        self._streaming = True
+
+    def stream_submit(self, P, group: int = 0):
+        """proposals (n, dim) of one sub-ensemble -> token; every rank submits the same rows (same seeds everywhere)"""
+        P = np.atleast_2d(np.asarray(P, dtype=np.float64))
+        lnprior = np.asarray(self.prior(P), dtype=np.float64)
+        ok = np.isfinite(lnprior)
+        tickets = None
+        if ok.any():
+            Pev = P.copy()
+            Pev[~ok] = P[ok][0]          # (a prior-rejected slot is evaluated on a stand-in: lnprob_batch explains why)
+            tickets = self.workers[self.mine[0]].stream_submit(Pev)
+        return (tickets, lnprior, ok)
+
+    def stream_fetch(self, token) -> np.ndarray:
+        """lnprob of the rows of ``token``: the chunk's result, ONE gather over the ranks, fixed-order sum, prior"""
+        tickets, lnprior, ok = token
+        out = np.full(lnprior.shape[0], -np.inf)
+        if tickets is not None:
+            block = np.asarray(self.workers[self.mine[0]].stream_fetch(tickets), dtype=np.float64)[None, :]
+            table = gather_chunk_lnprobs(block, self.n_chunks, self.world, self.rank, self.device_index)
+            out[ok] = (sum_over_chunks(table) + lnprior)[ok]
+        return out
+
+    def stream_close(self):
+        if getattr(self, "_streaming", False):
+            self.workers[self.mine[0]].stream_close()
+            self._streaming = False
+
+
+def _collective_on_device() -> bool:
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+    except Exception:
+        return False
+
+
+# Where the resident launch pays (profiles/r4_stream_table.jsonl, r5): from N ~ 5000 on with at least 16 chains; below, the
+# launch-per-step path is 1-5 % ahead.
+STREAM_MIN_N = 5000
+STREAM_MIN_CHAINS = 16
+
+
+def want_stream(post, chunks, n_chains) -> bool:
+    """the automatic rule of ``run(stream=None)``: one chunk per rank, an even number of >= 16 chains, chunks of >= 5000
+    pixels; and only ONE process on each GPU (a resident launch holds the device while it has results outstanding)"""
+    if not post.can_stream() or n_chains < STREAM_MIN_CHAINS or n_chains % 2:
+        return False
+    if not isinstance(post.device_lock, _NoLock):
+        return False
+    return min(int(np.asarray(ch.fl).shape[0]) for ch in chunks) >= STREAM_MIN_N
+
 
 def run(config, chunks, run_index=0, n_chains=1, seed=None, world=1, rank=0, device_index=None, iterations=None,
-        config_path=None, make_worker=None, prior=None, verbose=True, overwrite=False, device_lock=None):
+        config_path=None, make_worker=None, prior=None, verbose=True, overwrite=False, device_lock=None, stream=None):
     """Sample ``n_chains`` chains for ``config['samples']`` iterations; returns the sampler.
 
     Chain b uses ``RandomState(seed + b)`` when ``seed`` is given (fresh entropy otherwise -- then every
@@ -188,10 +258,23 @@ def run(config, chunks, run_index=0, n_chains=1, seed=None, world=1, rank=0, dev
         seeds = [None if seed is None else seed + b for b in range(n_chains)]
         sampler = MultiChainMHSampler(cov, dim, post.lnprob_batch, n_chains, seeds)
         n_iter = int(config["samples"] if iterations is None else iterations)
-        for i, _ in enumerate(sampler.sample(p0, lnprob0=lnp0, iterations=n_iter)):
+        # stream: None = automatic (want_stream), True / False force it.  Streamed, the chains' iterations go through one
+        # resident launch per GPU in two halves (samplers.sample_streamed: the loop of sample_parallel.py:434-438 with the
+        # gather of :378-387 per half); the chains are the same either way.
+        use_stream = want_stream(post, chunks, n_chains) if stream is None else bool(stream)
+        sampler.streamed = use_stream
+        if use_stream:
+            post.stream_open()
+            # (the starting value through the stream as well: a lane's result is bit-identical whatever else is in flight,
+            # the batch path's B = 1 plan sums in another order)
+            steps = sampler.sample_streamed(p0, post.stream_submit, post.stream_fetch, groups=2, iterations=n_iter)
+        else:
+            steps = sampler.sample(p0, lnprob0=lnp0, iterations=n_iter)
+        for i, _ in enumerate(steps):
             if verbose and rank == 0 and (i + 1) % 20 == 0:
                 print("Iteration", i + 1)
     finally:
+        post.stream_close()
         post.close()
     if rank == 0:
         if verbose:
@@ -216,6 +299,8 @@ def main(argv=None):
     parser.add_argument("--config", default="config.yaml")
     parser.add_argument("--prefix", default="", help="Directory prefix of the chunk files.")
     parser.add_argument("--overwrite", action="store_true", help="Replace existing run directories.")
+    parser.add_argument("--stream", choices=("auto", "on", "off"), default="auto",
+                        help="Iterations through one resident launch per GPU (auto: one chunk per GPU, >= 16 chains, N >= 5000).")
     args = parser.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -238,7 +323,8 @@ def main(argv=None):
         print("Loaded user defined prior." if prior is not None else "Using default prior.")
     try:
         run(config, chunks, args.run_index, args.chains, seed, world, rank, local if world > 1 else None,
-            config_path=args.config, prior=prior, overwrite=args.overwrite)
+            config_path=args.config, prior=prior, overwrite=args.overwrite,
+            stream={"auto": None, "on": True, "off": False}[args.stream])
     finally:
         if world > 1:
             import torch.distributed as dist

@@ -232,6 +232,76 @@ class MultiChainMHSampler:
             pass
         return results
 
+    # -- the same chains through a split-phase evaluator ------------------------------------------------------------
+    def _propose_rows(self, p, rows):
+        """one proposal per chain of ``rows`` (a range of chain indices), each from its chain's own stream -- the draws of
+        ``sample`` above, chain by chain"""
+        one_d = self.dim == 1 and self.cov.ndim < 2
+        if one_d:
+            return np.stack([self._random[b].normal(loc=p[b, 0], scale=np.ravel(self.cov)[0], size=(1,)) for b in rows])
+        if self._mvn_factor is None:
+            _u, sv, v = np.linalg.svd(self.cov)
+            self._mvn_factor = np.sqrt(sv)[:, None] * v
+        return np.stack([np.dot(self._random[b].standard_normal(self.dim).reshape(-1, self.dim), self._mvn_factor)[0] + p[b]
+                         for b in rows])
+
+    def sample_streamed(self, p0, submit, fetch, groups=2, lnprob0=None, thin=1, storechain=True, iterations=1):
+        """The chains of ``sample`` with the evaluation split into ``submit(P_rows, g) -> token`` and
+        ``fetch(token) -> lnprob_rows``: the B chains form ``groups`` sub-ensembles (red / black halves for two), and while
+        one group's accept / reject is decided and its next proposals are drawn on the host, the other groups' matrices
+        keep the device busy -- the back-to-back iterations of /root/reference/psoap/sample_parallel.py:434-438 through ONE
+        resident launch (``ChunkHandle.stream_*``, ``Posterior.stream_*``).
+
+        No chain's proposal depends on another chain, and every chain still consumes its own random stream in the order
+        propose, (uniform when dlnp < 0), propose, ...: given the same log-probabilities the chains are those of ``sample``
+        and of B scalar ``MHSampler`` runs, bit for bit.  Yields ``(p, lnprob)`` per iteration like ``sample``."""
+        B = self.n_chains
+        groups = int(groups)
+        if groups < 1 or B % groups:
+            raise ValueError("n_chains must be a multiple of groups")
+        rows = [range(g * B // groups, (g + 1) * B // groups) for g in range(groups)]
+        p = np.array(np.broadcast_to(np.asarray(p0, dtype=np.float64), (B, self.dim)))
+        if lnprob0 is None:
+            tok = [submit(p[r.start:r.stop], g) for g, r in enumerate(rows)]
+            lnprob = np.concatenate([np.asarray(fetch(t), dtype=np.float64) for t in tok])
+        else:
+            lnprob = np.array(np.broadcast_to(lnprob0, (B,)), dtype=np.float64)
+        if storechain:
+            n = int(iterations / thin)
+            self._chain = np.concatenate((self._chain, np.zeros((B, n, self.dim))), axis=1)
+            self._lnprob = np.concatenate((self._lnprob, np.zeros((B, n))), axis=1)
+        i0 = self.iterations
+        n_iter = int(iterations)
+        if n_iter < 1:
+            return
+        q = np.empty_like(p)
+        tokens = [None] * groups
+        for g, r in enumerate(rows):                       # iteration 0 of every group goes out
+            q[r.start:r.stop] = self._propose_rows(p, r)
+            tokens[g] = submit(q[r.start:r.stop], g)
+        for i in range(n_iter):
+            self.iterations += 1
+            for g, r in enumerate(rows):
+                new = np.asarray(fetch(tokens[g]), dtype=np.float64)
+                if new.shape != (len(r),):
+                    raise ValueError(f"fetch returned shape {new.shape}, expected ({len(r)},)")
+                for j, b in enumerate(r):
+                    diff = new[j] - lnprob[b]
+                    if diff < 0:
+                        diff = np.exp(diff) - self._random[b].rand()
+                    if diff > 0:
+                        p[b] = q[b]
+                        lnprob[b] = new[j]
+                        self.naccepted[b] += 1
+                if i + 1 < n_iter:                         # the group's next proposals leave before the next group is looked at
+                    q[r.start:r.stop] = self._propose_rows(p, r)
+                    tokens[g] = submit(q[r.start:r.stop], g)
+            if storechain and i % thin == 0:
+                ind = i0 + int(i / thin)
+                self._chain[:, ind, :] = p
+                self._lnprob[:, ind] = lnprob
+            yield p.copy(), lnprob.copy()
+
 
 def gelman_rubin(samplelist):
     """Split-chain Gelman-Rubin statistics of several flatchains (BDA3 p. 284), as

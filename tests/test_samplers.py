@@ -350,3 +350,140 @@ def test_existing_output_directory_raises_on_every_rank_together(tmp_path):
     mp.spawn(_rank_outdir_clash, args=(2, 0, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "verdict_0.txt").read_text() == "FileExistsError"
     assert (tmp_path / "verdict_1.txt").read_text() == "FileExistsError"
+
+
+# ---------------------------------------------------------------- streamed chains (round 5) ------------
+def test_streamed_sampler_equals_lockstep_and_scalar_chains():
+    """samplers.sample_streamed: the B chains in two halves through a split-phase evaluator -- same draws, same decisions,
+    same chains as the lock-step loop and as B scalar MHSampler runs; and the half that was just decided is resubmitted
+    BEFORE the other half is looked at (that is what keeps a resident launch busy)."""
+    cov_t = np.diag([1.0, 4.0, 0.25])
+    icov = np.linalg.inv(cov_t)
+    log = []
+
+    def submit(P, g):
+        log.append(("submit", g, len(P)))
+        return np.array(P)
+
+    def fetch(tok):
+        log.append(("fetch", len(tok)))
+        return np.array([-0.5 * p @ icov @ p for p in tok])
+
+    B, n = 6, 120
+    jump = 0.5 * cov_t
+    p0 = np.array([0.1, -0.2, 0.3])
+    seeds = [300 + b for b in range(B)]
+    m = samplers.MultiChainMHSampler(jump, 3, None, B, seeds=seeds)
+    out = list(m.sample_streamed(p0, submit, fetch, groups=2, iterations=n))
+    assert len(out) == n and m.iterations == n and m.chain.shape == (B, n, 3)
+    ref = samplers.MultiChainMHSampler(jump, 3, lambda P: np.array([-0.5 * p @ icov @ p for p in P]), B, seeds=seeds)
+    ref.run_mcmc(p0, n)
+    assert np.array_equal(m.chain, ref.chain) and np.array_equal(m.lnprobability, ref.lnprobability)
+    assert np.array_equal(m.naccepted, ref.naccepted)
+    for b in (0, B - 1):
+        s = samplers.MHSampler(jump, 3, _gauss(icov))
+        s.run_mcmc(p0, n, rstate0=np.random.mtrand.RandomState(seeds[b]).get_state())
+        assert np.array_equal(m.chain[b], s.chain)
+    # order of calls: start (2 submits, 2 fetches), prime (2 submits), then per iteration fetch g, submit g, fetch g', ...
+    assert log[:6] == [("submit", 0, 3), ("submit", 1, 3), ("fetch", 3), ("fetch", 3), ("submit", 0, 3), ("submit", 1, 3)]
+    body = log[6:]
+    assert body[:4] == [("fetch", 3), ("submit", 0, 3), ("fetch", 3), ("submit", 1, 3)]
+    assert body[-2:] == [("fetch", 3), ("fetch", 3)]                    # the last iteration resubmits nothing
+    assert sum(1 for e in log if e[0] == "submit") == 2 * (n + 1) and sum(1 for e in log if e[0] == "fetch") == 2 * (n + 1)
+    # continuing appends; three groups; a given starting value skips the first evaluation
+    more = samplers.MultiChainMHSampler(jump, 3, None, B, seeds=seeds)
+    list(more.sample_streamed(p0, submit, fetch, groups=3, lnprob0=-0.5 * p0 @ icov @ p0, iterations=n))
+    assert np.array_equal(more.chain, ref.chain)
+    with pytest.raises(ValueError):
+        list(samplers.MultiChainMHSampler(jump, 3, None, 5, seeds=[1] * 5).sample_streamed(p0, submit, fetch, groups=2))
+
+
+class _StreamOracleWorker(_OracleWorker):
+    """the stream entry points of ChunkWorker on the CPU oracle (tickets = the proposals themselves)"""
+    opened = 0
+
+    def stream_open(self, lanes=None, scheme=-1):
+        type(self).opened += 1
+
+    def stream_submit(self, P, mu_GP=1.0):
+        return np.array(P)
+
+    def stream_fetch(self, tickets):
+        return self.lnprob_batch(tickets)
+
+    def stream_close(self):
+        type(self).opened -= 1
+
+
+def test_driver_streamed_equals_lockstep(tmp_path):
+    """run(stream=True): same chains as the lock-step driver and as the oracle's scalar loop; prior-rejected rows never
+    reach the worker; several chunks on a rank refuse to stream."""
+    import sampler_oracle
+    from psoap_amd import sample_parallel as sp
+    config = dict(CONFIG, outdir=str(tmp_path / "a"), samples=8)
+    chunks = _chunks(1)
+    s = sp.run(config, chunks, n_chains=4, seed=40, make_worker=lambda ch: _StreamOracleWorker(ch, config), verbose=False,
+               stream=True)
+    assert s.streamed and _StreamOracleWorker.opened == 0
+    lnprob = _scalar_posterior(chunks, config)
+    p0 = utils.convert_dict("SB2", ["gamma"], **config["parameters"])
+    cov = utils.convert_dict("SB2", ["gamma"], **config["jumps"]) ** 2 * np.eye(10)
+    for b in range(4):
+        chain, lps, _ = sampler_oracle.mh_chain(lnprob, p0, cov, 8, np.random.mtrand.RandomState(40 + b))
+        assert np.array_equal(s.chain[b], chain) and np.allclose(s.lnprobability[b], lps, rtol=1e-13, atol=0)
+    config_b = dict(config, outdir=str(tmp_path / "b"))
+    s2 = sp.run(config_b, chunks, n_chains=4, seed=40, make_worker=lambda ch: _StreamOracleWorker(ch, config_b), verbose=False,
+                stream=False)
+    assert not s2.streamed and np.array_equal(s2.chain, s.chain)
+    # the automatic rule: small chunks / few chains do not stream
+    config_c = dict(config, outdir=str(tmp_path / "c"))
+    assert not sp.run(config_c, chunks, n_chains=4, seed=40, make_worker=lambda ch: _StreamOracleWorker(ch, config_c),
+                      verbose=False).streamed
+    post = sp.Posterior("SB2", _chunks(2), ["gamma"], CONFIG["parameters"], max_batch=2,
+                        make_worker=lambda ch: _StreamOracleWorker(ch, config))
+    assert not post.can_stream()
+    with pytest.raises(RuntimeError, match="one chunk"):
+        post.stream_open()
+    # prior-rejected rows: -inf, a stand-in goes to the worker
+    post1 = sp.Posterior("SB2", chunks, ["gamma"], CONFIG["parameters"], max_batch=4,
+                         make_worker=lambda ch: _StreamOracleWorker(ch, config))
+    post1.stream_open()
+    P = np.tile(p0, (3, 1))
+    P[1, 1] = -3.0
+    tok = post1.stream_submit(P, 0)
+    assert np.all(tok[0][:, 1] > 0.0)
+    out = post1.stream_fetch(tok)
+    assert out[1] == -np.inf and out[0] == out[2] == lnprob(p0)
+    assert post1.stream_fetch(post1.stream_submit(P[[1]], 0)).tolist() == [-np.inf]
+    post1.stream_close()
+
+
+def _rank_streamed(rank, world, port, outdir):
+    os.environ["GLOO_SOCKET_IFNAME"] = "lo"
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import test_samplers as me
+    from psoap_amd import sample_parallel as sp
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(outdir, "rendezvous"), rank=rank, world_size=world)
+    try:
+        config = dict(me.CONFIG, outdir=os.path.join(outdir, "output"), samples=5)
+        s = sp.run(config, me._chunks(2), n_chains=4, seed=9, world=world, rank=rank,
+                   make_worker=lambda ch: me._StreamOracleWorker(ch, config), verbose=False, stream=True)
+        np.save(os.path.join(outdir, f"schain_{rank}.npy"), s.chain)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_driver_streamed_two_ranks_gloo(tmp_path):
+    """one chunk per rank, every half gathered before it is resubmitted (sample_parallel.py:378-390): the chains of both
+    ranks and of the single-process lock-step run are identical"""
+    import torch.multiprocessing as mp
+    from psoap_amd import sample_parallel as sp
+    mp.spawn(_rank_streamed, args=(2, 0, str(tmp_path)), nprocs=2, join=True)
+    c0, c1 = np.load(tmp_path / "schain_0.npy"), np.load(tmp_path / "schain_1.npy")
+    assert np.array_equal(c0, c1)
+    config = dict(CONFIG, outdir=str(tmp_path / "single"), samples=5)
+    s = sp.run(config, _chunks(2), n_chains=4, seed=9, make_worker=lambda ch: _OracleWorker(ch, config), verbose=False)
+    assert np.array_equal(s.chain, c0)

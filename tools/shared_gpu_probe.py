@@ -1,55 +1,116 @@
 """How safe is ONE GPU under several processes?  W worker processes (the reference's fork-then-INIT model, sample_parallel.py:
-258-278), each with its own chunk, evaluate the same proposal over and over through the drop-in call; every value is compared
-with the process's first.  Prints mismatches per worker (-1: the worker's series ended in an error).      python tools/shared_gpu_probe.py [workers reps cfg lock]
-lock: 0 = none (PSOAP_DEVICE_LOCK=0: the hazard itself), 1 = psoap_amd.ensemble.SharedDeviceLock around each call and the
-library's own lock off, 2 = the library's device lock (the default behaviour of libpsoap_gp.so)."""
+258-278), each with its own chunk, evaluate TWO proposals in turn, over and over, through the drop-in call (a stale tile of
+the previous evaluation then belongs to the other proposal: a repeated single proposal would hide it); every value is
+compared with the process's first of that proposal.
+
+    python tools/shared_gpu_probe.py [workers reps cfg lock [policy]]
+
+cfg: 3 = N 6000 (SB2), 1 = N 2000 (SB1), 5 = N 8192 (ST3); lock: 0 = PSOAP_DEVICE_LOCK=0, 1 = ensemble.SharedDeviceLock around
+each call and the library's own lock off, 2 = the library's device lock (the default); policy: auto (default) | dag | staged
+(PSOAP_SHARE_POLICY).  PSOAP_SHARE_DETECT_ONLY=1 in the environment: disturbed launches are counted but their values kept --
+how many of the wrong values belong to a launch that reported a moved workgroup ("wrong_in_disturbed_launch")?  Per worker: WRONG values (beyond the 1e-10 parity contract: what must never happen), values that
+differ in the last bits only (a retry that ended on the staged path), -1 = the series ended in an error; and the library's
+own account (psoap_share_stats): disturbed launches, retries, staged evaluations, time spent waiting for the device."""
+import json
 import multiprocessing as mp
 import os
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-W, reps, cfg, lock = (int(a) for a in (sys.argv[1:5] + ["8", "100", "3", "2"][len(sys.argv) - 1:]))
+argv = sys.argv[1:]
+W, reps, cfg, lock = (int(a) for a in (argv[:4] + ["8", "100", "3", "2"][len(argv[:4]):]))
+policy = argv[4] if len(argv) > 4 else "auto"
 os.environ["PSOAP_DEVICE_LOCK"] = "1" if lock == 2 else "0"
+if policy != "auto":
+    os.environ["PSOAP_SHARE_POLICY"] = policy
 
 
-def worker(k, q):
+def worker(k, q, go):
     import numpy as np
-    from psoap_amd import covariance, synthetic as syn
+    from psoap_amd import _lib, covariance, synthetic as syn
     from psoap_amd.ensemble import SharedDeviceLock, _NoLock
-    ch = syn.make_config_chunk(4 if cfg == 3 else cfg, k) if cfg >= 3 else syn.make_chunk(2, 10, 140, seed=100 + k)
-    gp = syn.GP_BASE[ch.n_components]
-    call = (None, *ch.lwls, ch.fl, ch.sigma, *gp)
+    ch = syn.make_config_chunk(4 if cfg == 3 else cfg, k) if cfg >= 3 else syn.make_chunk(cfg, 10, 200, seed=100 + k)
+    gp = np.asarray(syn.GP_BASE[ch.n_components], dtype=float)
+    gps = (gp, gp * (1.0 + 0.03 * (1 + np.arange(gp.size) % 2)))
     fn = {1: covariance.lnlike_f, 2: covariance.lnlike_f_g, 3: covariance.lnlike_f_g_h}[ch.n_components]
+    calls = [(None, *ch.lwls, ch.fl, ch.sigma, *g) for g in gps]
     guard = SharedDeviceLock(0, "probe") if lock == 1 else _NoLock()
-    with guard:
-        first = fn(*call)
-    bad = 0
-    t0 = time.time()
     err = ""
+    wrong = bits = wrong_tainted = 0
+    detect_only = os.environ.get("PSOAP_SHARE_DETECT_ONLY") == "1"
+    t0 = time.time()
+    first = [None, None]
+    details = []
     try:
-        for _ in range(reps):
+        with guard:
+            first = [fn(*c) for c in calls]          # (the first pair comes up while the others still start: HIP init)
+        try:
+            go.wait(timeout=900)
+        except Exception:                            # (another worker failed before the start line: go on alone)
+            pass
+        t0 = time.time()
+        for r in range(reps):
+            before = _lib.share_stats(0)
+            t_before = before["tainted"]
             with guard:
-                v = fn(*call)
-            bad += (v != first)
-    except Exception as e:          # (without a lock: a dependency wait that timed out ends the worker's series)
-        err = str(e)[:160]
-        bad = -1
-    q.put((k, int(bad), first, time.time() - t0, err))
+                v = fn(*calls[r & 1])
+            f = first[r & 1]
+            if v != f:
+                if abs(v - f) > 1e-10 * max(1.0, abs(f)):
+                    wrong += 1
+                    if detect_only and _lib.share_stats(0)["tainted"] > t_before:
+                        wrong_tainted += 1
+                    if len(details) < 4:          # what came back instead, and what the library knew about that call
+                        after = _lib.share_stats(0)
+                        details.append({"call": r, "got": repr(v), "want": repr(f), "other_proposal": repr(first[1 - (r & 1)]),
+                                        "tainted_during": after["tainted"] - before["tainted"],
+                                        "retries_during": after["retries"] - before["retries"],
+                                        "staged_during": after["staged_fallbacks"] + after["staged_policy"]
+                                        - before["staged_fallbacks"] - before["staged_policy"], "procs": after["procs"]})
+                else:
+                    bits += 1
+    except Exception as e:          # (a dependency wait that timed out, a lock that was never released: the series ends)
+        err = str(e)[:200]
+        wrong = -1
+        try:
+            go.abort()
+        except Exception:
+            pass
+    dt = time.time() - t0
+    try:
+        stats = _lib.share_stats(0)
+    except Exception as e:
+        stats = {"error": str(e)[:80]}
+    stats["wrong_in_disturbed_launch"] = int(wrong_tainted)
+    stats["wrong_details"] = details
+    q.put((k, int(wrong), int(bits), first, dt, err, stats))
 
 
 if __name__ == "__main__":
     ctx = mp.get_context("fork")
     q = ctx.Queue()
-    ps = [ctx.Process(target=worker, args=(k, q)) for k in range(W)]
+    go = ctx.Barrier(W)
+    ps = [ctx.Process(target=worker, args=(k, q, go)) for k in range(W)]
     for p in ps:
         p.start()
     res = sorted(q.get() for _ in ps)
     for p in ps:
         p.join()
-    print(f"{W} workers x {reps} evaluations (cfg {cfg}, lock {lock}): mismatches per worker {[r[1] for r in res]}, "
-          f"seconds {max(r[3] for r in res):.1f}")
+    tot = {}
     for r in res:
-        if r[4]:
-            print(f"  worker {r[0]} ended with: {r[4]}")
-    sys.exit(1 if lock and any(r[1] for r in res) else 0)
+        for key, v in r[6].items():
+            if isinstance(v, int) and key not in ("procs", "lock_enabled"):
+                tot[key] = tot.get(key, 0) + v
+    secs = max(r[4] for r in res)
+    n_eval = W * reps
+    print(f"{W} workers x {reps} evaluations (cfg {cfg}, lock {lock}, policy {policy}): WRONG per worker {[r[1] for r in res]}, "
+          f"last-bit differences {[r[2] for r in res]}, {secs:.1f} s = {1e3 * secs / max(reps, 1):.2f} ms per call per worker, "
+          f"{n_eval / secs:.0f} evals/s in all")
+    print("  library account (all workers): " + json.dumps(tot) + f"; procs seen {[r[6].get('procs') for r in res]}")
+    for r in res:
+        if r[5]:
+            print(f"  worker {r[0]} ended with: {r[5]}")
+        for d in r[6].get("wrong_details", []):
+            print(f"  worker {r[0]} WRONG: {json.dumps(d)}")
+    sys.exit(1 if any(r[1] for r in res) else 0)
