@@ -226,13 +226,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--walkers", type=int, default=N_WALKERS)
     ap.add_argument("--groups", type=int, default=2, help="concurrent stream groups per batch (staged mode)")
-    ap.add_argument("--mode", default="stream", choices=["stream", "dag", "staged"],
+    ap.add_argument("--mode", default=None, choices=["stream", "dag", "staged"],
                     help="stream: the timed steps through ONE resident launch (two half-ensembles in flight); dag / staged: "
-                         "one launch (three per panel) per step")
+                         "one launch (three per panel) per step.  Default: stream on one GPU; dag on several -- the RCCL "
+                         "gather of a step then runs between two launches (beside a resident launch a device collective "
+                         "waits for the launch to leave: profiles/r5_gather_beside_stream.txt; --mode stream on several "
+                         "ranks gathers every half-ensemble through the gloo side group on the host instead)")
     ap.add_argument("--stream-groups", type=int, default=2, help="sub-ensembles in flight in --mode stream")
-    ap.add_argument("--stream-reserve", type=int, default=-1,
-                    help="workgroup slots the resident launch leaves free for the gather's kernels (-1: 8 with several ranks "
-                         "over RCCL, else 0)")
     ap.add_argument("--allow-fallback", action="store_true",
                     help="print `value` even if the library was built from the fallback flag rung (psoap_amd/build.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -254,6 +254,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.mode is None:
+        args.mode = "stream" if world == 1 else "dag"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if args.backend == "gloo":       # dry run: several ranks may share one GPU
@@ -348,20 +350,17 @@ def main():
     if args.mode == "stream":
         if B % args.stream_groups:
             raise SystemExit("--walkers must be a multiple of --stream-groups")
-        # several ranks over RCCL: the gather's kernels (staging copies, all_gather) run on another stream while the launch
-        # is resident -- it leaves a few workgroup slots free for them (tests/test_gpu_workers.py measures it)
-        stream_reserve = args.stream_reserve if args.stream_reserve >= 0 else (8 if (world > 1 and args.backend == "nccl") else 0)
-        if stream_reserve:
-            h.set_stream_reserve(stream_reserve)
         pipe = StreamPipeline(h, c, B, args.stream_groups)
         half = {"table": np.zeros((world, B)), "total": np.zeros(B)}
 
         def gather_half(g, rows, lnp_rows):
             """a sub-ensemble's lnprobs over the ranks BEFORE its successor is submitted: a sampler's next proposals
             depend on the chunk sum (sample_parallel.py:378-390)"""
-            t = gather_chunk_lnprobs(lnp_rows[None, :], world, world, rank, local_rank)
+            # (on the host -- the gloo side group of ensemble.host_group -- while the launch is resident: a device collective
+            # would wait for it to leave, 2.4 x the step time: profiles/r5_gather_beside_stream.txt)
+            t = gather_chunk_lnprobs(lnp_rows[None, :], world, world, rank, local_rank, on_host=True)
             if world > 1:
-                collectives["n"] += 1
+                collectives["host"] = collectives.get("host", 0) + 1
             half["table"][:, rows] = t
             half["total"][rows] = sum_over_chunks(t)
 
@@ -542,6 +541,7 @@ def main():
             # ranks of the RCCL communicator the gathers of this run actually went through (0: none ran -- one GPU, or gloo)
             "rccl_ranks": dist.get_world_size() if (world > 1 and args.backend == "nccl" and collectives["n"] > 0) else 0,
             "collectives_completed": collectives["n"],
+            "host_gathers_completed": collectives.get("host", 0),
             "backend": args.backend if world > 1 else None,
             "config": {"workload": f"SB2 chunk 20 epochs x 300 px (N={N}), {B} walkers per step per GPU, "
                                    f"one chunk per GPU (BASELINE.json configs[2]; configs[3] at 8 GPUs); " +
@@ -552,7 +552,6 @@ def main():
                                     f"timed step = H2D of next proposals || eval, D2H of {B} lnprobs, gather"),
                        "N": N, "components": c, "walkers": B, "chunks_per_gpu": 1, "mode": args.mode,
                        "stream_groups": args.stream_groups if args.mode == "stream" else args.groups,
-                       "stream_reserve": stream_reserve if args.mode == "stream" else 0,
                        "parallelism": f"chunk-sharded x{world}, RCCL all_gather of walker lnprobs"},
             "timing_boundary": ("pcie_inclusive (every proposal is pulled from pinned host memory by the resident launch, "
                                 "every result written to it; the timed region starts and ends with nothing in flight and "

@@ -324,11 +324,6 @@ int psoap_stream_pause(psoap_chunk *h);
 int psoap_stream_last_launch(psoap_chunk *h, double *ms, long long *matrices);
 /* waits for what is in flight, ends the resident launch, frees the stream */
 int psoap_stream_close(psoap_chunk *h);
-/* Workgroup slots (of the 2 x compute-units a resident launch would occupy) that the stream's launch leaves free, so that
- * kernels of OTHER streams -- the RCCL all_gather of the walker lnprobs (psoap/sample_parallel.py:378-387) and its
- * staging copies -- run beside it instead of waiting for it to leave.  Call before psoap_stream_open; 0 (default): the
- * launch takes the whole device.  Results do not depend on it. */
-int psoap_chunk_set_stream_reserve(psoap_chunk *h, int workgroups);
 /* counters: launches of the resident kernel so far (> 1 after an idle time-out), submissions, completed results, the
  * scheme of the lanes' task list and its length; any pointer may be NULL */
 int psoap_stream_stats(psoap_chunk *h, long long *launches, long long *submitted, long long *completed, int *scheme,
@@ -363,6 +358,13 @@ int psoap_dag_plan_aug(int P, int Mt, int Ms, int workers, int scheme, void *tas
                        long long max_tasks, long long *n_tasks, long long *n_slots,
                        long long *n_ctrs, unsigned int *queue_first);
 
+/* Pure host function: a batch's task list with the two hand-out orders of the ready-only scheme (round 5: finals in list
+ * order, PART tasks taken only when their panels and predecessor are there) -- order[], dep[], n_main[8]; *has_pool = 0 and
+ * no orders for the throughput scheme.  Mt / Ms > 0 (appended column tiles, Schur block): one matrix (predict).
+ * tests/test_dag_plan.py plays the hand-out through on the CPU. */
+int psoap_dag_plan_pool(int B, const int *Ps, int workers, int Mt, int Ms, int scheme, void *tasks_out,
+                        long long max_tasks, long long *n_tasks, unsigned int *order_out, unsigned int *dep_out,
+                        unsigned int *n_main_out, unsigned int *queue_first, int *has_pool, long long *n_ctrs);
 /* Pure host function: the number of persistent workgroups a batch gets -- all the device admits (two per
  * compute unit), or one per compute unit when the batch is bound by the row-to-row chains of its matrices
  * (algorithmic flops <= 3.3e9 x block rows of the largest matrix).  Ps[b]: block rows of

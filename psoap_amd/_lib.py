@@ -94,7 +94,6 @@ SIGNATURES = {
     "psoap_stream_wait_any": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), _ip]),
     "psoap_stream_ready": (ctypes.c_int, [_vp, ctypes.c_longlong, _ip]),
     "psoap_stream_close": (ctypes.c_int, [_vp]),
-    "psoap_chunk_set_stream_reserve": (ctypes.c_int, [_vp, ctypes.c_int]),
     "psoap_stream_pause": (ctypes.c_int, [_vp]),
     "psoap_stream_last_launch": (ctypes.c_int, [_vp, _dp, ctypes.POINTER(ctypes.c_longlong)]),
     "psoap_stream_stats": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong),
@@ -121,6 +120,10 @@ SIGNATURES = {
                                           ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong),
                                           ctypes.POINTER(ctypes.c_uint32)]),
     "psoap_dag_pick_workers": (ctypes.c_int, [ctypes.c_int, _ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, _ip]),
+    "psoap_dag_plan_pool": (ctypes.c_int, [ctypes.c_int, _ip, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp,
+                                           ctypes.c_longlong, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_uint32),
+                                           ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32),
+                                           ctypes.POINTER(ctypes.c_uint32), _ip, ctypes.POINTER(ctypes.c_longlong)]),
 }
 
 # include/psoap_bench.h (libpsoap_bench.so): measurement kernels, loaded by bench.py / tools / one GPU test only

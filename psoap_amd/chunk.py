@@ -73,11 +73,6 @@ class ChunkHandle:
         m = {"staged": 0, "dag": 1}.get(mode, mode)
         check(self._L.psoap_chunk_set_mode(self._h, int(m)), "psoap_chunk_set_mode")
 
-    def set_stream_reserve(self, workgroups: int):
-        """Workgroup slots a resident stream launch leaves free for kernels of other streams -- the RCCL gather of
-        ``psoap_amd.ensemble`` runs beside the launch instead of behind it.  Before ``stream_open``."""
-        check(self._L.psoap_chunk_set_stream_reserve(self._h, int(workgroups)), "psoap_chunk_set_stream_reserve")
-
     def set_profiling(self, enabled: bool):
         check(self._L.psoap_chunk_set_profiling(self._h, int(bool(enabled))), "psoap_chunk_set_profiling")
 

@@ -101,15 +101,29 @@ struct DagQueues {
     unsigned int first[DAG_QUEUES + 1];
     unsigned int follow_first;      // scheme 2: the first block row whose strip solves follow (0, or 2: PSOAP_FOLLOW_ROW0=0)
 };
-// Ready-only hand-out of the PART tasks (round 5; the latency schemes' plain launches: k_chol_dag<.., LAT = true, STREAM =
-// false>).  With ONE in-order ticket list a workgroup that draws a PART whose panels or predecessor are not there yet holds
-// it and waits -- 80-130 of the 256 workgroups of a single N = 6000 evaluation at any time (profiles/r3_wg_occupancy.txt),
-// while ready PARTs further down the list wait for a workgroup.  The list is therefore handed out in two parts per queue:
+// Ready-only hand-out of the PART tasks (round 5, the review's item 4, asked for since round 3) -- BUILT, MEASURED, NOT
+// SHIPPED: compiled in with -DPSOAP_POOL only (tools/build_variant.py pool -DPSOAP_POOL).  The premise was round 3's reading of
+// tools/wg_occupancy.py: "80-130 of the 256 workgroups of a single N = 6000 evaluation hold PARTs that wait".  That column
+// counts a part from its start to the stamp behind its LAST panel's wait -- the look-ahead K-loop over its older panels
+// included.  The stamps that add up the waits themselves (tools/part_wait_share.py, profiles/r5_pool_*.txt) say: in list
+// order the parts spend 6.9 % of the time they hold a workgroup waiting for block rows and 5.6 % for their predecessor's
+// tile at N = 6000 (2.7 / 2.1 % at N = 8192, 2.9 / 2.4 % for eight matrices) -- at most 8 % of the launch's capacity, on
+// a launch whose length is the row-to-row chain's.  Handed out ready-only (three iterations: compare-exchange per final,
+// chains overlapping again, fetch-add with held tickets; windows of 128 ... 4096 parts; just-in-time leads 0 ... 16) the
+// waits for rows drop to 1.2 % and the finals pay for it: they are drawn later, hold their workgroups for 186 ms in all
+// instead of 121 (eight matrices: 4.92 s instead of 3.37) and the row-to-row period grows from 55 to 70 us -- a single
+// N = 6000 evaluation takes 3.25 ms against 2.57, eight take 15.0 against 10.9, N = 8192 5.85 against 4.82, predict 11.7
+// against 10.5.  The list order with its just-in-time parts IS the better scheduler here; what bounds the single evaluation
+// is the chain.
+// How it works, for the record.  With ONE in-order ticket list a workgroup that draws a PART whose panels or predecessor are
+// not there yet holds it and waits, while ready PARTs further down the list wait for a workgroup.  The list is handed out
+// in two parts per queue:
 //   main  the finals (DIAG / OFF / SCHUR), in the list's order, from a ticket counter as before -- but a final with a chain
 //         is only handed out once the chain's LAST part has been taken (so whoever holds a final waits for running work only);
-//   pool  the PARTs, in the list's order, each with a `taken` word: a workgroup that finds no final to take scans a window
-//         of the pool from its first untaken entry and takes the first part that is READY -- its panels' block rows
-//         complete (rows_done >= pb) and its predecessor's tile there (arrive[ctr] >= S) -- so a part never waits.
+//   pool  the PARTs, in the list's order, each with a `taken` bit: a workgroup that finds no final to take scans a window
+//         of the pool from its first untaken entry and takes a part that is READY -- its panels' block rows complete
+//         (rows_done >= pb) and its predecessor in the chain TAKEN (it adds the predecessor's running sum at the end of
+//         its own update, so the parts of a chain overlap as they do in list order).
 // Every wait still targets a task somebody is running: finals wait for finals with smaller main tickets (all handed out)
 // and for their chain (all taken); parts wait for nothing.  And something can always be taken: when nothing runs, either
 // the head final's chain is taken (it can be handed out) or the pool's first untaken part is ready (its predecessors are
@@ -120,7 +134,7 @@ constexpr unsigned int DAG_POOL_NONE = 0xffffffffu;
 struct DagPool {
     const unsigned int* order;      // nullptr: the launch hands its tasks out in list order (schemes 0, streams)
     const unsigned int* dep;
-    int* taken;                     // one word per entry of order[] (those of pool entries are used), zeroed per launch
+    unsigned int* taken;            // one BIT per entry of order[] (bit p & 31 of word p >> 5), zeroed per launch
     unsigned int n_main[DAG_QUEUES];
 };
 
@@ -1480,6 +1494,161 @@ __device__ __forceinline__ void stream_dispatch(const StreamArgs& st, const DagM
     }
 }
 
+// Ready-only hand-out (DagPool): wave 0 finds this workgroup's next task -- the head final of a queue when it may be handed
+// out, else the first READY part in a window of that queue's pool, its own queue first, then the others from `steal0` on.
+// *s_ticket: the task's index in tasks[], or 0xffffffff when every queue is through (or the launch has failed).
+// Everything read here changes under the reader: the flag words are read with atomics (executed at the memory side, like
+// every poll of this kernel), claims are atomic compare-exchange / or.  Per scan of a queue: the ticket word, the pool's
+// first-untaken cursor, two words of the taken bitmap (a window of 64 parts), rows_done once per matrix in the window and
+// one wave instruction of arrival-counter reads.
+constexpr unsigned int DAG_NO_TASK = 0xffffffffu;
+#ifndef PSOAP_POOL_WINDOWS
+#define PSOAP_POOL_WINDOWS 4
+#endif
+constexpr unsigned int DAG_POOL_WINDOWS = PSOAP_POOL_WINDOWS;
+__device__ __forceinline__ void pool_take(const DagTask* __restrict__ tasks, const DagQueues& queues, const DagPool& pool,
+                                          DagCtl* ctl, MatFlags* flags, int home, int steal0,
+                                          unsigned int* s_ticket, unsigned int* s_pending)
+{
+    // *s_pending (in / out, LDS): the position in order[] of a final this workgroup has drawn a ticket for but may not
+    // run yet -- its chain's last part has not been taken.  Finals are drawn with ONE fetch-add each, like the tickets of
+    // the in-order list (a compare-exchange per final serialised the workgroups: one winner per round trip, 30-60 us per
+    // block row); whoever overshoots the finals that may be handed out keeps its ticket and takes ready parts meanwhile.
+    if (threadIdx.x < 64) {
+        const int l = hw_lane();
+        unsigned int got = DAG_NO_TASK;
+        unsigned int pending = (unsigned int)__builtin_amdgcn_readfirstlane((int)*s_pending);
+        long long spins = 0;
+        auto taken_bit = [&](unsigned int d) -> unsigned int {
+            unsigned int w = 0u;
+            if (l == 0) w = __hip_atomic_fetch_or(&pool.taken[d >> 5], 0u, PSOAP_RLX_AGENT);
+            return ((unsigned int)__builtin_amdgcn_readfirstlane((int)w) >> (d & 31u)) & 1u;
+        };
+        for (;;) {
+            bool left = pending != DAG_NO_TASK;     // something is still to be handed out somewhere
+            if (pending != DAG_NO_TASK) {
+                const unsigned int d = pool.dep[pending];
+                if (d == DAG_POOL_NONE || taken_bit(d)) {
+                    got = pool.order[pending];
+                    pending = DAG_NO_TASK;
+                    break;
+                }
+            }
+            for (int probe = 0; probe <= DAG_QUEUES && got == DAG_NO_TASK; ++probe) {
+                const int g = probe == 0 ? home : (steal0 + probe - 1) % DAG_QUEUES;
+                if (probe > 0 && g == home) continue;
+                const unsigned int lo = queues.first[g], n_all = queues.first[g + 1] - lo, n_main = pool.n_main[g];
+                if (n_all == 0u) continue;
+                // 1. the head final: handed out in list order, and only once the last part of its chain has been taken
+                unsigned int m = 0u;
+                if (l == 0) m = __hip_atomic_fetch_add(&ctl->queue[g].next, 0u, PSOAP_RLX_AGENT);
+                m = (unsigned int)__builtin_amdgcn_readfirstlane((int)m);
+                if (m < n_main) {
+                    left = true;
+                    const unsigned int d = pool.dep[lo + m];
+                    if (pending == DAG_NO_TASK && (d == DAG_POOL_NONE || taken_bit(d))) {
+                        unsigned int tk = 0u;
+                        if (l == 0) tk = __hip_atomic_fetch_add(&ctl->queue[g].next, 1u, PSOAP_RLX_AGENT);
+                        tk = (unsigned int)__builtin_amdgcn_readfirstlane((int)tk);
+                        if (tk < n_main) {
+                            const unsigned int d2 = pool.dep[lo + tk];
+                            if (d2 == DAG_POOL_NONE || taken_bit(d2)) {
+                                got = pool.order[lo + tk];
+                                break;
+                            }
+                            pending = lo + tk;      // drawn ahead of what may run: held, parts meanwhile
+                        }
+                    }
+                }
+                // 2. the pool: the 64 parts of the two bitmap words around the first untaken one
+                const unsigned int p0 = lo + n_main, p1 = lo + n_all;       // the pool's positions in order[]
+                if (p0 == p1) continue;
+                unsigned int cur = 0u;
+                if (l == 0) cur = __hip_atomic_fetch_add(&ctl->queue[g].fill[0], 0u, PSOAP_RLX_AGENT);
+                cur = p0 + (unsigned int)__builtin_amdgcn_readfirstlane((int)cur);
+                if (cur >= p1) continue;
+                left = true;
+                // (a second window when the first holds nothing ready: the parts at the cursor may all wait for a predecessor
+                // that is running, while the next rows' are ready)
+#pragma unroll 1
+                for (unsigned int win = 0u; win < DAG_POOL_WINDOWS && got == DAG_NO_TASK; ++win) {
+                const unsigned int base = (cur & ~31u) + 64u * win;
+                if (base >= p1) break;
+                unsigned int word = 0xffffffffu;
+                if (l < 2 && base + 32u * (unsigned int)l < p1)
+                    word = __hip_atomic_fetch_or(&pool.taken[(base >> 5) + (unsigned int)l], 0u, PSOAP_RLX_AGENT);
+                const unsigned int w0 = (unsigned int)__builtin_amdgcn_readlane((int)word, 0);
+                const unsigned int w1 = (unsigned int)__builtin_amdgcn_readlane((int)word, 1);
+                const unsigned int pos = base + (unsigned int)l;
+                const bool mine = pos >= cur && pos < p1 && !(((l < 32 ? w0 : w1) >> (l & 31)) & 1u);     // untaken, in range
+                // the cursor moves up to the first untaken part (monotone; a stale view only makes it lag)
+                if (win == 0u) {
+                    const unsigned long long un = __ballot(mine);
+                    const unsigned int first_un = un ? base + (unsigned int)__builtin_ctzll(un) : (base + 64u < p1 ? base + 64u : p1);
+                    if (l == 0 && first_un > cur) __hip_atomic_fetch_max(&ctl->queue[g].fill[0], first_un - p0, PSOAP_RLX_AGENT);
+                }
+                // ready: the block rows its panels read are complete and its predecessor's running sum is there
+                DagTask t{};
+                if (mine) t = tasks[pool.order[pos]];
+                bool ready = false;
+                {
+                    unsigned long long todo = __ballot(mine);
+                    while (todo) {                  // rows_done once per matrix of the window
+                        const int src = __builtin_ctzll(todo);
+                        const int b0 = __builtin_amdgcn_readlane((int)t.b, src);
+                        int rd = 0;
+                        if (l == 0) rd = dag_peek(&flags[b0].rows_done);
+                        rd = __builtin_amdgcn_readfirstlane(rd);
+                        const bool same = mine && (int)t.b == b0;
+                        if (same) ready = rd >= (int)t.pb;
+                        todo &= ~__ballot(same);
+                    }
+                }
+                if (ready && (t.type & DAG_CHAIN) && t.S > 0) {
+                    // the predecessor has been taken (it runs, or is through): the part may start, it waits for the
+                    // predecessor's tile only when its own update is done
+                    const unsigned int pp = pool.dep[pos];
+                    ready = (__hip_atomic_fetch_or(&pool.taken[pp >> 5], 0u, PSOAP_RLX_AGENT) >> (pp & 31u)) & 1u;
+                }
+                unsigned long long rdy = __ballot(ready);
+                while (rdy) {
+                    // (the workgroups scan the same window at the same time: each starts at another ready part)
+                    const int n_rdy = __builtin_popcountll(rdy);
+                    int skip = (int)(blockIdx.x % (unsigned int)n_rdy);
+                    unsigned long long r2 = rdy;
+                    while (skip-- > 0) r2 &= r2 - 1ull;
+                    const int pick = __builtin_ctzll(r2);
+                    unsigned int old = 0xffffffffu;
+                    if (l == pick) old = __hip_atomic_fetch_or(&pool.taken[pos >> 5], 1u << (pos & 31u), PSOAP_RLX_AGENT);
+                    old = (unsigned int)__builtin_amdgcn_readlane((int)old, pick);
+                    const unsigned int ppos = base + (unsigned int)pick;
+                    if (!((old >> (ppos & 31u)) & 1u)) {
+                        got = pool.order[ppos];
+                        break;
+                    }
+                    rdy &= ~(1ull << pick);
+                }
+                }
+            }
+            if (got != DAG_NO_TASK || !left) break;
+            unsigned int err = 0u;
+            if (l == 0) err = __hip_atomic_fetch_or(&ctl->error, 0u, PSOAP_RLX_AGENT);
+            if (__builtin_amdgcn_readfirstlane((int)err) != 0) break;
+            __builtin_amdgcn_s_sleep(64);
+            if (++spins > DAG_MAX_SPINS) {          // (nothing became ready for seconds: a failed launch, reported)
+                if (l == 0 && __hip_atomic_fetch_or(&ctl->error, 1u, PSOAP_RLX_AGENT) == 0u)
+                    __hip_atomic_store(&ctl->pad[0], 10u, PSOAP_RLX_AGENT);
+                break;
+            }
+        }
+        if (l == 0) {
+            *s_ticket = got;
+            *s_pending = pending;
+        }
+    }
+    __syncthreads();
+}
+
 // LAT: the instantiation launched for task lists of the latency scheme; only it contains the fused diagonal
 // fast path (dag_diag_fast).  With that path compiled into the one kernel, hipcc keeps a spilled value in the
 // MFMA loops of every task (a scratch load per 64-MFMA stage: 32-walker batch 39.5 -> 43.7 ms); the
@@ -1495,11 +1664,12 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
                                                              const DagTask* __restrict__ tasks, DagQueues queues,
                                                              MatFlags* flags, int* arrive, double* wspace,
                                                              DagCtl* ctl, unsigned long long* tlog, DagAug aug,
-                                                             StreamArgs st)
+                                                             StreamArgs st, DagPool pool)
 {
     __shared__ double vec1[NB];   // z_k (OFF)
     __shared__ double vec2[NB];   // column sums (OFF)
     __shared__ unsigned int s_ticket;
+    __shared__ unsigned int s_pending;      // ready-only hand-out: a final drawn ahead of its turn (pool_take)
     __shared__ int s_lane;
     if constexpr (STREAM) {
         if (blockIdx.x == 0) {
@@ -1542,6 +1712,16 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
     // workgroup waiting (257 us per diagonal task before, 1.9 % of all worker time of a streamed run) and potrf(q+1) is
     // out long before the strip solves of row q+1 ask for it.
     constexpr bool CONT = !LAT && DAG_TILE_DEPS;
+    // ready-only hand-out of the PART tasks (DagPool): an experiment of round 5, compiled in with -DPSOAP_POOL only -- it is
+    // SLOWER than the list order (see the comment at DagPool)
+#ifdef PSOAP_POOL
+    constexpr bool POOL = LAT && !STREAM;
+#else
+    constexpr bool POOL = false;
+#endif
+    (void)pool;
+    if (threadIdx.x == 0) s_pending = DAG_NO_TASK;
+    __syncthreads();
     bool cont = false;
     unsigned int ticket = 0;
     int b = 0;
@@ -1561,6 +1741,12 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             // scalar cache (uniform loads -- the hyper-parameters -- go through it; the vector caches were invalidated by
             // the acquire in stream_take)
             asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if constexpr (POOL) {
+            // the latency schemes' plain launches: finals in list order, parts ready-only (pool_take)
+            pool_take(tasks, queues, pool, ctl, flags, home, steal0, &s_ticket, &s_pending);
+            ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)s_ticket);
+            __syncthreads();  // s_ticket is rewritten by the next pool_take
+            if (ticket == DAG_NO_TASK) return;
         } else {
             if (dry == (1u << DAG_QUEUES) - 1u) return;
             const int g = (probe == 0) ? home : (steal0 + probe - 1) % DAG_QUEUES;
@@ -2203,6 +2389,9 @@ inline void dag_build_pool(DagPlan& plan)
         std::vector<unsigned int> last_part(plan.n_ctrs + 1, DAG_POOL_NONE);      // per arrival counter: its last part's position
         for (unsigned int t = lo; t < hi; ++t)
             if ((plan.tasks[t].type & DAG_TYPE_MASK) == DAG_PART) {
+                // a chained part adds its predecessor's running sum at the END of its own update: it may start while the
+                // predecessor still runs -- but only once the predecessor has been TAKEN (dep[] of a pool entry)
+                if ((plan.tasks[t].type & DAG_CHAIN) && plan.tasks[t].S > 0) plan.dep[pos] = last_part[plan.tasks[t].ctr];
                 last_part[plan.tasks[t].ctr] = pos;        // (a chain's parts are in list order: the last one wins)
                 plan.order[pos++] = t;
             }
@@ -2370,7 +2559,9 @@ inline DagPlan dag_build_tasks(const std::vector<int>& Ps, int workers, int sche
     }
     plan.queues.first[DAG_QUEUES] = (unsigned int)plan.tasks.size();
     plan.queues.follow_first = (unsigned int)dag_follow_first_row();
+#ifdef PSOAP_POOL
     if (scheme >= 1) dag_build_pool(plan);
+#endif
     return plan;
 }
 

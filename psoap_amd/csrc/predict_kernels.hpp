@@ -259,6 +259,7 @@ struct PredictWs {
     Grow<MatAcc> Acc;
     Grow<unsigned char> Dag;
     Grow<DagTask> Tasks;
+    Grow<unsigned int> Order, Dep;   // ready-only hand-out (DagPool)
     Grow<DagMat> Mat;
     Grow<double, true> hSmall;   // pinned: colx / m0 staging, mu
     // task list cache
@@ -503,6 +504,12 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
             PR_TRY(hipMemcpy(ws.Tasks, ws.plan.tasks.data(), sizeof(DagTask) * ws.plan.tasks.size(),
                              hipMemcpyHostToDevice));
             PR_TRY(ws.Ws.need((size_t)NB * NB * ((size_t)ws.plan.n_slots + 1)));
+            if (!ws.plan.order.empty()) {
+                PR_TRY(ws.Order.need(ws.plan.order.size()));
+                PR_TRY(ws.Dep.need(ws.plan.dep.size()));
+                PR_TRY(hipMemcpy(ws.Order, ws.plan.order.data(), sizeof(unsigned int) * ws.plan.order.size(), hipMemcpyHostToDevice));
+                PR_TRY(hipMemcpy(ws.Dep, ws.plan.dep.data(), sizeof(unsigned int) * ws.plan.dep.size(), hipMemcpyHostToDevice));
+            }
             ws.plan_P = P;
             ws.plan_Mt = Mt;
             ws.plan_workers = workers;
@@ -511,7 +518,8 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         }
         const DagPlan& plan = ws.plan;
         const size_t arrive_off = sizeof(DagCtl) + sizeof(MatFlags);
-        const size_t dag_bytes = arrive_off + sizeof(int) * ((size_t)plan.n_ctrs + 4);
+        const size_t taken_off = arrive_off + sizeof(int) * ((size_t)plan.n_ctrs + 4);      // the ready-only hand-out's bitmap
+        const size_t dag_bytes = taken_off + sizeof(unsigned int) * ((plan.tasks.size() + 31) / 32 + 1);
         PR_TRY(ws.Colx.need((size_t)c * Rq_pad));
         PR_TRY(ws.Dag.need(dag_bytes));
         PR_TRY(ws.Mat.need(1));
@@ -552,7 +560,14 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
 #define PSOAP_LAUNCH_AUG(CC, LAT, WPE)                                                                            \
     hipLaunchKernelGGL((k_chol_dag<CC, true, LAT, false, WPE>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st,  \
                        ws.Mat.p, ws.Tasks.p, plan.queues, fl_, reinterpret_cast<int*>(ws.Dag.p + arrive_off),        \
-                       ws.Ws.p, ctl_, (unsigned long long*)nullptr, aug, StreamArgs{})
+                       ws.Ws.p, ctl_, (unsigned long long*)nullptr, aug, StreamArgs{}, pool_)
+        DagPool pool_{};
+        if (!plan.order.empty()) {
+            pool_.order = ws.Order.p;
+            pool_.dep = ws.Dep.p;
+            pool_.taken = reinterpret_cast<unsigned int*>(ws.Dag.p + taken_off);
+            memcpy(pool_.n_main, plan.n_main, sizeof pool_.n_main);
+        }
         const bool lat = plan.scheme >= 1;
         // (at most one workgroup per compute unit: the kernels compiled for one wave per SIMD, as in psoap_gp.hip: eval_dag)
         const bool wide = lat && ws.n_cus > 0 && grid <= ws.n_cus && !(getenv("PSOAP_DAG_WIDE") && getenv("PSOAP_DAG_WIDE")[0] == '0');

@@ -435,10 +435,10 @@ struct StreamState {
     long long launches = 0;
     double idle_ms = 20.0;
 };
-// Workgroup slots a resident launch leaves FREE (psoap_chunk_set_stream_reserve): a kernel of another stream -- the RCCL
-// all_gather of the walker lnprobs and its staging copies, psoap_amd/ensemble.py -- gets compute units only where the
-// resident grid does not hold every register file; with `reserve` of the 2 x CUs slots unoccupied it runs BESIDE the
-// launch instead of behind it.  The lanes' task list does not depend on it (results stay bit-identical).
+// (Round 5 measured a resident launch that leaves workgroup slots FREE for kernels of other streams -- the RCCL all_gather
+// of the walker lnprobs and its staging copies: 0, 4 or 8 of the 512 slots unoccupied, the gather per half-ensemble still
+// waits for the launch to leave, 90.6-93.2 ms per step against 37.9 without a collective (profiles/r5_gather_beside_stream.txt).
+// Device collectives and a resident launch do not mix: several ranks use the launch-per-step path, or gather on the host.)
 
 struct psoap_group;
 struct psoap_chunk {
@@ -472,6 +472,10 @@ struct psoap_chunk {
     unsigned int plan_tasks = 0, plan_ctrs = 0, plan_slots = 0;
     DagQueues plan_queues{};
     DagTask* dTasks = nullptr;
+    unsigned int* dOrder = nullptr;   // ready-only hand-out (DagPool): order[] and dep[], tasks_cap entries each
+    unsigned int* dDep = nullptr;
+    unsigned int plan_n_main[DAG_QUEUES] = {};
+    bool plan_pool = false;
     size_t tasks_cap = 0;
     double* dWs = nullptr;   // split-K partial tiles, plan_slots x 128 x 128
     size_t ws_cap = 0;
@@ -510,7 +514,6 @@ struct psoap_chunk {
     psoap::PredictWs* pws = nullptr;
     // streamed evaluation (psoap_stream_*)
     StreamState stream;
-    int stream_reserve = 0;      // psoap_chunk_set_stream_reserve
     bool dev_locked = false;     // this handle holds a reference on the device's inter-process lock (device_lock_acquire)
     int last_path = 1;           // what the evaluation in flight runs on: 1 the persistent kernel, 0 the staged path
     struct psoap_group* last_group = nullptr;   // the group launch that evaluation belongs to (nullptr: the handle's own)
@@ -647,7 +650,9 @@ static int chunk_alloc(psoap_chunk* h, const double* fl, const double* sigma)
         HIP_TRY(hipEventCreateWithFlags(&sl.evEval, hipEventDisableTiming));
     }
     h->arrive_off = sizeof(DagCtl) + sizeof(MatFlags) * nb;
-    h->arrive_cap = nb * (size_t)h->P * (h->P + 1) / 2 + 16;
+    // (arrival counters, and behind them the `taken` bitmap of the ready-only hand-out: one bit per task, at most 9 parts
+    // per tile + the early diagonal parts)
+    h->arrive_cap = nb * (size_t)h->P * (h->P + 1) / 2 + 16 + (9 * nb * (size_t)h->P * (h->P + 1) / 2 + 1024) / 32 + 8;
     HIP_TRY(hipMalloc(&h->dDag, h->arrive_off + sizeof(int) * h->arrive_cap));
     HIP_TRY(hipHostMalloc(&h->hDagErr, 64));
     h->hDagErr[0] = 0;
@@ -719,7 +724,7 @@ extern "C" int psoap_chunk_destroy(psoap_chunk* h)
     (void)hipFree(h->dK); (void)hipFree(h->dWt); (void)hipFree(h->dR); (void)hipFree(h->dAcc);
     (void)hipFree(h->dVel); (void)hipFree(h->dOut);
     (void)hipFree(h->dDag); (void)hipHostFree(h->hDagErr); (void)hipFree(h->dTlog);
-    (void)hipFree(h->dTasks); (void)hipFree(h->dWs);
+    (void)hipFree(h->dTasks); (void)hipFree(h->dWs); (void)hipFree(h->dOrder); (void)hipFree(h->dDep);
     (void)hipFree(h->dDates); (void)hipFree(h->dPorb); (void)hipHostFree(h->hPorb);
     (void)hipHostFree(h->hLwl); (void)hipHostFree(h->hGp); (void)hipHostFree(h->hVel); (void)hipHostFree(h->hOut);
     for (BatchSlot& sl : h->slot) {
@@ -878,6 +883,34 @@ extern "C" int psoap_dag_plan_multi(int B, const int* Ps, int workers, void* out
     return 0;
 }
 
+// Pure host function: the task list of a batch (Ps[b] block rows each; Mt appended column tiles and an Ms x Ms Schur block
+// for a single matrix: predict) together with the two hand-out orders of the ready-only scheme (DagPool, dag_kernel.hpp):
+// order[] (per queue the finals' task indices, then the parts'), dep[] (per final: the position in order[] of the last
+// part of its chain, 0xffffffff without one), n_main[8].  Empty orders (*has_pool = 0) for the throughput scheme.
+extern "C" int psoap_dag_plan_pool(int B, const int* Ps, int workers, int Mt, int Ms, int scheme, void* tasks_out,
+                                   long long max_tasks, long long* n_tasks, unsigned int* order_out, unsigned int* dep_out,
+                                   unsigned int* n_main_out, unsigned int* queue_first, int* has_pool, long long* n_ctrs)
+{
+    if (B < 1 || !Ps || workers < 1 || !n_tasks || Mt < 0 || Ms < 0 || Ms > Mt || (Mt > 0 && B != 1))
+        FAIL("psoap_dag_plan_pool: bad arguments");
+    for (int b = 0; b < B; ++b)
+        if (Ps[b] < 1 || Ps[b] + Mt > 255) FAIL("psoap_dag_plan_pool: 1 <= P (+ Mt) <= 255");
+    DagPlan plan = dag_build_tasks(std::vector<int>(Ps, Ps + B), workers, scheme, Mt, Ms);
+    if (plan.scheme >= 1 && plan.order.empty()) dag_build_pool(plan);      // (the shipped build does not use the orders)
+    *n_tasks = (long long)plan.tasks.size();
+    if (has_pool) *has_pool = plan.order.empty() ? 0 : 1;
+    if (n_ctrs) *n_ctrs = plan.n_ctrs;
+    if (queue_first) memcpy(queue_first, plan.queues.first, sizeof plan.queues.first);
+    if (n_main_out) memcpy(n_main_out, plan.n_main, sizeof plan.n_main);
+    const long long n = max_tasks < *n_tasks ? max_tasks : *n_tasks;
+    if (tasks_out) memcpy(tasks_out, plan.tasks.data(), sizeof(DagTask) * n);
+    if (!plan.order.empty()) {
+        if (order_out) memcpy(order_out, plan.order.data(), sizeof(unsigned int) * n);
+        if (dep_out) memcpy(dep_out, plan.dep.data(), sizeof(unsigned int) * n);
+    }
+    return 0;
+}
+
 // Pure host function: how many persistent workgroups a batch of B matrices (Ps[b] block rows each, Mt appended
 // column tiles) gets on a device with `compute_units` CUs that admits `max_workers` of them (dag_pick_workers).
 extern "C" int psoap_dag_pick_workers(int B, const int* Ps, int Mt, int compute_units, int max_workers, int* workers)
@@ -908,14 +941,6 @@ extern "C" int psoap_chunk_set_mode(psoap_chunk* h, int mode)
 {
     if (!h || mode < 0 || mode > 1) FAIL("psoap_chunk_set_mode: mode must be 0 (staged) or 1 (dag)");
     h->mode = mode;
-    return 0;
-}
-
-extern "C" int psoap_chunk_set_stream_reserve(psoap_chunk* h, int workgroups)
-{
-    if (!h || workgroups < 0 || workgroups > 64) FAIL("psoap_chunk_set_stream_reserve: 0 <= workgroups <= 64");
-    if (h->stream.open) FAIL("psoap_chunk_set_stream_reserve: set it before psoap_stream_open");
-    h->stream_reserve = workgroups;
     return 0;
 }
 
@@ -1201,13 +1226,25 @@ static int dag_prepare(psoap_chunk* h)
     // (PSOAP_FIXED_PLAN=1: the task structure of a stream lane for every matrix, whatever the batch -- dag_fixed_plan)
     DagPlan plan = dag_build_tasks(Ps, workers, env_scheme ? atoi(env_scheme) : -1, 0, 0,
                                    dag_fixed_plan() ? dag_nominal_share(h->dag_grid - 1) : 0);
-    if (plan.n_ctrs > h->arrive_cap) FAIL("internal: arrival counter capacity exceeded");
+    if ((size_t)plan.n_ctrs + 4 + (plan.tasks.size() + 31) / 32 + 1 > h->arrive_cap)
+        FAIL("internal: arrival counter capacity exceeded");
     if (plan.tasks.size() > h->tasks_cap) {
         if (h->dTasks) HIP_TRY(hipFree(h->dTasks));
+        if (h->dOrder) HIP_TRY(hipFree(h->dOrder));
+        if (h->dDep) HIP_TRY(hipFree(h->dDep));
         h->dTasks = nullptr;
+        h->dOrder = h->dDep = nullptr;
         h->tasks_cap = 0;
         HIP_TRY(hipMalloc(&h->dTasks, sizeof(DagTask) * plan.tasks.size()));
+        HIP_TRY(hipMalloc(&h->dOrder, sizeof(unsigned int) * plan.tasks.size()));
+        HIP_TRY(hipMalloc(&h->dDep, sizeof(unsigned int) * plan.tasks.size()));
         h->tasks_cap = plan.tasks.size();
+    }
+    h->plan_pool = !plan.order.empty();
+    if (h->plan_pool) {
+        HIP_TRY(hipMemcpy(h->dOrder, plan.order.data(), sizeof(unsigned int) * plan.order.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->dDep, plan.dep.data(), sizeof(unsigned int) * plan.dep.size(), hipMemcpyHostToDevice));
+        memcpy(h->plan_n_main, plan.n_main, sizeof h->plan_n_main);
     }
     if (plan.n_slots > h->ws_cap) {
         if (h->dWs) HIP_TRY(hipFree(h->dWs));
@@ -1241,7 +1278,9 @@ static int eval_dag(psoap_chunk* h)
     hipLaunchKernelGGL(k_init_rhs, dim3((h->Npad + 255) / 256, B), dim3(256), 0, s, h->dR, h->Npad, N, h->dFl,
                        sl.mu, h->dAcc);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(h->dDag, 0, h->arrive_off + sizeof(int) * ((size_t)h->plan_ctrs + 4), s));
+    // (flags, arrival counters and -- behind them -- the taken bitmap of the ready-only hand-out: one memset)
+    const size_t taken_off = h->arrive_off + sizeof(int) * ((size_t)h->plan_ctrs + 4);
+    HIP_TRY(hipMemsetAsync(h->dDag, 0, taken_off + sizeof(unsigned int) * (((size_t)h->plan_tasks + 31) / 32 + 1), s));
     if (prof_end(h, s)) return 1;
     const long long tasks = h->plan_tasks;
     const int grid = (int)(tasks < h->plan_workers ? tasks : h->plan_workers);
@@ -1255,7 +1294,14 @@ static int eval_dag(psoap_chunk* h)
 #define PSOAP_LAUNCH_DAG(CC, LAT, WPE)                                                                           \
     hipLaunchKernelGGL((k_chol_dag<CC, false, LAT, false, WPE>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, \
                        sl.dMats, h->dTasks, h->plan_queues, fl_, reinterpret_cast<int*>(h->dDag + h->arrive_off),   \
-                       h->dWs, ctl_, h->dTlog, DagAug{P, 0, 0, nullptr}, StreamArgs{})
+                       h->dWs, ctl_, h->dTlog, DagAug{P, 0, 0, nullptr}, StreamArgs{}, pool_)
+        DagPool pool_{};
+        if (h->plan_pool) {
+            pool_.order = h->dOrder;
+            pool_.dep = h->dDep;
+            pool_.taken = reinterpret_cast<unsigned int*>(h->dDag + taken_off);
+            memcpy(pool_.n_main, h->plan_n_main, sizeof pool_.n_main);
+        }
         const bool lat = h->plan_scheme >= 1;
         // at most one workgroup per compute unit (single evaluations: dag_pick_workers): the kernels compiled for one wave
         // per SIMD -- 512 registers per lane, nothing of the chain phases in scratch memory
@@ -1427,6 +1473,11 @@ struct psoap_group {
     DagMat* dMats = nullptr;
     size_t mats_cap = 0;
     DagTask* dTasks = nullptr;
+    unsigned int* dOrder = nullptr;   // DagPool: order[], dep[] (tasks_cap entries each)
+    unsigned int* dDep = nullptr;
+    unsigned int n_main[DAG_QUEUES] = {};
+    bool pool = false;
+    size_t taken_off = 0;
     size_t tasks_cap = 0;
     double* dWs = nullptr;
     size_t ws_cap = 0;
@@ -1474,6 +1525,7 @@ extern "C" int psoap_group_destroy(psoap_group* g)
     (void)hipSetDevice(g->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(g->dDag); (void)hipFree(g->dMats); (void)hipFree(g->dTasks); (void)hipFree(g->dWs);
+    (void)hipFree(g->dOrder); (void)hipFree(g->dDep);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     if (g->evDone) (void)hipEventDestroy(g->evDone);
     delete g;
@@ -1551,9 +1603,21 @@ static int group_eval_locked(psoap_group* g, bool promote)
         }
         if (plan.tasks.size() > g->tasks_cap) {
             if (g->dTasks) HIP_TRY(hipFree(g->dTasks));
+            if (g->dOrder) HIP_TRY(hipFree(g->dOrder));
+            if (g->dDep) HIP_TRY(hipFree(g->dDep));
             g->dTasks = nullptr;
+            g->dOrder = g->dDep = nullptr;
+            g->tasks_cap = 0;
             HIP_TRY(hipMalloc(&g->dTasks, sizeof(DagTask) * plan.tasks.size()));
+            HIP_TRY(hipMalloc(&g->dOrder, sizeof(unsigned int) * plan.tasks.size()));
+            HIP_TRY(hipMalloc(&g->dDep, sizeof(unsigned int) * plan.tasks.size()));
             g->tasks_cap = plan.tasks.size();
+        }
+        g->pool = !plan.order.empty();
+        if (g->pool) {
+            HIP_TRY(hipMemcpy(g->dOrder, plan.order.data(), sizeof(unsigned int) * plan.order.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(g->dDep, plan.dep.data(), sizeof(unsigned int) * plan.dep.size(), hipMemcpyHostToDevice));
+            memcpy(g->n_main, plan.n_main, sizeof g->n_main);
         }
         if ((size_t)plan.n_slots + 1 > g->ws_cap) {
             if (g->dWs) HIP_TRY(hipFree(g->dWs));
@@ -1562,7 +1626,8 @@ static int group_eval_locked(psoap_group* g, bool promote)
             g->ws_cap = (size_t)plan.n_slots + 1;
         }
         g->arrive_off = sizeof(DagCtl) + sizeof(MatFlags) * (size_t)total;
-        g->dag_bytes = g->arrive_off + sizeof(int) * ((size_t)plan.n_ctrs + 4);
+        g->taken_off = g->arrive_off + sizeof(int) * ((size_t)plan.n_ctrs + 4);
+        g->dag_bytes = g->taken_off + sizeof(unsigned int) * ((plan.tasks.size() + 31) / 32 + 1);
         if (g->dag_bytes > g->dag_cap) {
             if (g->dDag) HIP_TRY(hipFree(g->dDag));
             g->dDag = nullptr;
@@ -1610,7 +1675,14 @@ static int group_eval_locked(psoap_group* g, bool promote)
 #define PSOAP_LAUNCH_GROUP(CC, LAT, WPE)                                                                        \
     hipLaunchKernelGGL((k_chol_dag<CC, false, LAT, false, WPE>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, \
                        g->dMats, g->dTasks, g->queues, fl_, reinterpret_cast<int*>(g->dDag + g->arrive_off),        \
-                       g->dWs, ctl_, (unsigned long long*)nullptr, DagAug{0, 0, 0, nullptr}, StreamArgs{})
+                       g->dWs, ctl_, (unsigned long long*)nullptr, DagAug{0, 0, 0, nullptr}, StreamArgs{}, pool_)
+        DagPool pool_{};
+        if (g->pool) {
+            pool_.order = g->dOrder;
+            pool_.dep = g->dDep;
+            pool_.taken = reinterpret_cast<unsigned int*>(g->dDag + g->taken_off);
+            memcpy(pool_.n_main, g->n_main, sizeof pool_.n_main);
+        }
         const bool lat = g->scheme >= 1;
         const bool wide = lat && grid <= g->hs[0]->n_cus && !(getenv("PSOAP_DAG_WIDE") && getenv("PSOAP_DAG_WIDE")[0] == '0');
         if (C == 1) { if (wide) PSOAP_LAUNCH_GROUP(1, true, 1); else if (lat) PSOAP_LAUNCH_GROUP(1, true, 2); else PSOAP_LAUNCH_GROUP(1, false, 2); }
@@ -1687,11 +1759,11 @@ static int stream_launch(psoap_chunk* h)
     a.tlog_cap = st.tlog_cap;
     MatFlags* fl_ = reinterpret_cast<MatFlags*>(st.dDag + sizeof(DagCtl));
     DagCtl* ctl_ = reinterpret_cast<DagCtl*>(st.dDag);
-    const int grid = h->dag_grid - h->stream_reserve > 2 ? h->dag_grid - h->stream_reserve : 2;
+    const int grid = h->dag_grid;
 #define PSOAP_LAUNCH_STREAM(CC, LAT)                                                                              \
     hipLaunchKernelGGL((k_chol_dag<CC, false, LAT, true>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s,      \
                        st.dMats, st.dTasks, st.queues, fl_, reinterpret_cast<int*>(st.dDag + st.arrive_off), st.dWs, \
-                       ctl_, st.dTlog, DagAug{h->P, 0, 0, nullptr}, a)
+                       ctl_, st.dTlog, DagAug{h->P, 0, 0, nullptr}, a, DagPool{})
     const bool lat = st.scheme >= 1;
     if (st.C == 1) { if (lat) PSOAP_LAUNCH_STREAM(1, true); else PSOAP_LAUNCH_STREAM(1, false); }
     else if (st.C == 2) { if (lat) PSOAP_LAUNCH_STREAM(2, true); else PSOAP_LAUNCH_STREAM(2, false); }

@@ -46,15 +46,31 @@ class _GatherBuffers:
 
 
 _buffers: dict = {}
+_host_group = {"pg": None}
+
+
+def host_group():
+    """A gloo process group beside the default (RCCL) one, created on first use -- collectively: every rank reaches its
+    first host-side gather at the same point.  What a gather uses WHILE a resident stream launch holds the device: the
+    lnprobs are in pinned host memory already, and a device collective would wait for the launch to leave (measured:
+    90.6 ms per 32-walker step against 37.9, whatever number of workgroup slots the launch leaves free --
+    profiles/r5_gather_beside_stream.txt)."""
+    dist = _dist()
+    if _host_group["pg"] is None:
+        _host_group["pg"] = dist.new_group(backend="gloo")
+    return _host_group["pg"]
 
 
 def gather_chunk_lnprobs(local: np.ndarray, n_chunks: int, world: int, rank: int,
-                         device_index: int | None = None, force_collective: bool = False) -> np.ndarray:
+                         device_index: int | None = None, force_collective: bool = False,
+                         on_host: bool = False) -> np.ndarray:
     """all_gather the (n_local, B) block of every rank into the (n_chunks, B) table.
 
     ``local[i]`` is the lnprob vector of chunk ``owned_chunks(...)[i]``.  Ranks with fewer
     chunks are padded so the collective has equal counts.  ``force_collective``: go through the
     process group even when ``world == 1`` (a one-rank RCCL communicator exercises the same code).
+    ``on_host``: with an RCCL default group, exchange through the gloo side group instead (``host_group``) -- for gathers
+    issued while a resident stream launch is on the device.
     """
     local = np.ascontiguousarray(local, dtype=np.float64)
     if local.ndim != 2:
@@ -68,10 +84,11 @@ def gather_chunk_lnprobs(local: np.ndarray, n_chunks: int, world: int, rank: int
     import torch
     dist = _dist()
     per = -(-n_chunks // world)
-    use_cuda = dist.get_backend() == "nccl"
+    use_cuda = dist.get_backend() == "nccl" and not on_host
+    group = host_group() if (on_host and dist.get_backend() == "nccl") else None
     dev = torch.device("cuda", device_index if device_index is not None else torch.cuda.current_device()) \
         if use_cuda else torch.device("cpu")
-    key = (per, B, world, dist.get_backend(), str(dev))
+    key = (per, B, world, dist.get_backend() if group is None else "gloo-side", str(dev))
     buf = _buffers.get(key)
     if buf is None:
         buf = _buffers[key] = _GatherBuffers(per, B, world, dev)
@@ -86,7 +103,7 @@ def gather_chunk_lnprobs(local: np.ndarray, n_chunks: int, world: int, rank: int
     else:
         buf.send.zero_()
         buf.send[:len(mine)] = torch.from_numpy(local)
-        dist.all_gather_into_tensor(buf.recv, buf.send)
+        dist.all_gather_into_tensor(buf.recv, buf.send, group=group)
         table = buf.recv.numpy().reshape(world, per, B)
     out = np.empty((n_chunks, B))
     for k in range(n_chunks):
@@ -95,8 +112,9 @@ def gather_chunk_lnprobs(local: np.ndarray, n_chunks: int, world: int, rank: int
 
 
 def release_gather_buffers():
-    """drop the cached tensors (before ``destroy_process_group``)"""
+    """drop the cached tensors and the host-side group (before ``destroy_process_group``)"""
     _buffers.clear()
+    _host_group["pg"] = None
 
 
 def sum_over_chunks(table: np.ndarray) -> np.ndarray:

@@ -146,17 +146,10 @@ class Posterior:
         device (each takes every compute unit), so a rank with several chunks keeps the launch-per-step group path."""
         return len(self.mine) == 1 and all(hasattr(w, "stream_submit") for w in self.workers.values())
 
-    def stream_open(self, scheme: int = -1, reserve: int | None = None):
-        """``reserve``: workgroup slots the resident launch leaves free for the gather's kernels (default: 8 when the
-        gather is a device collective -- several ranks over RCCL -- else 0)."""
+    def stream_open(self, scheme: int = -1):
         if not self.can_stream():
             raise RuntimeError("Posterior.stream_open: needs exactly one chunk on this rank (see can_stream)")
-        w = self.workers[self.mine[0]]
-        if reserve is None:
-            reserve = 8 if (self.world > 1 and _collective_on_device()) else 0
-        if reserve and hasattr(w, "handle"):
-            w.handle.set_stream_reserve(reserve)
-        w.stream_open(self.max_batch, scheme)
+        self.workers[self.mine[0]].stream_open(self.max_batch, scheme)
         self._streaming = True
 
     def stream_submit(self, P, group: int = 0):
@@ -177,7 +170,8 @@ class Posterior:
         out = np.full(lnprior.shape[0], -np.inf)
         if tickets is not None:
             block = np.asarray(self.workers[self.mine[0]].stream_fetch(tickets), dtype=np.float64)[None, :]
-            table = gather_chunk_lnprobs(block, self.n_chunks, self.world, self.rank, self.device_index)
+            # (on the host: a device collective would wait for the resident launch to leave -- ensemble.host_group)
+            table = gather_chunk_lnprobs(block, self.n_chunks, self.world, self.rank, self.device_index, on_host=True)
             out[ok] = (sum_over_chunks(table) + lnprior)[ok]
         return out
 
@@ -187,14 +181,6 @@ class Posterior:
             self._streaming = False
 
 
-def _collective_on_device() -> bool:
-    try:
-        import torch.distributed as dist
-        return dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
-    except Exception:
-        return False
-
-
 # Where the resident launch pays (profiles/r4_stream_table.jsonl, r5): from N ~ 5000 on with at least 16 chains; below, the
 # launch-per-step path is 1-5 % ahead.
 STREAM_MIN_N = 5000
@@ -202,9 +188,14 @@ STREAM_MIN_CHAINS = 16
 
 
 def want_stream(post, chunks, n_chains) -> bool:
-    """the automatic rule of ``run(stream=None)``: one chunk per rank, an even number of >= 16 chains, chunks of >= 5000
-    pixels; and only ONE process on each GPU (a resident launch holds the device while it has results outstanding)"""
+    """the automatic rule of ``run(stream=None)``: ONE rank with one chunk, an even number of >= 16 chains, chunks of >= 5000
+    pixels; and only one process on the GPU (a resident launch holds the device while it has results outstanding)"""
     if not post.can_stream() or n_chains < STREAM_MIN_CHAINS or n_chains % 2:
+        return False
+    if post.world > 1:
+        # every half-ensemble waits for its gather before it is resubmitted: ~2 ms on the host with half the device idle
+        # (a device collective waits for the resident launch to leave altogether) -- more than the resident launch gains
+        # (profiles/r5_gather_beside_stream.txt); several ranks keep the launch-per-step path unless told otherwise
         return False
     if not isinstance(post.device_lock, _NoLock):
         return False

@@ -400,3 +400,225 @@ def test_lane_plan_of_a_stream(P, scheme):
     else:
         # schemes 1, 2 (lists in order of readiness, short tasks): the lanes are served ticket by ticket in turn
         assert list(ends) == list(range(len(tasks)))
+
+
+# ---------------------------------------------------------------------------------------------- ready-only hand-out (round 5)
+def plan_pool(Ps, workers, Mt=0, Ms=0, scheme=-1):
+    from psoap_amd import _lib
+    L = _lib.load()
+    B = len(Ps)
+    arr = (ctypes.c_int * B)(*Ps)
+    n, ctrs = ctypes.c_longlong(), ctypes.c_longlong()
+    first, n_main = (ctypes.c_uint32 * 9)(), (ctypes.c_uint32 * 8)()
+    has = ctypes.c_int(0)
+    assert L.psoap_dag_plan_pool(B, arr, workers, Mt, Ms, scheme, None, 0, ctypes.byref(n), None, None, n_main, first,
+                                 ctypes.byref(has), ctypes.byref(ctrs)) == 0
+    tasks = np.zeros(n.value, dtype=TASK)
+    order = np.zeros(n.value, dtype=np.uint32)
+    dep = np.zeros(n.value, dtype=np.uint32)
+    assert L.psoap_dag_plan_pool(B, arr, workers, Mt, Ms, scheme, tasks.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n),
+                                 order.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                 dep.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), n_main, first, ctypes.byref(has),
+                                 ctypes.byref(ctrs)) == 0
+    return tasks, order, dep, list(n_main), list(first), bool(has.value), ctrs.value
+
+
+def _simulate_pool(tasks, order, dep, n_main, first, Ps, Pt, workers, rng, window=64):
+    """The hand-out of dag_kernel.hpp: pool_take played through with `workers` workgroups in rounds.  A final that has been
+    handed out completes once everything it waits for is complete (its chain, the finals of the block rows its panels read,
+    the diagonal final of its own row); a part is only ever TAKEN when it is ready and completes in the next round.
+    Returns the number of rounds; raises when a round passes with work left, nothing running to completion and nothing
+    taken (a deadlock of the hand-out)."""
+    NONE = 0xFFFFFFFF
+    ty = tasks["type"] & TYPE_MASK
+    n = len(tasks)
+    done = np.zeros(n, dtype=bool)
+    taken = np.zeros(n, dtype=bool)              # by position in order[]
+    nxt = [0] * 8
+    lo = [0] * 8
+    row_finals = {}                              # (b, q) -> task ids of the row's finals (not SCHUR)
+    diag_of = {}
+    parts_of = {}                                # ctr -> part task ids
+    for t in range(n):
+        b, q = int(tasks["b"][t]), int(tasks["q"][t])
+        if ty[t] == PART:
+            parts_of.setdefault(int(tasks["ctr"][t]), []).append(t)
+        else:
+            if q < Ps[b]:
+                row_finals.setdefault((b, q), []).append(t)
+            if ty[t] == DIAG:
+                diag_of[(b, q)] = t
+    rows_done = lambda b, m: all(done[x] for x in row_finals[(b, m)])      # noqa: E731
+
+    pos_of = {int(order[p]): p for p in range(n)}
+
+    def part_ready(t):
+        b = int(tasks["b"][t])
+        if not all(rows_done(b, m) for m in range(int(tasks["pb"][t]))):
+            return False
+        if (tasks["type"][t] & CHAIN) and tasks["S"][t] > 0:
+            return bool(taken[int(dep[pos_of[t]])])         # its predecessor has been handed out
+        return True
+
+    def part_can_finish(t):
+        if (tasks["type"][t] & CHAIN) and tasks["S"][t] > 0:
+            return sum(done[x] for x in parts_of[int(tasks["ctr"][t])]) >= int(tasks["S"][t])
+        return True
+
+    def final_can_finish(t):
+        b, q = int(tasks["b"][t]), int(tasks["q"][t])
+        if tasks["S"][t] > 1 and not all(done[x] for x in parts_of[int(tasks["ctr"][t])]):
+            return False
+        if not all(rows_done(b, m) for m in range(min(int(tasks["pb"][t]), Ps[b]))):
+            # (a diagonal final of the latency schemes reads only the tile right of the diagonal above: weaker than this)
+            if not (ty[t] == DIAG and all(rows_done(b, m) for m in range(int(tasks["pb"][t]) - 1)) and
+                    done[[x for x in row_finals[(b, q - 1)] if tasks["j"][x] == q][0]]):
+                return False
+        if ty[t] == OFF and not (tasks["type"][t] & NOSOLVE and not tasks["type"][t] & WAITNEXT) and q < Ps[b]:
+            d = diag_of[(b, q)]
+            # (a strip solve needs its row's factorisation; in the following scheme it FOLLOWS it: the diagonal task must
+            # have been handed out, and -- scheme 1 -- the fused diagonal task in turn waits for the update-only task)
+            if not (done[d] or running_set.__contains__(d)):
+                return False
+        return True
+
+    running = []                                 # task ids
+    running_set = set()
+    pendings = []                                # finals drawn ahead of their turn: (position in order[]) held by a workgroup
+    rounds = 0
+    burst = max(2, workers // 8)                 # how many workgroups see the same head final before its ticket counter moves
+
+    def runnable(pos):
+        d = int(dep[pos])
+        return d == NONE or taken[d]
+
+    while not done.all():
+        rounds += 1
+        progressed = False
+        still = []
+        for t in running:
+            if (ty[t] == PART and part_can_finish(t)) or (ty[t] != PART and final_can_finish(t)):
+                done[t] = True
+                running_set.discard(t)
+                progressed = True
+            else:
+                still.append(t)
+        running = still
+        # workgroups that hold a final ahead of its turn: run it once its chain's last part has been taken
+        keep = []
+        for pos in pendings:
+            if runnable(pos):
+                running.append(int(order[pos]))
+                running_set.add(int(order[pos]))
+                progressed = True
+            else:
+                keep.append(pos)
+        pendings = keep
+        idle = workers - len(running) - len(pendings)
+        helpers = len(pendings)                  # ... and take ready parts meanwhile (one each per round)
+        queues = list(range(8))
+        seen_head = {}
+        for w in range(idle + helpers):
+            helper = w >= idle
+            got = None
+            rng.shuffle(queues)
+            for g in queues:
+                f0, n_all = first[g], first[g + 1] - first[g]
+                if n_all == 0:
+                    continue
+                if not helper:
+                    # the head as this workgroup sees it: up to `burst` workgroups read the counter before any of their
+                    # fetch-adds lands, so all of them draw when the head may be handed out -- the overshoot of pool_take
+                    m_seen = seen_head.setdefault(g, [nxt[g], 0])
+                    if m_seen[1] >= burst:
+                        m_seen[0], m_seen[1] = nxt[g], 0
+                    m_seen[1] += 1
+                    m = m_seen[0]
+                    if m < n_main[g] and runnable(f0 + m):
+                        tk = nxt[g]
+                        nxt[g] += 1
+                        if tk < n_main[g]:
+                            if runnable(f0 + tk):
+                                got = int(order[f0 + tk])
+                            else:
+                                pendings.append(f0 + tk)
+                                got = -1
+                            break
+                p0, p1 = f0 + n_main[g], f0 + n_all
+                while lo[g] < p1 - p0 and taken[p0 + lo[g]]:
+                    lo[g] += 1
+                cur = p0 + lo[g]
+                base = cur & ~31
+                for pos in range(max(base, cur), min(base + window, p1)):
+                    if not taken[pos] and part_ready(int(order[pos])):
+                        taken[pos] = True
+                        got = int(order[pos])
+                        break
+                if got is not None:
+                    break
+            if got is None:
+                continue
+            progressed = True
+            if got >= 0:
+                running.append(got)
+                running_set.add(got)
+        assert progressed, (f"hand-out deadlock after {rounds} rounds: {int((~done).sum())} tasks left, running {running[:8]}, "
+                            f"held {pendings[:8]}")
+        assert rounds < 100000
+    assert not pendings
+    return rounds
+
+
+@pytest.mark.parametrize("Ps,workers,Mt,Ms,scheme", [([47], 256, 0, 0, -1), ([47], 256, 0, 0, 1), ([16], 256, 0, 0, -1),
+                                                     ([64], 256, 0, 0, -1), ([1], 256, 0, 0, -1), ([2], 256, 0, 0, 2), ([3], 4, 0, 0, 2),
+                                                     ([47] * 8, 512, 0, 0, -1), ([16] * 24, 512, 0, 0, -1), ([47] * 16, 512, 0, 0, 1),
+                                                     ([16, 13, 11, 16, 20, 7], 512, 0, 0, -1), ([47], 1, 0, 0, -1), ([20], 3, 0, 0, 1),
+                                                     ([64], 512, 24, 24, -1), ([9], 256, 4, 4, 1), ([16], 8, 6, 3, 2)])
+def test_ready_only_hand_out_is_complete_and_cannot_deadlock(Ps, workers, Mt, Ms, scheme):
+    """DagPool (dag_kernel.hpp): finals in list order -- a final with a chain only once the chain's last part is taken --
+    and parts taken only when ready.  The orders cover every task once, a final's `dep` is its chain's last part, a chain's
+    parts appear in chain order, and the hand-out played through with many, few and ONE workgroup (random queue order)
+    always completes."""
+    tasks, order, dep, n_main, first, has, n_ctrs = plan_pool(Ps, workers, Mt, Ms, scheme)
+    assert has, "the latency schemes build the hand-out orders"
+    ty = tasks["type"] & TYPE_MASK
+    n = len(tasks)
+    assert sorted(order.tolist()) == list(range(n))
+    NONE = 0xFFFFFFFF
+    for g in range(8):
+        f0, f1 = first[g], first[g + 1]
+        main = order[f0:f0 + n_main[g]]
+        pool = order[f0 + n_main[g]:f1]
+        assert np.all(ty[main] != PART) and np.all(ty[pool] == PART)
+        assert np.all(np.diff(main.astype(np.int64)) > 0) and np.all(np.diff(pool.astype(np.int64)) > 0)     # list order kept
+        assert np.all((main >= f0) & (main < f1)) and np.all((pool >= f0) & (pool < f1))
+        for m in range(f0, f0 + n_main[g]):
+            t = int(order[m])
+            if tasks["S"][t] > 1:
+                d = int(dep[m])
+                assert f0 + n_main[g] <= d < f1
+                last = int(order[d])
+                assert ty[last] == PART and tasks["ctr"][last] == tasks["ctr"][t]
+                mine = [int(x) for x in pool if tasks["ctr"][x] == tasks["ctr"][t]]
+                assert mine[-1] == last and len(mine) == tasks["S"][t] - 1
+                if tasks["type"][t] & CHAIN:
+                    assert [int(tasks["S"][x]) for x in mine] == list(range(len(mine)))
+            else:
+                assert int(dep[m]) == NONE
+        # a chained part's dep: the position of its predecessor in the chain
+        for p in range(f0 + n_main[g], f1):
+            t = int(order[p])
+            if (tasks["type"][t] & CHAIN) and tasks["S"][t] > 0:
+                pr = int(order[int(dep[p])])
+                assert int(dep[p]) < p and ty[pr] == PART and tasks["ctr"][pr] == tasks["ctr"][t] and tasks["S"][pr] == tasks["S"][t] - 1
+            else:
+                assert int(dep[p]) == NONE
+    Pt = [p + Mt for p in Ps]
+    rng = np.random.default_rng(5)
+    for w in sorted({workers, 1, 7}):
+        _simulate_pool(tasks, order, dep, n_main, first, Ps, Pt, w, rng)
+
+
+def test_throughput_scheme_has_no_hand_out_orders():
+    _, _, _, n_main, _, has, _ = plan_pool([47] * 32, 512)
+    assert not has and n_main == [0] * 8

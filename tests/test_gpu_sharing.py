@@ -118,7 +118,7 @@ def test_staged_policy_meets_the_goldens(tmp_path):
     through the drop-in calls, lnlike and predict."""
     env = dict(os.environ, PSOAP_SHARE_POLICY="staged", PSOAP_LOCK_DIR=str(tmp_path / "locks"))
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x",
-                          "-k", "lnlike_golden or edge_sizes or batch_matches or predict_golden or predict_edge or walker_batch",
+                          "-k", "lnlike_golden or edge_sizes or predict_golden or predict_edge or walker_batch or conventions",
                           "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     assert " passed" in res.stdout
@@ -181,9 +181,10 @@ with ChunkHandle(ch.fl, ch.sigma, device=0) as h:
 
 @pytest.mark.parametrize("workers,lock", [(12, 2), (6, 0)])
 def test_many_worker_processes_never_get_a_wrong_value(workers, lock):
-    """12 forked workers with the device lock (more than the eight process contexts the device keeps mapped: its scheduler
-    then suspends and moves running workgroups -- 3-8 silently wrong lnprobs in 24,000 before round 5), and 6 WITHOUT the
-    lock (persistent launches of several processes would starve each other: the library sends them down the staged path):
+    """12 forked workers with the device lock on (more than the eight process contexts the device keeps mapped: its scheduler
+    then suspends and moves running workgroups -- 3-8 silently wrong lnprobs in 24,000 before round 5; the library sends them
+    down the staged path, without the lock), and 6 WITHOUT the lock (persistent launches of several processes would starve
+    each other: the staged path as well):
     two proposals in turn, every value equal to the worker's first to the parity contract, no time-out, and the library's
     account says what it did."""
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shared_gpu_probe.py"), str(workers), "120", "3", str(lock)],
@@ -191,7 +192,8 @@ def test_many_worker_processes_never_get_a_wrong_value(workers, lock):
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     assert f"WRONG per worker {[0] * workers}" in res.stdout, res.stdout
     acct = json.loads(res.stdout.split("library account (all workers): ")[1].split("; procs seen")[0])
+    # both regimes end on the staged path, without the lock (12 processes are more than PSOAP_SHARE_DAG_MAX; without the lock
+    # two are): only what ran before the other workers had their slots was a persistent launch under the lock
+    assert acct["staged_policy"] >= workers * 100
     if lock == 0:
-        assert acct["staged_policy"] > 0 and acct["lock_acquisitions"] == 0
-    else:
-        assert acct["lock_acquisitions"] >= workers * 120
+        assert acct["lock_acquisitions"] == 0
