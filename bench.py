@@ -756,11 +756,29 @@ def run_extras(args, h, chunk, gps, lwls, dev, mode):
     spipe.close()
     require(close(lnp_s, lnp_batch), "lnprob(p) through the stream vs the batch path")
     # the sampler boundary (8(f) f-2): B Metropolis-Hastings chains in lock-step on that worker
-    mh = MultiChainMHSampler(1e-6 * np.eye(pfit.shape[1]), pfit.shape[1], worker.lnprob_batch, B,
-                             seeds=[7000 + b for b in range(B)])
+    cov_mh = 1e-6 * np.eye(pfit.shape[1])
+    mh = MultiChainMHSampler(cov_mh, pfit.shape[1], worker.lnprob_batch, B, seeds=[7000 + b for b in range(B)])
     t3 = time.perf_counter()
     mh.run_mcmc(pfit, 3)                              # 1 starting + 3 proposal evaluations of B chains
-    ex["mh_sampler_evals_per_s"] = 4 * B / (time.perf_counter() - t3)
+    ex["mh_sampler_lockstep_evals_per_s"] = 4 * B / (time.perf_counter() - t3)
+    # ... and through ONE resident launch (round 5: MultiChainMHSampler.sample_streamed): the chains in two halves, a half's
+    # accept / reject and next proposals drawn while the other half is being factored -- the loop of sample_parallel.py:434-438
+    # as a consumer of the stream.  Same seeds: the chains must be the lock-step sampler's (decisions identical; lnprob to the
+    # parity tolerance -- a lane's plan sums in another order than a batch of 32).
+    n_it = 8
+    worker.stream_open(B)
+    mhs = MultiChainMHSampler(cov_mh, pfit.shape[1], None, B, seeds=[7000 + b for b in range(B)])
+    list(mhs.sample_streamed(pfit, lambda P, g: worker.stream_submit(P), worker.stream_fetch, groups=2, iterations=1))   # warm
+    mhs = MultiChainMHSampler(cov_mh, pfit.shape[1], None, B, seeds=[7000 + b for b in range(B)])
+    t3s = time.perf_counter()
+    list(mhs.sample_streamed(pfit, lambda P, g: worker.stream_submit(P), worker.stream_fetch, groups=2, iterations=n_it))
+    ex["mh_sampler_evals_per_s"] = (n_it + 1) * B / (time.perf_counter() - t3s)      # start + n_it iterations of B chains
+    worker.stream_close()
+    require(np.array_equal(mhs.chain[:, :3], mh.chain),
+            "streamed sampler: the first 3 iterations differ from the lock-step sampler's chains")
+    require(close(mhs.lnprobability[:, :3], mh.lnprobability), "streamed sampler: lnprob vs the lock-step sampler")
+    ex["mh_sampler_what"] = (f"{B} Metropolis-Hastings chains through one resident launch, two halves in flight, {n_it} iterations "
+                             "(+ the starting evaluation); chains equal to the lock-step sampler's")
     worker.close()
 
     # BASELINE configs[4]: predict_f_g_h at the retrieve shape (N = 8192, M = 2 n_pix = 1024), handle-resident

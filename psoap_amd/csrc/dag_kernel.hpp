@@ -2636,6 +2636,14 @@ inline DagPlan dag_build_lane_plan(int P, int lanes, int workers, int scheme, bo
     return plan;
 }
 
+// Waves per SIMD of the throughput-scheme kernels (k_chol_dag<C, false, false, *>).  -DPSOAP_WPE3 (round 5, experiment): three
+// workgroups per compute unit, 168 registers per lane -- see DESIGN.md / LABNOTES.md for what it measured.
+#ifdef PSOAP_WPE3
+constexpr int DAG_WPE_TP = 3;
+#else
+constexpr int DAG_WPE_TP = 2;
+#endif
+
 // uniform batch: B matrices of P block rows each
 inline DagPlan dag_build_tasks(int B, int P, int workers, int scheme = -1, int Mt = 0, int Ms = 0)
 {

@@ -84,8 +84,15 @@ __device__ __forceinline__ void exp_nonpos_batch(const double (&x)[NE], double (
     for (int e = 0; e < NE; ++e) t[e] = __builtin_fma(NLN2_LO, dn[e], t[e]);
 #pragma unroll
     for (int e = 0; e < NE; ++e) p[e] = __builtin_fma(CK[0], t[e], CK[1]);
+    // (-DPSOAP_EXP_PROBE: a TIMING probe only -- six of the eleven Horner steps dropped, the operation count a 64-entry
+    // table + degree-5 polynomial would have, WRONG values: what a table-driven exp could gain at most.  DESIGN.md 3.)
+#ifdef PSOAP_EXP_PROBE
+    constexpr int K0 = 8;
+#else
+    constexpr int K0 = 2;
+#endif
 #pragma unroll
-    for (int k = 2; k < 10; ++k)
+    for (int k = K0; k < 10; ++k)
 #pragma unroll
         for (int e = 0; e < NE; ++e) p[e] = __builtin_fma(t[e], p[e], CK[k]);
 #pragma unroll

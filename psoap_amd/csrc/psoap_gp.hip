@@ -579,9 +579,9 @@ static int configure_kernels(int device)
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
 #define PSOAP_SET_LDS(...) \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
-    PSOAP_SET_LDS(k_chol_dag<1, false, false>);
-    PSOAP_SET_LDS(k_chol_dag<2, false, false>);
-    PSOAP_SET_LDS(k_chol_dag<3, false, false>);
+    PSOAP_SET_LDS(k_chol_dag<1, false, false, false, DAG_WPE_TP>);
+    PSOAP_SET_LDS(k_chol_dag<2, false, false, false, DAG_WPE_TP>);
+    PSOAP_SET_LDS(k_chol_dag<3, false, false, false, DAG_WPE_TP>);
     PSOAP_SET_LDS(k_chol_dag<1, false, true>);
     PSOAP_SET_LDS(k_chol_dag<2, false, true>);
     PSOAP_SET_LDS(k_chol_dag<3, false, true>);
@@ -618,6 +618,7 @@ static int dag_workers(int device, int* out, int* cus = nullptr)
                                                          GEMM_LDS_BYTES));
     if (blocks_per_cu < 1) blocks_per_cu = 1;
     if (blocks_per_cu > 2) blocks_per_cu = 2;
+    if (DAG_WPE_TP > 2) blocks_per_cu = DAG_WPE_TP;      // (-DPSOAP_WPE3: the throughput kernels are compiled for three)
     *out = blocks_per_cu * prop.multiProcessorCount;
     if (cus) *cus = prop.multiProcessorCount;
     return 0;
@@ -1283,7 +1284,7 @@ static int eval_dag(psoap_chunk* h)
     HIP_TRY(hipMemsetAsync(h->dDag, 0, taken_off + sizeof(unsigned int) * (((size_t)h->plan_tasks + 31) / 32 + 1), s));
     if (prof_end(h, s)) return 1;
     const long long tasks = h->plan_tasks;
-    const int grid = (int)(tasks < h->plan_workers ? tasks : h->plan_workers);
+    const int grid_all = (int)(tasks < h->plan_workers ? tasks : h->plan_workers);
     // executed MFMA flops: left-looking updates + strip solves, full 128^3 tiles
     double fl = 0.0;
     for (int q = 0; q < P; ++q) fl += 2.0 * NB * NB * ((double)q * NB * (P - q) + (double)NB * (P - q - 1));
@@ -1303,12 +1304,13 @@ static int eval_dag(psoap_chunk* h)
             memcpy(pool_.n_main, h->plan_n_main, sizeof pool_.n_main);
         }
         const bool lat = h->plan_scheme >= 1;
+        const int grid = (lat && grid_all > 2 * h->n_cus) ? 2 * h->n_cus : grid_all;     // (the LAT kernels: two per compute unit)
         // at most one workgroup per compute unit (single evaluations: dag_pick_workers): the kernels compiled for one wave
         // per SIMD -- 512 registers per lane, nothing of the chain phases in scratch memory
         const bool wide = lat && grid <= h->n_cus && !(getenv("PSOAP_DAG_WIDE") && getenv("PSOAP_DAG_WIDE")[0] == '0');
-        if (C == 1) { if (wide) PSOAP_LAUNCH_DAG(1, true, 1); else if (lat) PSOAP_LAUNCH_DAG(1, true, 2); else PSOAP_LAUNCH_DAG(1, false, 2); }
-        else if (C == 2) { if (wide) PSOAP_LAUNCH_DAG(2, true, 1); else if (lat) PSOAP_LAUNCH_DAG(2, true, 2); else PSOAP_LAUNCH_DAG(2, false, 2); }
-        else { if (wide) PSOAP_LAUNCH_DAG(3, true, 1); else if (lat) PSOAP_LAUNCH_DAG(3, true, 2); else PSOAP_LAUNCH_DAG(3, false, 2); }
+        if (C == 1) { if (wide) PSOAP_LAUNCH_DAG(1, true, 1); else if (lat) PSOAP_LAUNCH_DAG(1, true, 2); else PSOAP_LAUNCH_DAG(1, false, DAG_WPE_TP); }
+        else if (C == 2) { if (wide) PSOAP_LAUNCH_DAG(2, true, 1); else if (lat) PSOAP_LAUNCH_DAG(2, true, 2); else PSOAP_LAUNCH_DAG(2, false, DAG_WPE_TP); }
+        else { if (wide) PSOAP_LAUNCH_DAG(3, true, 1); else if (lat) PSOAP_LAUNCH_DAG(3, true, 2); else PSOAP_LAUNCH_DAG(3, false, DAG_WPE_TP); }
 #undef PSOAP_LAUNCH_DAG
     }
     HIP_TRY(hipGetLastError());
@@ -1668,7 +1670,7 @@ static int group_eval_locked(psoap_group* g, bool promote)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(g->dDag, 0, g->dag_bytes, s));
     {
-        const int workers = g->workers;
+        const int workers = (g->scheme >= 1 && g->workers > 2 * g->hs[0]->n_cus) ? 2 * g->hs[0]->n_cus : g->workers;
         const int grid = (int)(g->n_tasks < workers ? g->n_tasks : workers);
         MatFlags* fl_ = reinterpret_cast<MatFlags*>(g->dDag + sizeof(DagCtl));
         DagCtl* ctl_ = reinterpret_cast<DagCtl*>(g->dDag);
@@ -1685,9 +1687,9 @@ static int group_eval_locked(psoap_group* g, bool promote)
         }
         const bool lat = g->scheme >= 1;
         const bool wide = lat && grid <= g->hs[0]->n_cus && !(getenv("PSOAP_DAG_WIDE") && getenv("PSOAP_DAG_WIDE")[0] == '0');
-        if (C == 1) { if (wide) PSOAP_LAUNCH_GROUP(1, true, 1); else if (lat) PSOAP_LAUNCH_GROUP(1, true, 2); else PSOAP_LAUNCH_GROUP(1, false, 2); }
-        else if (C == 2) { if (wide) PSOAP_LAUNCH_GROUP(2, true, 1); else if (lat) PSOAP_LAUNCH_GROUP(2, true, 2); else PSOAP_LAUNCH_GROUP(2, false, 2); }
-        else { if (wide) PSOAP_LAUNCH_GROUP(3, true, 1); else if (lat) PSOAP_LAUNCH_GROUP(3, true, 2); else PSOAP_LAUNCH_GROUP(3, false, 2); }
+        if (C == 1) { if (wide) PSOAP_LAUNCH_GROUP(1, true, 1); else if (lat) PSOAP_LAUNCH_GROUP(1, true, 2); else PSOAP_LAUNCH_GROUP(1, false, DAG_WPE_TP); }
+        else if (C == 2) { if (wide) PSOAP_LAUNCH_GROUP(2, true, 1); else if (lat) PSOAP_LAUNCH_GROUP(2, true, 2); else PSOAP_LAUNCH_GROUP(2, false, DAG_WPE_TP); }
+        else { if (wide) PSOAP_LAUNCH_GROUP(3, true, 1); else if (lat) PSOAP_LAUNCH_GROUP(3, true, 2); else PSOAP_LAUNCH_GROUP(3, false, DAG_WPE_TP); }
 #undef PSOAP_LAUNCH_GROUP
     }
     HIP_TRY(hipGetLastError());
@@ -1759,15 +1761,17 @@ static int stream_launch(psoap_chunk* h)
     a.tlog_cap = st.tlog_cap;
     MatFlags* fl_ = reinterpret_cast<MatFlags*>(st.dDag + sizeof(DagCtl));
     DagCtl* ctl_ = reinterpret_cast<DagCtl*>(st.dDag);
-    const int grid = h->dag_grid;
-#define PSOAP_LAUNCH_STREAM(CC, LAT)                                                                              \
-    hipLaunchKernelGGL((k_chol_dag<CC, false, LAT, true>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s,      \
+    // (the stream kernels are compiled for two workgroups per compute unit, also in a -DPSOAP_WPE3 build: with three, hipcc's
+    // code for them shows the exec-restore defect of psoap_amd/asmcheck.py and the build refuses it)
+    const int grid = h->dag_grid > 2 * h->n_cus ? 2 * h->n_cus : h->dag_grid;
+#define PSOAP_LAUNCH_STREAM(CC, LAT, WPE)                                                                         \
+    hipLaunchKernelGGL((k_chol_dag<CC, false, LAT, true, WPE>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, \
                        st.dMats, st.dTasks, st.queues, fl_, reinterpret_cast<int*>(st.dDag + st.arrive_off), st.dWs, \
                        ctl_, st.dTlog, DagAug{h->P, 0, 0, nullptr}, a, DagPool{})
     const bool lat = st.scheme >= 1;
-    if (st.C == 1) { if (lat) PSOAP_LAUNCH_STREAM(1, true); else PSOAP_LAUNCH_STREAM(1, false); }
-    else if (st.C == 2) { if (lat) PSOAP_LAUNCH_STREAM(2, true); else PSOAP_LAUNCH_STREAM(2, false); }
-    else { if (lat) PSOAP_LAUNCH_STREAM(3, true); else PSOAP_LAUNCH_STREAM(3, false); }
+    if (st.C == 1) { if (lat) PSOAP_LAUNCH_STREAM(1, true, 2); else PSOAP_LAUNCH_STREAM(1, false, 2); }
+    else if (st.C == 2) { if (lat) PSOAP_LAUNCH_STREAM(2, true, 2); else PSOAP_LAUNCH_STREAM(2, false, 2); }
+    else { if (lat) PSOAP_LAUNCH_STREAM(3, true, 2); else PSOAP_LAUNCH_STREAM(3, false, 2); }
 #undef PSOAP_LAUNCH_STREAM
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(st.evExit, s));
@@ -1894,7 +1898,7 @@ extern "C" int psoap_stream_open(psoap_chunk* h, int c, int lanes, int scheme)
     // the dispatcher keeps 3 x n_epochs velocities, 16 parameters and one flag per lane in the tile engine's LDS array
     if (h->n_epochs > 0 && (3 * (size_t)h->n_epochs + 16) * sizeof(double) + sizeof(int) * (size_t)lanes > GEMM_LDS_BYTES)
         FAIL("psoap_stream_open: too many epochs for the dispatcher's staging (3 n_epochs + 16 doubles + one int per lane must "
-             "fit 18432 bytes)");
+             "fit the tile engine's 73728 bytes of LDS)");
     if (share_wants_staged(h->device))
         FAIL("psoap_stream_open: too many processes share this GPU for a resident launch (more than PSOAP_SHARE_DAG_MAX, or "
              "several without the device lock): use the batch calls");
@@ -2505,6 +2509,7 @@ extern "C" int psoap_predict(int device, int mode, int c, int N, int M, const do
     if (int rc = enter_device(device)) return rc;
     PredictWs ws;
     if (int rc = dag_workers(device, &ws.workers, &ws.n_cus)) return rc;
+    if (ws.workers > 2 * ws.n_cus) ws.workers = 2 * ws.n_cus;
     int status = 0;
     const int rc = predict_settled(ws, device, mode, c, N, M, lwl, fl, sigma, nullptr, nullptr, lwl_pred, mu_c, gp, mu_out,
                                    Sigma_out, &status, nullptr);
@@ -2542,6 +2547,7 @@ extern "C" int psoap_predictor_create(psoap_predictor** out, int device)
         delete p;
         return rc;
     }
+    if (p->ws.workers > 2 * p->ws.n_cus) p->ws.workers = 2 * p->ws.n_cus;
     *out = p;
     return 0;
 }
@@ -2626,7 +2632,7 @@ static int chunk_predict(psoap_chunk* h, int mode, int c, int M, const double* l
     if (int rc = enter_device(h->device)) return rc;
     if (!h->pws) {
         h->pws = new PredictWs();
-        h->pws->workers = h->dag_grid;
+        h->pws->workers = h->dag_grid < 2 * h->n_cus ? h->dag_grid : 2 * h->n_cus;       // (the AUG kernels: two per compute unit)
         h->pws->n_cus = h->n_cus;
     }
     int status = 0;

@@ -87,3 +87,37 @@ def test_quickstart_example(tmp_path):
     assert (tmp_path / "work" / "opt_jump.npy").exists()
     assert (tmp_path / "work" / "plots_chunk_20_5100_5110" / "f.npy").exists()
     assert np.all(np.isfinite(res["mu"]))
+
+
+def test_streamed_device_chains_equal_oracle_and_lockstep_chains(tmp_path):
+    """Round 5: run(stream=True) -- the sampler's iterations through ONE resident launch, the chains in two halves
+    (samplers.sample_streamed, Posterior.stream_*; /root/reference/psoap/sample_parallel.py:434-438 with the gather of :378-387
+    per half).  One chunk on the rank; same seeds: the chains of the oracle's scalar loop and of the lock-step driver."""
+    import sampler_oracle
+    from psoap_amd import sample_parallel as sp
+    from test_samplers import _scalar_posterior
+    config = _write_dataset(tmp_path, n_chunks=1)
+    chunks = sp.load_chunks(sp.load_config(str(tmp_path / "config.yaml")), prefix=str(tmp_path) + "/")
+    s = sp.run(config, chunks, run_index=0, n_chains=6, seed=31, verbose=False, stream=True)
+    assert s.streamed
+    lock = sp.run(config, chunks, run_index=0, n_chains=6, seed=31, verbose=False, stream=False, overwrite=True)
+    assert not lock.streamed and np.array_equal(s.chain, lock.chain) and np.array_equal(s.naccepted, lock.naccepted)
+    assert np.all(np.abs(s.lnprobability - lock.lnprobability) <= 1e-10 * np.maximum(1.0, np.abs(lock.lnprobability)))
+    lnprob = _scalar_posterior(chunks, config)
+    p0 = utils.convert_dict("SB2", ["gamma"], **config["parameters"])
+    cov = utils.convert_dict("SB2", ["gamma"], **config["jumps"]) ** 2 * np.eye(10)
+    for b in range(6):
+        chain, lps, acc = sampler_oracle.mh_chain(lnprob, p0, cov, 10, np.random.mtrand.RandomState(31 + b))
+        assert np.array_equal(s.chain[b], chain), b
+        assert np.all(np.abs(s.lnprobability[b] - lps) <= LNP_RTOL * np.maximum(1.0, np.abs(lps)))
+    # the automatic rule leaves small chunks / few chains on the launch-per-step path
+    assert not sp.run(config, chunks, run_index=0, n_chains=6, seed=31, verbose=False, overwrite=True).streamed
+    # a row outside the prior inside a streamed half: -inf, never accepted
+    post = sp.Posterior("SB2", chunks, ["gamma"], config["parameters"], max_batch=4)
+    post.stream_open()
+    P = np.tile(p0, (4, 1))
+    P[2, 1] = -1.0
+    out = post.stream_fetch(post.stream_submit(P))
+    assert out[2] == -np.inf and out[0] == out[1] == out[3] and np.isfinite(out[0])
+    post.stream_close()
+    post.close()

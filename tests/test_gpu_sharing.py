@@ -197,3 +197,71 @@ def test_many_worker_processes_never_get_a_wrong_value(workers, lock):
     assert acct["staged_policy"] >= workers * 100
     if lock == 0:
         assert acct["lock_acquisitions"] == 0
+
+
+_TWO_STREAMS = r'''
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, %(root)r)
+from psoap_amd import _lib, synthetic as syn
+from psoap_amd.chunk import ChunkHandle
+k = int(sys.argv[1])
+ch = syn.make_chunk(2, 10, 200, seed=8300 + k)                  # N = 2000
+B = 8
+gps = syn.make_walkers(2, B, seed=8301)
+lw = syn.walker_lwls(ch, syn.make_walker_velocities(ch, B, seed=8302 + k))
+with ChunkHandle(ch.fl, ch.sigma, max_batch=B, device=0) as h:
+    ref = h.lnlike_batch(lw, gps)
+    h.stream_open(2, B)
+    first = None
+    bad = 0
+    for step in range(40):
+        out = h.stream_fetch(h.stream_submit(lw, gps))          # the stream stays OPEN between the steps
+        first = out if first is None else first
+        bad += int(not np.array_equal(out, first))
+        time.sleep(0.002)                                        # (the other process gets the device in between)
+    st = h.stream_stats()
+    h.stream_close()
+ok = bool(np.all(np.abs(first - ref) <= 1e-10 * np.maximum(1.0, np.abs(ref))))
+print("RESULT " + json.dumps({"bad": bad, "ok": ok, "launches": st["launches"], "stats": _lib.share_stats(0)}), flush=True)
+'''
+
+
+def test_two_processes_with_open_streams_take_the_device_in_turn(tmp_path):
+    """ADVICE r4 (medium): a stream whose last ticket has been fetched gave the device lock back while its resident launch
+    still held every compute unit (idle time-out 20 ms) -- another process could start ITS persistent launch beside it.  Now the
+    launch leaves before the lock does whenever other processes use the device.  Two processes, each with a stream left open
+    between 40 steps: every step's values are the first step's, nothing times out, and the streams relaunch per step."""
+    prog = tmp_path / "two_streams.py"
+    prog.write_text(_TWO_STREAMS % {"root": ROOT})
+    env = dict(os.environ, PSOAP_LOCK_DIR=str(tmp_path / "locks"))
+    ps = [subprocess.Popen([sys.executable, str(prog), str(k)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+          for k in range(2)]
+    outs = [p.communicate(timeout=600) for p in ps]
+    for p, (so, se) in zip(ps, outs):
+        assert p.returncode == 0, so[-1500:] + se[-3000:]
+    recs = [json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):]) for so, _ in outs]
+    for r in recs:
+        assert r["bad"] == 0 and r["ok"], recs
+        assert r["stats"]["procs"] == 2 and r["stats"]["lock_acquisitions"] >= 40
+        assert r["launches"] >= 30             # shared device: the resident launch left after (nearly) every step
+
+
+def test_stream_submissions_are_checked_against_the_lane_buffers():
+    """ADVICE r4 (low): orbital parameters of the wrong width and more epochs than the dispatcher's LDS staging holds are
+    refused instead of read / written past a lane's buffer."""
+    from psoap_amd import _lib, synthetic as syn
+    from psoap_amd.lnprob import ChunkWorker
+    from psoap_amd.chunk import ChunkHandle
+    ch = syn.make_chunk(2, 6, 50, seed=8400)
+    w = ChunkWorker("SB2", ch.lwl, ch.fl, ch.sigma, ch.epoch_index, ch.dates, max_batch=2, device=0)
+    w.stream_open(2)
+    with pytest.raises(ValueError, match="p_orb must have shape"):
+        w.handle.stream_submit_orbits(1, np.zeros((1, 5)), np.tile(syn.GP_BASE[2], (1, 1)))
+    w.stream_close()
+    w.close()
+    big = syn.make_chunk(1, 3100, 2, seed=8401)                  # 3100 epochs: 3 x 3100 + 16 doubles > the 72 KB of LDS
+    with ChunkHandle(big.fl, big.sigma, max_batch=2, device=0) as h:
+        h.set_grid(big.lwl, big.epoch_index, 3100)
+        with pytest.raises(_lib.PsoapError, match="too many epochs"):
+            h.stream_open(1, 2)

@@ -41,6 +41,21 @@ def newest(pattern):
 shutil.copy(newest("trace/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
 if glob.glob(os.path.join(src, "trace_full/*/*_kernel_stats.csv")):
     shutil.copy(newest("trace_full/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats_full_bench.csv"))
+if glob.glob(os.path.join(src, "trace_driver/*/*_kernel_stats.csv")):
+    # (round 5) the driver's exact command under the kernel trace: stats + every dispatch of the persistent kernels
+    shutil.copy(newest("trace_driver/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats_driver_command.csv"))
+    drows = list(csv.DictReader(open(newest("trace_driver/*/*_kernel_trace.csv"))))
+    with open(os.path.join(dst, f"{tag}_kernel_trace_driver_command_dag.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Dispatch_Id", "Kernel_Name", "Start_Timestamp", "End_Timestamp", "Duration_ms"])
+        for r in drows:
+            if KERNEL in r["Kernel_Name"]:
+                w.writerow([r["Dispatch_Id"], r["Kernel_Name"].split("(")[0], r["Start_Timestamp"], r["End_Timestamp"],
+                            "%.4f" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)])
+    if os.path.exists(os.path.join(src, "trace_driver.log")):
+        for ln in open(os.path.join(src, "trace_driver.log")):
+            if ln.startswith("{") and '"metric"' in ln:
+                open(os.path.join(dst, f"{tag}_bench_under_kernel_trace.json"), "w").write(ln)
 shutil.copy(os.path.join(src, f"summary_{tag}.md"), os.path.join(dst, f"{tag}_summary.md"))
 # every dispatch of the persistent kernels (resident and launch-per-step) from the kernel trace: the per-dispatch durations
 # the roofline of bench.py has to agree with

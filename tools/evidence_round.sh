@@ -41,9 +41,9 @@ step row_periods bash -c "{ timeout 120 python tools/row_periods.py 3 1; timeout
 step wg_occupancy bash -c "timeout 120 python tools/wg_occupancy.py 3 1 200 2>&1 | grep -v amdgpu.ids > gpurun_out/wg_occupancy_$TAG.txt"
 step scheme_table bash -c "timeout 600 python tools/scheme_table.py 2>&1 | grep -v amdgpu.ids > gpurun_out/scheme_table_$TAG.txt"
 step queue_sweep bash -c "timeout 600 python tools/queue_sweep.py 3 9,10,12,13,17,20,25,31,32 2>&1 | grep -v amdgpu.ids > gpurun_out/queue_sweep_final_$TAG.txt"
-# several processes on this one GPU: without the library's device lock (wrong values now and then -- reported, not a failure
-# of the step) and with it (the step fails on a single wrong value)
-step shared_gpu bash -c "{ for i in 1 2 3; do timeout 200 python tools/shared_gpu_probe.py 8 200 3 0; done; for i in 1 2 3; do timeout 300 python tools/shared_gpu_probe.py 8 200 3 2 || exit 1; done; } 2>&1 | grep -v amdgpu.ids > gpurun_out/shared_gpu_probe_$TAG.txt"
+# several processes on this one GPU (round 5: no wrong value and no time-out with the library's lock on OR off, 8 and 16 workers;
+# the step fails on a single wrong value)
+step shared_gpu bash -c "{ for a in '8 300 3 2' '8 200 3 0' '16 300 3 2' '16 200 3 0' '16 300 1 2'; do timeout 600 python tools/shared_gpu_probe.py \$a || exit 1; done; } 2>&1 | grep -v amdgpu.ids > gpurun_out/shared_gpu_probe_$TAG.txt"
 cat $STATUS
 if [ $FAILED -ne 0 ]; then echo "evidence INCOMPLETE: at least one step failed"; exit 5; fi
 echo "evidence complete"

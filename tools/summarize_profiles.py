@@ -8,7 +8,7 @@ def one(pattern):
 
 print(f"# rocprofv3 summary {tag}\n")
 print("Command profiled: `python3 bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-extras --no-strong` on one MI355X (ROCm 7.2): 32 walkers x SB2")
-print("N=6000 per step.  Round 4: the headline runs through ONE resident launch of `k_chol_dag<2, false, false, true>` (the last")
+print("N=6000 per step.  Since round 4 the headline runs through ONE resident launch of `k_chol_dag<2, false, false, true>` (the last")
 print("template argument: STREAM) per region -- the warm-up's 5 steps and the timed region's 5 steps are one dispatch each, 160")
 print("evaluations per dispatch, so the dispatches of that kernel in this run are alike.  `k_chol_dag<2, false, false, false>` is the")
 print("launch-per-step path measured beside it (2 warm-up + 5 timed + 1 + 5 proposals-resident + 1 event-profiled dispatches of 32")
@@ -36,13 +36,15 @@ if f:
             print(f"| {name} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
     print()
 
+def is_stream(name):
+    head = name.split("(")[0].replace(" ", "")
+    # template arguments <C, AUG, LAT, STREAM, WPE>: the fourth one (rounds 1-3 had three, the start of round 4 four)
+    m = re.search(r"k_chol_dag<([^>]*)>", head)
+    return bool(m) and len(m.group(1).split(",")) >= 4 and m.group(1).split(",")[3] == "true"
+
+
 f = one("trace/**/*kernel_trace.csv")
 if f:
-    def is_stream(name):
-        head = name.split("(")[0].replace(" ", "")
-        # template arguments <C, AUG, LAT, STREAM, WPE>: the fourth one (rounds 1-3 had three, the start of round 4 four)
-        m = re.search(r"k_chol_dag<([^>]*)>", head)
-        return bool(m) and len(m.group(1).split(",")) >= 4 and m.group(1).split(",")[3] == "true"
     rows = [r for r in csv.DictReader(open(f)) if is_stream(r["Kernel_Name"])]
     if rows:
         print("## every dispatch of the resident (stream) kernel, from the kernel trace\n")
@@ -53,6 +55,49 @@ if f:
             ms = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
             tf = 160 * F / (ms * 1e-3) / 1e12
             print(f"| {r['Dispatch_Id']} | {ms:.3f} | 160 | {tf:.2f} | {tf / 78.6:.3f} |")
+        print()
+
+
+f = one("trace_driver/**/*kernel_trace.csv")
+if f:
+    import json
+    rows = [r for r in csv.DictReader(open(f)) if is_stream(r["Kernel_Name"])]
+    line = None
+    logp = os.path.join(out, "trace_driver.log")
+    if os.path.exists(logp):
+        for ln in open(logp):
+            if ln.startswith("{") and '"metric"' in ln:
+                line = json.loads(ln)
+    print("## the driver's command, `python3 bench.py --steps 20 --warmup 5`, under `rocprofv3 --kernel-trace --stats`\n")
+    print("Every dispatch of the resident kernel `k_chol_dag<2, false, false, true, 2>` in that run.  The warm-up's 5 steps are one")
+    print("dispatch of 160 evaluations, the TIMED REGION's 20 steps are one dispatch of 640 evaluations (the longest one below;")
+    print("`stream.matrices` of the bench line counts them on the device), the others belong to the side legs (lnprob(p) and the")
+    print("sampler through a stream).  `roofline.frac` of the line = 640 x F(6000) / that dispatch's duration / 78.6 TFLOP/s.\n")
+    print("| dispatch | duration ms | what | algorithmic TFLOP/s | of 78.6 |")
+    print("|---|---|---|---|---|")
+    F = 6000.0 ** 3 / 3.0 + 2.0 * 6000.0 ** 2
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+    big = max(range(len(rows)), key=lambda i: durs[i]) if rows else -1
+    for i, r in enumerate(rows):
+        ms = durs[i]
+        if i == big:
+            tf = 640 * F / (ms * 1e-3) / 1e12
+            print(f"| {r['Dispatch_Id']} | {ms:.3f} | **the timed region: 640 evaluations** | **{tf:.2f}** | **{tf / 78.6:.4f}** |")
+        else:
+            print(f"| {r['Dispatch_Id']} | {ms:.3f} | warm-up (160 evaluations) or a side leg | | |")
+    if line is not None:
+        rf = line.get("roofline", {})
+        print(f"\nThe bench line of this very run (under the profiler): value {line.get('value'):.1f} evals/s, ms_per_step "
+              f"{line.get('ms_per_step'):.3f}, roofline.achieved {rf.get('achieved')}, roofline.frac {rf.get('frac')}, "
+              f"avg_launch_ms {rf.get('avg_launch_ms', rf.get('launch_ms'))}.")
+    print()
+    f2 = one("trace_driver/**/*kernel_stats.csv")
+    if f2:
+        print("| kernel (driver's command) | calls | total ms | avg us | % |")
+        print("|---|---|---|---|---|")
+        for r in csv.DictReader(open(f2)):
+            if float(r["Percentage"]) >= 0.05:
+                print(f"| {r['Name'].split('(')[0]} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
         print()
 
 
