@@ -765,7 +765,7 @@ def run_extras(args, h, chunk, gps, lwls, dev, mode):
     # accept / reject and next proposals drawn while the other half is being factored -- the loop of sample_parallel.py:434-438
     # as a consumer of the stream.  Same seeds: the chains must be the lock-step sampler's (decisions identical; lnprob to the
     # parity tolerance -- a lane's plan sums in another order than a batch of 32).
-    n_it = 8
+    n_it = 30            # (long enough for the start and the drain not to show: tools/sampler_stream_bench.py)
     worker.stream_open(B)
     mhs = MultiChainMHSampler(cov_mh, pfit.shape[1], None, B, seeds=[7000 + b for b in range(B)])
     list(mhs.sample_streamed(pfit, lambda P, g: worker.stream_submit(P), worker.stream_fetch, groups=2, iterations=1))   # warm
