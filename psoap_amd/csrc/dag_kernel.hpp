@@ -2015,7 +2015,7 @@ struct DagPlan {
     int scheme = 0;            // 0 throughput, 1 latency: selects the kernel instantiation (k_chol_dag<.., LAT>)
 };
 
-inline int dag_split_factor(int tasks_in_row, int q, int workers, int scheme, int n_mats = 0)
+inline int dag_split_factor(int tasks_in_row, int q, int workers, int scheme, int n_mats = 0, bool augmented = false)
 {
     // cut tiles of sparse block rows until the row offers about `workers` tasks (at most 8 parts).
     // Throughput scheme: full occupancy, parts at least two panels long.  Latency scheme: half the workers,
@@ -2028,7 +2028,10 @@ inline int dag_split_factor(int tasks_in_row, int q, int workers, int scheme, in
     static const int env_min = getenv("PSOAP_DAG_SPLIT_MIN") ? atoi(getenv("PSOAP_DAG_SPLIT_MIN")) : 0;
     // (scheme 2: 35 % -- with the PARTs handed out just in time the chains run ahead of the finals anyway, and every part
     // less is a partial-tile hand-over less; measured over N = 4096 .. 8192, B = 1 .. 8: 25 / 35 / 50 / 70 %)
-    const int pct = env_pct > 0 ? env_pct : (scheme == 2 ? 35 : (scheme >= 1 ? 50 : 100));
+    // (predict -- appended columns: the launch is bound by throughput, not by its chain: 494 of 512 workgroups busy, 88 % of
+    // their time in PART tasks (tools/predict_timeline.py), and every part less is a 128 KB partial tile that does not
+    // travel: 25 % measured 9.85-10.0 ms against 10.25-10.3 at 35 %, profiles/r5_experiments.txt)
+    const int pct = env_pct > 0 ? env_pct : (scheme == 2 ? (augmented ? 25 : 35) : (scheme >= 1 ? 50 : 100));
     const int minp = env_min > 0 ? env_min : (scheme >= 1 ? 4 : 2);
     int S = 1;
     while (S < 8 && tasks_in_row * S * 100 < workers * pct && minp * S <= q) S *= 2;
@@ -2220,7 +2223,7 @@ inline void dag_build_queue(DagPlan& plan, const std::vector<int>& mats, const s
         // (fixed_share > 0: per matrix, from its own size only)
         auto s_off = [&](int b) {
             return fixed_share > 0 ? dag_split_factor(Ps[b] + Mt - q, q, fixed_share, scheme, 1)
-                                   : dag_split_factor((int)row_tiles, q, workers, scheme, (int)Ps.size());
+                                   : dag_split_factor((int)row_tiles, q, workers, scheme, (int)Ps.size(), Mt > 0);
         };
         // latency scheme: DIAG(q) also solves the tile right of the diagonal (DAG_FUSED) whenever a next
         // diagonal tile exists, and DIAG(q >= 1) waits only for that tile of the row above (DAG_WAITNEXT)

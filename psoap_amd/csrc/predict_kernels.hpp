@@ -260,6 +260,7 @@ struct PredictWs {
     Grow<unsigned char> Dag;
     Grow<DagTask> Tasks;
     Grow<unsigned int> Order, Dep;   // ready-only hand-out (DagPool)
+    Grow<unsigned long long> Tlog;   // per-task stamps of the launch (PSOAP_PREDICT_TLOG=<file>: tools/predict_timeline.py)
     Grow<DagMat> Mat;
     Grow<double, true> hSmall;   // pinned: colx / m0 staging, mu
     // task list cache
@@ -560,7 +561,14 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
 #define PSOAP_LAUNCH_AUG(CC, LAT, WPE)                                                                            \
     hipLaunchKernelGGL((k_chol_dag<CC, true, LAT, false, WPE>), dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st,  \
                        ws.Mat.p, ws.Tasks.p, plan.queues, fl_, reinterpret_cast<int*>(ws.Dag.p + arrive_off),        \
-                       ws.Ws.p, ctl_, (unsigned long long*)nullptr, aug, StreamArgs{}, pool_)
+                       ws.Ws.p, ctl_, tlog_, aug, StreamArgs{}, pool_)
+        // debug: per-task stamps of this launch, written with the task list to the file PSOAP_PREDICT_TLOG names
+        unsigned long long* tlog_ = nullptr;
+        if (getenv("PSOAP_PREDICT_TLOG")) {
+            PR_TRY(ws.Tlog.need(plan.tasks.size() * 8));
+            PR_TRY(hipMemsetAsync(ws.Tlog, 0, sizeof(unsigned long long) * plan.tasks.size() * 8, st));
+            tlog_ = ws.Tlog.p;
+        }
         DagPool pool_{};
         if (!plan.order.empty()) {
             pool_.order = ws.Order.p;
@@ -682,6 +690,18 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         if (dag_err[0] != 0) {
             err = "predict: dependency wait timed out inside the persistent kernel";
             return 1;
+        }
+        if (const char* tpath = getenv("PSOAP_PREDICT_TLOG")) {
+            std::vector<unsigned long long> hl(ws.plan.tasks.size() * 8);
+            PR_TRY(hipMemcpy(hl.data(), ws.Tlog.p, sizeof(unsigned long long) * hl.size(), hipMemcpyDeviceToHost));
+            if (FILE* fh = fopen(tpath, "wb")) {
+                const unsigned long long hdr[4] = {(unsigned long long)ws.plan.tasks.size(), (unsigned long long)P,
+                                                   (unsigned long long)Mt, (unsigned long long)ws.plan.scheme};
+                fwrite(hdr, sizeof hdr, 1, fh);
+                fwrite(ws.plan.tasks.data(), sizeof(DagTask), ws.plan.tasks.size(), fh);
+                fwrite(hl.data(), sizeof(unsigned long long), hl.size(), fh);
+                fclose(fh);
+            }
         }
         if (dag_err[4] != 0) {
             // a workgroup moved between compute units under one of the launch's tasks (dag_where): the outputs are not

@@ -20,6 +20,7 @@
 #include <condition_variable>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -1494,6 +1495,8 @@ struct psoap_group {
 };
 
 extern "C" int psoap_group_destroy(psoap_group* g);
+static std::mutex g_groups_mu;
+static std::set<psoap_group*> g_live_groups;      // groups that exist: a handle's last_group is only followed while it is in here
 
 extern "C" int psoap_group_create(psoap_group** out, psoap_chunk* const* handles, int n)
 {
@@ -1516,6 +1519,10 @@ extern "C" int psoap_group_create(psoap_group** out, psoap_chunk* const* handles
         g_err = std::string("psoap_group_create: ") + hipGetErrorString(e);
         return 1;
     }
+    {
+        std::lock_guard<std::mutex> lk(g_groups_mu);
+        g_live_groups.insert(g);
+    }
     *out = g;
     return 0;
 }
@@ -1526,6 +1533,10 @@ extern "C" int psoap_group_destroy(psoap_group* g)
     DEVICE_SCOPE(g->device);
     (void)hipSetDevice(g->device);
     (void)hipDeviceSynchronize();
+    {   // (a member's fetch must not come back to a group that is gone: settle_evaluation asks the registry)
+        std::lock_guard<std::mutex> lk(g_groups_mu);
+        g_live_groups.erase(g);
+    }
     (void)hipFree(g->dDag); (void)hipFree(g->dMats); (void)hipFree(g->dTasks); (void)hipFree(g->dWs);
     (void)hipFree(g->dOrder); (void)hipFree(g->dDep);
     if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -2324,7 +2335,12 @@ static int settle_evaluation(psoap_chunk* h)
         if (share_detect_only()) return 0;
         if (attempt < share_retries()) {
             g_share.retries += 1;
+            bool group_alive = false;
             if (h->last_group) {
+                std::lock_guard<std::mutex> lk(g_groups_mu);
+                group_alive = g_live_groups.count(h->last_group) != 0;
+            }
+            if (group_alive) {
                 if (int rc = group_eval_locked(h->last_group, false)) return rc;
             } else if (int rc = eval_dag(h)) {
                 return rc;

@@ -105,7 +105,10 @@ for a, b in ((f"latency_{tag}.jsonl", f"{tag}_latency_table.jsonl"), (f"bench_{t
              (f"follow_table_{tag}.txt", f"{tag}_follow_table.txt"), (f"row_periods_{tag}.txt", f"{tag}_row_periods.txt"),
              (f"wg_occupancy_{tag}.txt", f"{tag}_wg_occupancy.txt"), (f"lib_sha256_{tag}.txt", f"{tag}_lib_sha256.txt"),
              (f"scheme_table_{tag}.txt", f"{tag}_scheme_table.txt"), (f"queue_sweep_final_{tag}.txt", f"{tag}_queue_sweep_final.txt"),
-             (f"shared_gpu_probe_{tag}.txt", f"{tag}_shared_gpu_probe.txt"), (f"evidence_status_{tag}.txt", f"{tag}_evidence_status.txt")):
+             (f"shared_gpu_probe_{tag}.txt", f"{tag}_shared_gpu_probe.txt"), (f"evidence_status_{tag}.txt", f"{tag}_evidence_status.txt"),
+             (f"predict_timeline_{tag}.txt", f"{tag}_predict_timeline.txt"), (f"part_wait_share_{tag}.txt", f"{tag}_part_wait_share.txt"),
+             (f"sampler_stream_{tag}.txt", f"{tag}_sampler_stream_same_call.txt"),
+             (f"gather_beside_stream_{tag}.txt", f"{tag}_gather_beside_stream_same_call.txt")):
     p = os.path.join(ROOT, "gpurun_out", a)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, b))

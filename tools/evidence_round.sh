@@ -38,6 +38,10 @@ step stream_timeline bash -c "PSOAP_STREAM_IDLE_MS=50 timeout 300 python tools/s
 step fill bash -c "timeout 300 python tools/fill_bench.py 2>/dev/null > gpurun_out/fill_$TAG.jsonl"
 step follow_table bash -c "tools/follow_table.sh 1,2,4,8,16,32 > gpurun_out/follow_table_$TAG.txt 2>&1"
 step row_periods bash -c "{ timeout 120 python tools/row_periods.py 3 1; timeout 120 python tools/row_periods.py 5 1; } 2>&1 | grep -v amdgpu.ids > gpurun_out/row_periods_$TAG.txt"
+step predict_timeline bash -c "timeout 300 python tools/predict_timeline.py 1000 2>&1 | grep -v amdgpu.ids > gpurun_out/predict_timeline_$TAG.txt"
+step part_wait_share bash -c "{ timeout 120 python tools/part_wait_share.py 3 1; timeout 120 python tools/part_wait_share.py 3 8; timeout 120 python tools/part_wait_share.py 5 1; timeout 120 python tools/part_wait_share.py 1 32; } 2>&1 | grep -v amdgpu.ids > gpurun_out/part_wait_share_$TAG.txt"
+step sampler_stream bash -c "timeout 300 python tools/sampler_stream_bench.py 30 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/sampler_stream_$TAG.txt"
+step gather bash -c "python -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node=1 tools/gather_beside_stream.py 12 device,host,per-step 2>&1 | grep RESULT > gpurun_out/gather_beside_stream_$TAG.txt"
 step wg_occupancy bash -c "timeout 120 python tools/wg_occupancy.py 3 1 200 2>&1 | grep -v amdgpu.ids > gpurun_out/wg_occupancy_$TAG.txt"
 step scheme_table bash -c "timeout 600 python tools/scheme_table.py 2>&1 | grep -v amdgpu.ids > gpurun_out/scheme_table_$TAG.txt"
 step queue_sweep bash -c "timeout 600 python tools/queue_sweep.py 3 9,10,12,13,17,20,25,31,32 2>&1 | grep -v amdgpu.ids > gpurun_out/queue_sweep_final_$TAG.txt"
