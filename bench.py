@@ -277,6 +277,12 @@ def main():
     # everything from a launch to the fetch of its results, never around a collective.
     shared_gpu = world > 1 and args.backend == "gloo"
     gpu = SharedDeviceLock(local_rank) if shared_gpu else _NoLock()
+    if shared_gpu:
+        # (a dry run puts up to 8 ranks + whatever started them on ONE device: more process contexts than the device keeps
+        # mapped, where the library would send every evaluation down the staged path and refuse streams.  The dry run exists
+        # to exercise the persistent-kernel paths of the N > 1 layout: keep them -- a launch the scheduler disturbs is still
+        # detected and run again -- and say so in the line.)
+        os.environ.setdefault("PSOAP_SHARE_DAG_MAX", "64")
 
     # which binary runs: its hash, what it was built from and by, and the rung of the build's flag ladder
     library = _build.provenance()

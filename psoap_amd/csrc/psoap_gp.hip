@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <errno.h>
+#include <dirent.h>
 #include <fcntl.h>
 #include <time.h>
 #include <sys/file.h>
@@ -292,7 +293,77 @@ static void device_slot_take(int device)
         (void)close(fd);
     }
 }
-// processes with a slot on this device (this one included); re-counted at most four times a second
+// The driver's own account of who uses the device: every process that has opened /dev/kfd appears under
+// /sys/class/kfd/kfd/proc/<pid>/ with one entry per hardware queue (queues/<id>/gpuid).  Counting the processes with a queue
+// on THIS device sees what the slot files cannot: programs that do not go through this library (a torch job, another
+// user's work) -- they, too, take one of the eight process contexts the device keeps mapped.  -1 where sysfs does not say
+// (no KFD, a container without it, PSOAP_KFD_COUNT=0).  The device's KFD id comes from the topology node whose PCI location
+// matches hipDeviceGetPCIBusId.
+static int kfd_procs_on_device(int device)
+{
+    static const bool off = getenv("PSOAP_KFD_COUNT") && getenv("PSOAP_KFD_COUNT")[0] == '0';
+    if (off) return -1;
+    static std::map<int, std::string> gpu_ids;          // per HIP device: its KFD gpu_id ("" = unknown); guarded by g_devlock_mu
+    auto it = gpu_ids.find(device);
+    if (it == gpu_ids.end()) {
+        std::string found;
+        char bus[64] = {0};
+        unsigned int dom = 0, b = 0, d = 0, f = 0;
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) == hipSuccess && sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) == 4) {
+            const unsigned long want_loc = ((unsigned long)b << 8) | ((unsigned long)d << 3) | (unsigned long)f;
+            if (DIR* nodes = opendir("/sys/class/kfd/kfd/topology/nodes")) {
+                while (struct dirent* e = readdir(nodes)) {
+                    if (e->d_name[0] == '.') continue;
+                    const std::string nd = std::string("/sys/class/kfd/kfd/topology/nodes/") + e->d_name;
+                    FILE* fp = fopen((nd + "/properties").c_str(), "r");
+                    if (!fp) continue;
+                    char key[64];
+                    unsigned long long val = 0, loc = ~0ull, domain = 0, simd = 0;
+                    while (fscanf(fp, "%63s %llu", key, &val) == 2) {
+                        if (!strcmp(key, "location_id")) loc = val;
+                        else if (!strcmp(key, "domain")) domain = val;
+                        else if (!strcmp(key, "simd_count")) simd = val;
+                    }
+                    fclose(fp);
+                    if (simd == 0 || loc != want_loc || domain != dom) continue;
+                    if (FILE* fg = fopen((nd + "/gpu_id").c_str(), "r")) {
+                        char id[32] = {0};
+                        if (fscanf(fg, "%31s", id) == 1) found = id;
+                        fclose(fg);
+                    }
+                }
+                closedir(nodes);
+            }
+        }
+        it = gpu_ids.emplace(device, found).first;
+    }
+    if (it->second.empty()) return -1;
+    DIR* procs = opendir("/sys/class/kfd/kfd/proc");
+    if (!procs) return -1;
+    int n = 0;
+    while (struct dirent* e = readdir(procs)) {
+        if (e->d_name[0] < '0' || e->d_name[0] > '9') continue;
+        const std::string qd = std::string("/sys/class/kfd/kfd/proc/") + e->d_name + "/queues";
+        DIR* qs = opendir(qd.c_str());
+        if (!qs) continue;
+        bool here = false;
+        while (struct dirent* q = readdir(qs)) {
+            if (q->d_name[0] == '.' || here) continue;
+            if (FILE* fg = fopen((qd + "/" + q->d_name + "/gpuid").c_str(), "r")) {
+                char id[32] = {0};
+                if (fscanf(fg, "%31s", id) == 1 && it->second == id) here = true;
+                fclose(fg);
+            }
+        }
+        closedir(qs);
+        n += here ? 1 : 0;
+    }
+    closedir(procs);
+    return n;
+}
+
+// processes on this device: those with a slot file (this library's), or -- where the driver says -- all that hold a hardware
+// queue on it (kfd_procs_on_device), whichever is more; this one included; re-counted at most four times a second
 static int share_procs(int device)
 {
     if (const char* e = getenv("PSOAP_SHARE_PROCS"))      // tests: pretend
@@ -311,6 +382,8 @@ static int share_procs(int device)
         else ++n;                                       // held: by another process, or by this one's own descriptor
         (void)close(fd);
     }
+    const int k = kfd_procs_on_device(device);
+    if (k > n) n = k;
     S.procs = n > 0 ? n : 1;
     S.counted = now;
     return S.procs;
