@@ -30,7 +30,9 @@
  *     $XDG_RUNTIME_DIR/psoap, else /tmp/psoap-<uid>: per user, 0700.  Within a
  *     process the lock is counted.  A wait longer than
  *     PSOAP_DEVICE_LOCK_TIMEOUT_S (300) is an error that names the holder.
- *   - the processes are counted (slot files beside the lock);
+ *   - the processes on the device are counted: slot files beside the lock, and
+ *     where the driver lists them (/sys/class/kfd/kfd/proc/<pid>/queues/<q>/gpuid)
+ *     every process with a hardware queue on the device, library or not;
  *   - every persistent launch reports workgroups that the device's scheduler
  *     moved between compute units while a task ran (the one disturbance its
  *     hand-off protocol does not survive): such an evaluation is

@@ -4,7 +4,7 @@ out, tag = sys.argv[1], sys.argv[2]
 
 def one(pattern):
     g = glob.glob(os.path.join(out, pattern), recursive=True)
-    return g[0] if g else None
+    return max(g, key=os.path.getmtime) if g else None      # (the newest: a directory may hold the files of an earlier call)
 
 print(f"# rocprofv3 summary {tag}\n")
 print("Command profiled: `python3 bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-extras --no-strong` on one MI355X (ROCm 7.2): 32 walkers x SB2")
@@ -70,21 +70,29 @@ if f:
                 line = json.loads(ln)
     print("## the driver's command, `python3 bench.py --steps 20 --warmup 5`, under `rocprofv3 --kernel-trace --stats`\n")
     print("Every dispatch of the resident kernel `k_chol_dag<2, false, false, true, 2>` in that run.  The warm-up's 5 steps are one")
-    print("dispatch of 160 evaluations, the TIMED REGION's 20 steps are one dispatch of 640 evaluations (the longest one below;")
-    print("`stream.matrices` of the bench line counts them on the device), the others belong to the side legs (lnprob(p) and the")
-    print("sampler through a stream).  `roofline.frac` of the line = 640 x F(6000) / that dispatch's duration / 78.6 TFLOP/s.\n")
+    print("dispatch of 160 evaluations, the TIMED REGION's 20 steps are the next dispatch: 640 evaluations (`stream.matrices` of the")
+    print("bench line counts them on the device), the later ones belong to the side legs (lnprob(p) and the sampler through a")
+    print("stream).  `roofline.frac` of the line = 640 x F(6000) / that dispatch's duration / 78.6 TFLOP/s.\n")
     print("| dispatch | duration ms | what | algorithmic TFLOP/s | of 78.6 |")
     print("|---|---|---|---|---|")
     F = 6000.0 ** 3 / 3.0 + 2.0 * 6000.0 ** 2
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
-    big = max(range(len(rows)), key=lambda i: durs[i]) if rows else -1
+    # which dispatch is the timed region: the second one of the run (behind the warm-up's) -- and, where the run's own bench
+    # line is there, the one whose duration is its roofline.avg_launch_ms (the two must agree)
+    big = 1 if len(rows) > 1 else (0 if rows else -1)
+    if line is not None and rows:
+        want = line.get("roofline", {}).get("avg_launch_ms")
+        if want:
+            big = min(range(len(rows)), key=lambda i: abs(durs[i] - float(want)))
     for i, r in enumerate(rows):
         ms = durs[i]
         if i == big:
             tf = 640 * F / (ms * 1e-3) / 1e12
             print(f"| {r['Dispatch_Id']} | {ms:.3f} | **the timed region: 640 evaluations** | **{tf:.2f}** | **{tf / 78.6:.4f}** |")
+        elif i == 0:
+            print(f"| {r['Dispatch_Id']} | {ms:.3f} | the warm-up's 5 steps (160 evaluations) | | |")
         else:
-            print(f"| {r['Dispatch_Id']} | {ms:.3f} | warm-up (160 evaluations) or a side leg | | |")
+            print(f"| {r['Dispatch_Id']} | {ms:.3f} | a side leg (lnprob(p) through a stream: 6 x 32; the streamed sampler: 32 + 31 x 32) | | |")
     if line is not None:
         rf = line.get("roofline", {})
         print(f"\nThe bench line of this very run (under the profiler): value {line.get('value'):.1f} evals/s, ms_per_step "
