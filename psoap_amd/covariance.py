@@ -28,7 +28,7 @@ _MAX_CACHED_CHUNKS = 4
 _handles: "OrderedDict[tuple, ChunkHandle]" = OrderedDict()
 
 
-def _chunk_for(fl, sigma) -> ChunkHandle:
+def _chunk_for(fl, sigma):
     """One persistent device handle per (fl, sigma) pair, keyed on the buffers and
     verified by content, so a Worker re-uses its resident chunk on every proposal."""
     fl = as_f64(fl)
@@ -41,7 +41,13 @@ def _chunk_for(fl, sigma) -> ChunkHandle:
     if h is not None:
         h.close()
         del _handles[key]
-    h = ChunkHandle(fl.copy(), sigma.copy(), max_batch=1)
+    from . import server as _server
+    if _server.wanted():
+        # PSOAP_GPU_SERVER: the chunk lives in the process that owns the GPU (psoap_amd/server.py), this worker never
+        # initialises HIP -- the reference's worker-per-chunk model with dozens of workers per device
+        h = _server.connect_chunk(fl.copy(), sigma.copy())
+    else:
+        h = ChunkHandle(fl.copy(), sigma.copy(), max_batch=1)
     _handles[key] = h
     while len(_handles) > _MAX_CACHED_CHUNKS:
         _, old = _handles.popitem(last=False)

@@ -417,7 +417,14 @@ static bool share_wants_staged(int device)
     const int procs = share_procs(device);
     if (procs <= 1) return false;
     if (!device_lock_enabled()) return true;            // nobody keeps two persistent launches apart
-    return procs > share_dag_max();
+    if (procs <= share_dag_max()) return false;
+    static std::atomic<bool> hinted{false};
+    if (!hinted.exchange(true) && !(getenv("PSOAP_QUIET") && getenv("PSOAP_QUIET")[0] == '1'))
+        fprintf(stderr,
+                "psoap: %d processes share this GPU: evaluations take the staged path (safe, slower).  PSOAP_GPU_SERVER=auto lets "
+                "ONE process own the device and evaluate all workers' calls in group launches (psoap_amd/server.py: 4-9 x the "
+                "rate beyond 8 workers).\n", procs);
+    return true;
 }
 // tests: every k-th launch is treated as tainted (PSOAP_TEST_TAINT_EVERY=k), to drive the retry / fallback logic on a
 // device nobody shares

@@ -7,7 +7,8 @@ compared with the process's first of that proposal.
 
 cfg: 3 = N 6000 (SB2), 1 = N 2000 (SB1), 5 = N 8192 (ST3); lock: 0 = PSOAP_DEVICE_LOCK=0, 1 = ensemble.SharedDeviceLock around
 each call and the library's own lock off, 2 = the library's device lock (the default); policy: auto (default) | dag | staged
-(PSOAP_SHARE_POLICY).  PSOAP_SHARE_DETECT_ONLY=1 in the environment: disturbed launches are counted but their values kept --
+(PSOAP_SHARE_POLICY).  PSOAP_GPU_SERVER=auto in the environment: the workers become clients of ONE process that owns the GPU
+(psoap_amd/server.py) and evaluates the requests that arrive together in one group launch.  PSOAP_SHARE_DETECT_ONLY=1 in the environment: disturbed launches are counted but their values kept --
 how many of the wrong values belong to a launch that reported a moved workgroup ("wrong_in_disturbed_launch")?  Per worker: WRONG values (beyond the 1e-10 parity contract: what must never happen), values that
 differ in the last bits only (a retry that ended on the staged path), -1 = the series ended in an error; and the library's
 own account (psoap_share_stats): disturbed launches, retries, staged evaluations, time spent waiting for the device."""
@@ -51,7 +52,7 @@ def worker(k, q, go):
             pass
         t0 = time.time()
         for r in range(reps):
-            before = _lib.share_stats(0)
+            before = _lib.share_stats(0) if not os.environ.get("PSOAP_GPU_SERVER") else {"tainted": 0, "retries": 0, "staged_fallbacks": 0, "staged_policy": 0}
             t_before = before["tainted"]
             with guard:
                 v = fn(*calls[r & 1])
@@ -61,7 +62,7 @@ def worker(k, q, go):
                     wrong += 1
                     if detect_only and _lib.share_stats(0)["tainted"] > t_before:
                         wrong_tainted += 1
-                    if len(details) < 4:          # what came back instead, and what the library knew about that call
+                    if len(details) < 4 and not os.environ.get("PSOAP_GPU_SERVER"):   # what came back instead, and what the library knew
                         after = _lib.share_stats(0)
                         details.append({"call": r, "got": repr(v), "want": repr(f), "other_proposal": repr(first[1 - (r & 1)]),
                                         "tainted_during": after["tainted"] - before["tainted"],
@@ -79,7 +80,10 @@ def worker(k, q, go):
             pass
     dt = time.time() - t0
     try:
-        stats = _lib.share_stats(0)
+        if os.environ.get("PSOAP_GPU_SERVER"):         # (the workers hold no GPU context: what the SERVER did, from worker 0)
+            stats = {"server_" + key: v for key, v in next(iter(covariance._handles.values())).server_stats().items()} if k == 0 else {}
+        else:
+            stats = _lib.share_stats(0)
     except Exception as e:
         stats = {"error": str(e)[:80]}
     stats["wrong_in_disturbed_launch"] = int(wrong_tainted)
