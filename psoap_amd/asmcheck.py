@@ -54,6 +54,37 @@ def short(mangled: str | None) -> str:
     return mangled or "?"
 
 
+def _narrows_exec(code, lo: int, k: int) -> bool:
+    """``s_mov_b64 exec, s[A:B]`` at line k, where inside the block (lines lo .. k) s[A:B] was last written by
+    ``s_and_b64 s[A:B], s[X:Y], ...`` (either operand order) and s[X:Y] by ``s_mov_b64 s[X:Y], exec`` with no write of exec
+    in between: hipcc's long form of ``s_and_saveexec`` -- the START of a masked region.  The new mask is a subset of the
+    one the block ran under, so this is not the instruction that hands parked values to lanes that did not park them."""
+    m = re.match(r"^s_mov_b64\s+exec,\s*(s\[\d+:\d+\])$", code[k])
+    if not m:
+        return False
+    mask = m.group(1)
+    saved = None
+    for j in range(k - 1, lo - 1, -1):
+        s = code[j]
+        if not s or s.startswith(".") or _LABEL.match(s):
+            continue
+        parts = s.replace(",", " ").split()
+        op, dst = parts[0], (parts[1] if len(parts) > 1 else "")
+        if dst == "exec" or "saveexec" in op:
+            return False
+        if saved is None:
+            if dst == mask:
+                if op != "s_and_b64" or len(parts) < 4:
+                    return False
+                others = [x for x in parts[2:4] if x != mask]
+                if not others:
+                    return False
+                saved = others[0]
+        elif dst == saved:
+            return op == "s_mov_b64" and len(parts) > 2 and parts[2] == "exec"
+    return False
+
+
 def scan_exec_restore(text: str):
     """-> [(function, join block, line of its label, [(line, instruction), ...]), ...]: the join blocks -- targets of an
     ``s_cbranch_execz``, or the fall-through exit of a loop closed by ``s_cbranch_execnz`` -- in which an instruction that
@@ -95,6 +126,8 @@ def scan_exec_restore(text: str):
                 break
             op = s2.split()[0]
             if _EXEC_RESTORE.match(s2) or _EXEC_RESTORE_ALT.match(s2):
+                if _narrows_exec(code, n + 1, k):
+                    break       # exec := exec & mask, spelled with a copy: no lane comes back, nothing was parked for one
                 if pend:
                     hits.append((fn_of[n], name, n + 1, pend))
                 break

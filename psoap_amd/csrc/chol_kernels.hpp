@@ -45,14 +45,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_panel_update(double* __rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 4; ++m) {
+        double* p0 = Km + (size_t)(k0 + tile_row(wr, m, lane, 0)) * ld + j0 + tile_col(wc, 0, lane);
+        double v[4][4];
+        tile_load16(p0, (size_t)4 * ld, v);
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double* p = Km + (size_t)(k0 + tile_row(wr, m, lane, r)) * ld + j0 + tile_col(wc, n, lane);
-                *p = *p - t.acc[m][n][r];
-            }
+            for (int r = 0; r < 4; ++r) p0[(size_t)4 * r * ld + 16 * n] = v[n][r] - t.acc[m][n][r];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -437,12 +437,36 @@ struct DagMat {
 
 // INPLACE: the result replaces the accumulators instead of going to memory (the strip solve that follows works on the
 // tile in registers: dag_pss)
-template <int C, bool AUG, bool INPLACE = false, bool ROWMAP = false>
+// FAST: a task that adds no covariance and writes a workspace slot (every PART but a chain's first) stores its partial
+// sum through a loop of its own (see there).
+template <int C, bool AUG, bool INPLACE = false, bool ROWMAP = false, bool FAST = false>
 __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ dest, size_t ldd, int k0, int j0,
                                                   const double* __restrict__ lw, const GpDev& g, double dsum,
                                                   const double* __restrict__ sigma, int N, double scale,
-                                                  int Npad, const DagAug& aug, double* __restrict__ mirror = nullptr)
+                                                  int Npad, const DagAug& aug, double* __restrict__ mirror = nullptr,
+                                                  bool to_slot = false)
 {
+    static_assert(INPLACE || !ROWMAP, "tiles that go to memory use the plain accumulator map");
+    if constexpr (FAST && !INPLACE) {
+        if (to_slot && scale == 0.0) {
+            // 0 * K - acc, and K >= 0 is finite, so 0.0 - acc is the same value bit for bit: 64 stores back to back.  (The
+            // general routine below is ~100 KB of straight-line code whose covariance blocks such a task jumps over, 16-64
+            // far branches per tile through the instruction cache: 33 us for 64 stores with no wait between them,
+            // 4.5 us here -- tools/predict_timeline.py.)
+            int tid_ = threadIdx.x;
+            asm volatile("" : "+v"(tid_));
+            const int lane = tid_ & 63, wave = tid_ >> 6;
+            const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dag_st(&dest[(size_t)tile_row(wr, m, lane, r) * NB + (size_t)tile_col(wc, n, lane)], 0.0 - t.acc[m][n][r]);
+            return;
+        }
+    }
     // the thread id passes through an opaque statement: everything below (coordinate loads, addresses)
     // depends on it and so cannot be hoisted above the K-loops of the update, where it would sit in
     // registers the MFMA loop then has to spill around
@@ -468,18 +492,93 @@ __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ 
             for (int c = 0; c < C; ++c) xj[n][c] = (jj[n] < N) ? lw[(size_t)c * N + jj[n]] : 0.0;
         }
     }
+    if constexpr (INPLACE) {
+        // (nothing is stored here: the load of a diagonal element's sigma_i inside the element loop delays nobody, and this
+        // shape -- rounds 2-5 -- keeps the chain phases of dag_special in registers)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            double xi[4][C];
+            int ii[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ii[r] = k0 + (ROWMAP ? 16 * tile_rowblock(wr, m) + (lane >> 4) + 4 * r : tile_row(wr, m, lane, r));
+                if (rowcross) {
+                    const int e = ii[r] - Npad;        // the same index map as the columns: equal indices = the diagonal of A
+#pragma unroll
+                    for (int c = 0; c < C; ++c) xi[r][c] = (e < aug.R) ? aug.rowx[(size_t)c * aug.Rpad + e] : 0.0;
+                    ii[r] = (e < aug.R) ? -1 - e : 0x7ffffffe;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) xi[r][c] = (ii[r] < N) ? lw[(size_t)c * N + ii[r]] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                double kv[4] = {0.0, 0.0, 0.0, 0.0};
+                if (scale != 0.0) kern_elem4_skip<C>(xi, xj[n], g, kv);   // wave-uniform: only one task per tile adds K
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = ii[r], j = jj[n];
+                    double v;
+                    if (i < N && j < N) {
+                        if (i == j) {
+#pragma clang fp contract(off)
+                            if (rowcross) {
+                                v = aug.diag[-1 - i];
+                            } else {
+                                const double sg = sigma[i];
+                                v = dsum + sg * sg;
+                            }
+                        } else {
+                            v = kv[r];
+                        }
+                    } else {
+                        v = (i == j) ? 1.0 : 0.0;
+                    }
+                    t.acc[m][n][r] = scale * v - t.acc[m][n][r];
+                }
+            }
+        }
+        return;
+    }
+    // The element loop contains no load: the rows' coordinates are fetched per 16-row block m ahead of its 16 element
+    // groups, and the DIAGONAL elements -- the only ones that need another load (sigma_i, or the prior variance of a Schur
+    // row) -- are written a second time, with their values, by the pass below.  (Rounds 2-5 fetched sigma[i] / diag[e]
+    // inside an `i == j` branch of this loop; hipcc joins such a branch with `s_waitcnt vmcnt(0)`, and on gfx9 that counter
+    // counts STORES too: every one of a tile's 64 stores waited for the one before it to reach memory.)  An element of the
+    // diagonal can only sit in the 16 x 16 block n == m of a wave with wr == wc (row block 4 wr + m against column block
+    // 4 wc + n) of a tile with k0 == j0.
+    const auto row_index = [&](int m, int r) {
+        const int i = k0 + tile_row(wr, m, lane, r);
+        if (!rowcross) return i;
+        const int e = i - Npad;            // the same index map as the columns: equal indices = the diagonal of A
+        return (e < aug.R) ? -1 - e : 0x7ffffffe;
+    };
+    const auto put = [&](int m, int n, int r, double out) {
+        const int jc = tile_col(wc, n, lane), ic = tile_row(wr, m, lane, r);      // column and row inside the tile
+        if (AUG && mirror) {
+            // a tile of Sigma, written twice: as it is and transposed.  A DIAGONAL tile (mirror == dest) comes out of
+            // the update with its lower-left quadrant missing (the symmetric update skips it): only the elements
+            // on and above the diagonal are stored, each also at its mirror position.
+            if (mirror != dest || ic <= jc) {
+                dest[(size_t)ic * ldd + (size_t)jc] = out;
+                mirror[(size_t)jc * ldd + (size_t)ic] = out;
+            }
+            return;
+        }
+        dag_st(&dest[(size_t)ic * ldd + (size_t)jc], out);
+    };
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         double xi[4][C];
         int ii[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            ii[r] = k0 + (ROWMAP ? 16 * tile_rowblock(wr, m) + (lane >> 4) + 4 * r : tile_row(wr, m, lane, r));
+            ii[r] = row_index(m, r);
             if (rowcross) {
-                const int e = ii[r] - Npad;        // the same index map as the columns: equal indices = the diagonal of A
+                const int e = -1 - ii[r];
 #pragma unroll
-                for (int c = 0; c < C; ++c) xi[r][c] = (e < aug.R) ? aug.rowx[(size_t)c * aug.Rpad + e] : 0.0;
-                ii[r] = (e < aug.R) ? -1 - e : 0x7ffffffe;
+                for (int c = 0; c < C; ++c) xi[r][c] = (ii[r] < 0) ? aug.rowx[(size_t)c * aug.Rpad + e] : 0.0;
             } else {
 #pragma unroll
                 for (int c = 0; c < C; ++c) xi[r][c] = (ii[r] < N) ? lw[(size_t)c * N + ii[r]] : 0.0;
@@ -492,41 +591,39 @@ __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = ii[r], j = jj[n];
-                double v;
-                if (i < N && j < N) {
-                    if (i == j) {
-#pragma clang fp contract(off)
-                        if (rowcross) {
-                            v = aug.diag[-1 - i];
-                        } else {
-                            const double sg = sigma[i];
-                            v = dsum + sg * sg;
-                        }
-                    } else {
-                        v = kv[r];
-                    }
-                } else {
-                    v = (i == j) ? 1.0 : 0.0;
-                }
-                const int jc = tile_col(wc, n, lane);                          // column inside the tile
-                const int ic = ROWMAP ? 16 * tile_rowblock(wr, m) + (lane >> 4) + 4 * r : tile_row(wr, m, lane, r);   // row inside the tile
-                const double out = scale * v - t.acc[m][n][r];
-                if (INPLACE) {
-                    t.acc[m][n][r] = out;
-                } else if (AUG && mirror) {
-                    // a tile of Sigma, written twice: as it is and transposed.  A DIAGONAL tile (mirror == dest) comes out of
-                    // the update with its lower-left quadrant missing (the symmetric update skips it): only the elements
-                    // on and above the diagonal are stored, each also at its mirror position.
-                    if (mirror != dest || ic <= jc) {
-                        dest[(size_t)ic * ldd + (size_t)jc] = out;
-                        mirror[(size_t)jc * ldd + (size_t)ic] = out;
-                    }
-                } else {
-                    dag_st(&dest[(size_t)ic * ldd + (size_t)jc], out);
-                }
+                const double v = (i < N && j < N) ? kv[r] : 0.0;
+                // (an element of the diagonal is written here like its neighbours and again, with its value, by the pass below:
+                // two stores of one lane to one address arrive in program order, and no exec-masked store sits in this loop)
+                put(m, n, r, scale * v - t.acc[m][n][r]);
             }
         }
     }
+    // the diagonal of the matrix: sigma_i^2 + sum of amp^2 (the prior variance for a row of the Schur complement), 1 in
+    // the identity padding -- the 16 loads first, then the stores
+    if (k0 == j0 && wr == wc) {
+        double dg[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = row_index(m, r);
+                if (rowcross) {
+                    dg[m][r] = (i < 0) ? aug.diag[-1 - i] : 1.0;      // (rows and columns beyond R never compare equal)
+                } else {
+                    const double sg = (i < N) ? sigma[i] : 0.0;
+                    {
+#pragma clang fp contract(off)
+                        dg[m][r] = (i < N) ? dsum + sg * sg : 1.0;
+                    }
+                }
+            }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (row_index(m, r) == jj[m]) put(m, m, r, scale * dg[m][r] - t.acc[m][m][r]);
+    }
+    (void)to_slot;
 }
 
 // the accumulators as a tile in memory (after dag_store_updated<.., INPLACE>): the same element map and mirror rule
@@ -561,7 +658,9 @@ __device__ __forceinline__ void dag_store_tile(const Tile& t, double* __restrict
 // the store routine free of them (a load per element between its stores serialised on the memory
 // latency: 64 round trips, 44 us per tile).  A chain's final calls this BEFORE it waits for the block row
 // above -- its PARTs ran ahead -- so the running sum is read off the row-to-row path.
-template <bool ROWMAP = false>
+// BATCH: through tile_load16 (gemm_core.hpp) -- four round trips to memory per tile where hipcc schedules this loop as 64
+// (behind an update, and in dag_special: 25-29 us per partial tile, tools/predict_timeline.py).
+template <bool ROWMAP = false, bool BATCH = false>
 __device__ __forceinline__ void dag_sub_partials(Tile& t, const double* __restrict__ prev, int n_prev)
 {
     // (opaque copy of the thread id, as in dag_store_updated: otherwise the 64 per-lane element offsets below are
@@ -572,6 +671,20 @@ __device__ __forceinline__ void dag_sub_partials(Tile& t, const double* __restri
     const int wr = wave >> 1, wc = wave & 1;
     for (int sidx = 0; sidx < n_prev; ++sidx) {
         const double* __restrict__ ps = prev + (size_t)sidx * NB * NB;
+#ifndef PSOAP_NO_BATCH_FOLD
+        if constexpr (BATCH && !ROWMAP) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                double v[4][4];          // [n][r]
+                tile_load16(ps + (size_t)tile_row(wr, m, lane, 0) * NB + (size_t)tile_col(wc, 0, lane), (size_t)4 * NB, v);
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t.acc[m][n][r] -= v[n][r];
+            }
+            continue;
+        }
+#endif
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -989,7 +1102,7 @@ __device__ __attribute__((noinline, not_tail_called)) void dag_special(lds_speci
     if (n_wait > 0) {
         dag_wait_ge(arrive_ctr, n_wait, ctl, 4u);
         if (tl && threadIdx.x == 0) tl[1] = __builtin_amdgcn_s_memrealtime();
-        dag_sub_partials(t, prev, preload ? 1 : n_prev);
+        dag_sub_partials<false, true>(t, prev, preload ? 1 : n_prev);
     }
     // the covariance goes in BEFORE the wait for the row above (the accumulators then hold -(tile) during the update);
     // the final of a chain has nothing to add -- the chain's first part carried K
@@ -1878,7 +1991,7 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
         if (preload) {
             // the chain ran ahead (its PARTs need older block rows): normally no wait at all
             dag_wait_ge(&arrive_l[task.ctr], n_wait, ctl, 4u);
-            dag_sub_partials(t, prev, 1);
+            dag_sub_partials<false, true>(t, prev, 1);
             n_prev = 0;
         }
         // (DAG_WAITNEXT on a DIAG task: its last panel needs only the tile right of the diagonal above; on an OFF task
@@ -1890,7 +2003,7 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
         if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 5] = __builtin_amdgcn_s_memrealtime();
         if (!preload && n_wait > 0) dag_wait_ge(&arrive_l[task.ctr], n_wait, ctl, 4u);
         if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 6] = __builtin_amdgcn_s_memrealtime();
-        dag_sub_partials(t, prev, n_prev);
+        dag_sub_partials<false, true>(t, prev, n_prev);
         {
             GpDev g;
             load_gp(mat.gp, C, g);
@@ -1912,11 +2025,14 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             // that the exp() evaluations are off the critical row-to-row path (the final of a chain runs
             // right after the block row above completes; its PARTs ran ahead)
             const bool carries_k = chain ? (is_part ? task.S == 0 : task.S <= 1) : !is_part;
-            dag_store_updated<C, AUG>(t, dest, ldd, k0, j0, mat.lw, g, dsum, mat.sigma, N, carries_k ? 1.0 : 0.0, Npad, aug,
-                                      mirror);
+            if (tlog_l && is_part && threadIdx.x == 0) tlog_l[ticket * 8 + 1] = __builtin_amdgcn_s_memrealtime();   // folded
+            dag_store_updated<C, AUG, false, false, !STREAM>(t, dest, ldd, k0, j0, mat.lw, g, dsum, mat.sigma, N, carries_k ? 1.0 : 0.0, Npad, aug,
+                                      mirror, is_part);
         }
         if (is_part) {
+            if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 2] = __builtin_amdgcn_s_memrealtime();              // stores issued
             dag_drain();
+            if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 4] = __builtin_amdgcn_s_memrealtime();              // drained
             if (threadIdx.x == 0) {
                 dag_release_fence();
                 __hip_atomic_fetch_add(&arrive_l[task.ctr], 1, PSOAP_RLX_AGENT);

@@ -352,4 +352,28 @@ __device__ __forceinline__ void tile_gemm_tn_lower_balanced(Tile& t, const doubl
 __device__ __forceinline__ int tile_row(int wr, int m, int lane, int r) { return wr * 64 + m * 16 + (lane >> 4) + 4 * r; }
 __device__ __forceinline__ int tile_col(int wc, int n, int lane) { return wc * 64 + n * 16 + (lane & 15); }
 
+// The 16 elements a lane holds of one 16-row block of a tile in memory -- rows 4 apart (r = 0 .. 3, `row4` doubles from one
+// to the next), column blocks 16 doubles apart (n = 0 .. 3) -- as ONE statement: sixteen loads and the wait for them.
+// Behind a K-loop hipcc has two or three vector registers to spare and schedules the plain C++ loop as 64 load / wait / use
+// round trips to memory per tile (29 us of a partial tile's hand-over, tools/predict_timeline.py; the read-modify-write
+// epilogues of the staged kernels likewise); a statement it cannot split costs four.  v[n][r].
+__device__ __forceinline__ void tile_load16(const double* p0, size_t row4, double (&v)[4][4])
+{
+    const double *p1 = p0 + row4, *p2 = p1 + row4, *p3 = p2 + row4;
+    asm volatile("global_load_dwordx2 %0, %16, off\n\tglobal_load_dwordx2 %1, %17, off\n\t"
+                 "global_load_dwordx2 %2, %18, off\n\tglobal_load_dwordx2 %3, %19, off\n\t"
+                 "global_load_dwordx2 %4, %16, off offset:128\n\tglobal_load_dwordx2 %5, %17, off offset:128\n\t"
+                 "global_load_dwordx2 %6, %18, off offset:128\n\tglobal_load_dwordx2 %7, %19, off offset:128\n\t"
+                 "global_load_dwordx2 %8, %16, off offset:256\n\tglobal_load_dwordx2 %9, %17, off offset:256\n\t"
+                 "global_load_dwordx2 %10, %18, off offset:256\n\tglobal_load_dwordx2 %11, %19, off offset:256\n\t"
+                 "global_load_dwordx2 %12, %16, off offset:384\n\tglobal_load_dwordx2 %13, %17, off offset:384\n\t"
+                 "global_load_dwordx2 %14, %18, off offset:384\n\tglobal_load_dwordx2 %15, %19, off offset:384\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0][0]), "=&v"(v[0][1]), "=&v"(v[0][2]), "=&v"(v[0][3]), "=&v"(v[1][0]), "=&v"(v[1][1]),
+                   "=&v"(v[1][2]), "=&v"(v[1][3]), "=&v"(v[2][0]), "=&v"(v[2][1]), "=&v"(v[2][2]), "=&v"(v[2][3]),
+                   "=&v"(v[3][0]), "=&v"(v[3][1]), "=&v"(v[3][2]), "=&v"(v[3][3])
+                 : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+                 : "memory");
+}
+
 }  // namespace psoap

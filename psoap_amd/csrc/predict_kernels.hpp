@@ -88,14 +88,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_sub(const double* __re
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 4; ++m) {
+        double* p0 = S + (size_t)(NB * ti + tile_row(wr, m, lane, 0)) * lds + NB * tj + tile_col(wc, 0, lane);
+        double v[4][4];
+        tile_load16(p0, (size_t)4 * lds, v);
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double* p = S + (size_t)(NB * ti + tile_row(wr, m, lane, r)) * lds + NB * tj + tile_col(wc, n, lane);
-                *p = *p - t.acc[m][n][r];
-            }
+            for (int r = 0; r < 4; ++r) p0[(size_t)4 * r * lds + 16 * n] = v[n][r] - t.acc[m][n][r];
+    }
 }
 
 // Symmetric form for predict's Sigma = A - W^T W (returned in full, covariance.py:143,251): one workgroup
@@ -116,17 +117,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_sub_sym(const double* 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < 4; ++m) {
+        double* p0 = S + (size_t)(NB * ti + tile_row(wr, m, lane, 0)) * lds + NB * tj + tile_col(wc, 0, lane);
+        double c[4][4];
+        tile_load16(p0, (size_t)4 * lds, c);
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = tile_row(wr, m, lane, r), col = tile_col(wc, n, lane);
-                double* p = S + (size_t)(NB * ti + row) * lds + NB * tj + col;
-                const double v = *p - t.acc[m][n][r];
-                *p = v;
+                const double v = c[n][r] - t.acc[m][n][r];
+                p0[(size_t)4 * r * lds + 16 * n] = v;
                 if (ti != tj) S[(size_t)(NB * tj + col) * lds + NB * ti + row] = v;
             }
+    }
 }
 
 // partial[s][q] = sum_{k in slab s} W[k][q] z[k];  slabs of 256 rows, 128 columns per block

@@ -117,6 +117,19 @@ def test_build_falls_back_when_the_default_flags_show_the_defect(tmp_path, monke
         build.compile_checked([], str(tmp_path / "all"), scan=lambda text: asmcheck.scan_exec_restore(faulty))
 
 
+def test_exec_restore_scanner_tells_a_narrowed_mask_from_a_restored_one():
+    """`s_mov_b64 exec, s[A:B]` re-enables lanes only when s[A:B] is a saved mask; hipcc also spells the START of a masked
+    region that way (copy exec, and it with the condition, move it back): no lane comes back there, and the vector writes
+    ahead of it ran under the mask the block was entered with."""
+    from psoap_amd import asmcheck
+    head = "_Zf:\n\ts_cbranch_execz .LBB0_1\n.LBB0_1:\n\tv_mov_b32 v1, v2\n"
+    narrowed = head + "\ts_mov_b64 s[0:1], exec\n\ts_and_b64 s[14:15], s[0:1], s[14:15]\n\ts_mov_b64 exec, s[14:15]\n"
+    restored = head + "\ts_mov_b64 exec, s[14:15]\n"
+    rewritten = head + "\ts_mov_b64 s[0:1], exec\n\ts_and_b64 s[14:15], s[0:1], s[14:15]\n\ts_mov_b64 s[14:15], s[2:3]\n\ts_mov_b64 exec, s[14:15]\n"
+    assert asmcheck.scan_exec_restore(narrowed) == []
+    assert len(asmcheck.scan_exec_restore(restored)) == 1 and len(asmcheck.scan_exec_restore(rewritten)) == 1
+
+
 def test_exec_restore_scanner_flags_the_faulting_join_block():
     """The join block of k_chol_dag<3, true, true> from the build that faulted on the GPU (rocgdb session in
     profiles/r3_lat_fault_rocgdb.txt): ten vector writes -- `v_mov_b32 v172, v244` among them -- ahead of the

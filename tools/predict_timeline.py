@@ -54,6 +54,13 @@ for name, sel in (("PARTs of B tiles", parts & data & (tasks["q"] < P)), ("PARTs
     pn = panels[sel].mean() if sel.any() else 0.0
     print(f"  {name:28s} mean {pn:4.1f} panels: update {kl:6.1f} us ({kl / max(pn, 1e-9):5.1f} us per panel; 27.3 at this workgroup's share "
           f"of the peak), predecessor's tile {fold:5.1f} us, fold + store + publish {st:5.1f} us")
+# the hand-over in four pieces (stamps 1 = predecessor's tile folded in, 2 = stores issued, 4 = stores drained + barrier)
+k1, k2, k4 = (log[:, i].astype(np.float64) / 100.0 - t0 for i in (1, 2, 4))
+sub = parts & (log[:, 1] > 0) & (log[:, 2] > 0) & (log[:, 4] > 0)
+for name, sel in (("PARTs with a predecessor", sub & (tasks["S"] > 0)), ("first PARTs of a chain", sub & (tasks["S"] == 0))):
+    n = max(1, int(sel.sum()))
+    print(f"  {name:28s} {int(sel.sum()):6d}: fold {(k1[sel] - k6[sel]).sum() / n:5.1f} us, stores issued {(k2[sel] - k1[sel]).sum() / n:5.1f}, "
+          f"drained {(k4[sel] - k2[sel]).sum() / n:5.1f}, release + arrive {(end[sel] - k4[sel]).sum() / n:5.1f}")
 dend = np.array([end[ok & (ty == 1) & (tasks["q"] == q)].max() for q in range(P)])
 print("diag end (us):", " ".join(f"{x:.0f}" for x in dend))
 print("row period  :", " ".join(f"{b - a:.0f}" for a, b in zip(dend[:-1], dend[1:])))
