@@ -449,10 +449,12 @@ __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ 
     static_assert(INPLACE || !ROWMAP, "tiles that go to memory use the plain accumulator map");
     if constexpr (FAST && !INPLACE) {
         if (to_slot && scale == 0.0) {
-            // 0 * K - acc, and K >= 0 is finite, so 0.0 - acc is the same value bit for bit: 64 stores back to back.  (The
-            // general routine below is ~100 KB of straight-line code whose covariance blocks such a task jumps over, 16-64
-            // far branches per tile through the instruction cache: 33 us for 64 stores with no wait between them,
-            // 4.5 us here -- tools/predict_timeline.py.)
+            // 0 * K - acc, and K >= 0 is finite, so 0.0 - acc is the same value bit for bit: 64 stores back to back, four
+            // instructions each.  (In the general routine below such a task jumps over the covariance blocks and still
+            // executes ~40 vector instructions per element -- index tests, selects, 64-bit address arithmetic -- each of
+            // which, beside a neighbour that streams MFMAs, waits for a gap in that stream: 33 us for its 64 stores with no
+            // memory wait between them, 4.5 us here -- tools/predict_timeline.py.  Not instruction fetch: SQC_ICACHE_MISSES
+            // is 0.02 % of the requests.)
             int tid_ = threadIdx.x;
             asm volatile("" : "+v"(tid_));
             const int lane = tid_ & 63, wave = tid_ >> 6;
@@ -2029,6 +2031,7 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             dag_store_updated<C, AUG, false, false, !STREAM>(t, dest, ldd, k0, j0, mat.lw, g, dsum, mat.sigma, N, carries_k ? 1.0 : 0.0, Npad, aug,
                                       mirror, is_part);
         }
+        if (tlog_l && !is_part && threadIdx.x == 0) tlog_l[ticket * 8 + 4] = __builtin_amdgcn_s_memrealtime();     // a final's stores issued
         if (is_part) {
             if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 2] = __builtin_amdgcn_s_memrealtime();              // stores issued
             dag_drain();

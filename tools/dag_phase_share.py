@@ -44,3 +44,8 @@ for name, v in (("update K-loops + dependency waits", kloop), ("wait for / fold 
     print(f"  {name:58s} {v/1e3:9.1f} ms  {100*v/tot:5.1f} %")
 n_fin = fin.sum()
 print(f"  per final tile: store routine {store_fin/n_fin:.1f} us, strip solve phase {solve/max(1,off.sum()):.1f} us; per PART: store {store_part/max(1,part.sum()):.1f} us")
+# the finals' store phase in two pieces (stamp 4 = the tile's last store issued by wave 0; 1 = drained + barrier)
+issued = (log[:, 4] > log[:, 6]) & fin
+if issued.any():
+    print(f"  finals: covariance + 64 stores issued {(log[:, 4] - log[:, 6])[issued].mean():.1f} us, drain + barrier {(log[:, 1] - log[:, 4])[issued].mean():.1f} us"
+          f" (of {int(issued.sum())} tasks)")
