@@ -33,7 +33,7 @@ import numpy as np
 
 _HDR = struct.Struct("<Q")
 WINDOW_S = 0.002          # how long a request waits for the others of its iteration (only while others are expected)
-RECENT_S = 0.25           # a client counts as "expected" while its last request is at most this old
+RECENT_S = 2.0            # a client counts as "expected" while its last request is at most this old (an idle one costs the others WINDOW_S)
 
 
 # ------------------------------------------------------------------------------------------------ framing
