@@ -141,6 +141,51 @@ def scan_exec_restore(text: str):
     return hits
 
 
+def scan_serial_loads(text: str, min_run: int = 16):
+    """-> {function: [(line, length), ...]}: runs of at least ``min_run`` global / flat loads each of which is followed by
+    ``s_waitcnt vmcnt(0)`` before the next load is issued -- a tile read element by element, one round trip to memory per
+    element.  hipcc schedules a plain C++ loop over a tile that way wherever it has only a few vector registers to spare
+    (behind a K-loop); rounds 1-5 carried five such loops -- the fold of a partial tile (27 us per tile, 52 round trips on the
+    row-to-row chain of every single evaluation) and the read-modify-write epilogues of the staged kernels -- until
+    tile_load16 (gemm_core.hpp).  A performance defect: reported by the tests, not fatal for a build."""
+    code = [ln.split(";")[0].strip() for ln in text.split("\n")]
+    out = {}
+    cur = None
+    run_start, run_len, last_hit = 0, 0, -100
+    load = re.compile(r"^(global|flat)_load_dword")
+
+    def close():
+        nonlocal run_len
+        if cur is not None and run_len >= min_run:
+            out.setdefault(short(cur), []).append((run_start + 1, run_len))
+        run_len = 0
+
+    for n, s in enumerate(code):
+        m = _LABEL.match(s)
+        if m and not m.group(1).startswith(".L"):
+            close()
+            cur = m.group(1)
+            continue
+        if not load.match(s) or "lds" in s:
+            continue
+        waited = False
+        for k in range(n + 1, min(n + 8, len(code))):
+            if load.match(code[k]):
+                break
+            if code[k].startswith("s_waitcnt") and "vmcnt(0)" in code[k]:
+                waited = True
+                break
+        if not waited:
+            continue
+        if n - last_hit > 14:
+            close()
+            run_start = n
+        run_len += 1
+        last_hit = n
+    close()
+    return out
+
+
 def scan_hot_loops(text: str):
     """-> {function: (number of 64-MFMA K-loop stage blocks, scratch accesses inside them)} for every k_chol_dag kernel
     and every dag_special<C, AUG> (the out-of-line routine that runs the following strip-solve tasks, K-loops included)"""

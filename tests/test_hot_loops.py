@@ -117,6 +117,20 @@ def test_build_falls_back_when_the_default_flags_show_the_defect(tmp_path, monke
         build.compile_checked([], str(tmp_path / "all"), scan=lambda text: asmcheck.scan_exec_restore(faulty))
 
 
+def test_no_tile_is_read_one_round_trip_per_element():
+    """No kernel of the library reads a tile as a run of load / `s_waitcnt vmcnt(0)` pairs (asmcheck.scan_serial_loads): the
+    shape hipcc gives a plain loop over a tile behind a K-loop, 27 us per partial tile until round 5.  The
+    scanner is checked on that shape itself."""
+    from psoap_amd import asmcheck, build
+    build.build()
+    with open(build.ASM_PATH) as fh:
+        assert asmcheck.scan_serial_loads(fh.read()) == {}
+    pair = "\tglobal_load_dwordx2 v[0:1], v[2:3], off\n\ts_waitcnt vmcnt(0)\n\tv_add_f64 v[4:5], v[4:5], -v[0:1]\n"
+    assert asmcheck.scan_serial_loads("_Zk:\n" + 20 * pair) == {"_Zk": [(2, 20)]}
+    batch = 16 * "\tglobal_load_dwordx2 v[0:1], v[2:3], off\n" + "\ts_waitcnt vmcnt(0)\n"
+    assert asmcheck.scan_serial_loads("_Zk:\n" + 4 * batch) == {}
+
+
 def test_exec_restore_scanner_tells_a_narrowed_mask_from_a_restored_one():
     """`s_mov_b64 exec, s[A:B]` re-enables lanes only when s[A:B] is a saved mask; hipcc also spells the START of a masked
     region that way (copy exec, and it with the condition, move it back): no lane comes back there, and the vector writes
