@@ -619,11 +619,17 @@ __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ 
                     }
                 }
             }
+        // (the 16 values before the first conditional store: one wait for the loads, outside the branches -- hipcc otherwise
+        // waits inside every one of them, and each such wait covers the store of the branch before)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dg[m][r] = scale * dg[m][r] - t.acc[m][m][r];
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (row_index(m, r) == jj[m]) put(m, m, r, scale * dg[m][r] - t.acc[m][m][r]);
+                if (row_index(m, r) == jj[m]) put(m, m, r, dg[m][r]);
     }
     (void)to_slot;
 }
