@@ -437,18 +437,23 @@ struct DagMat {
 
 // INPLACE: the result replaces the accumulators instead of going to memory (the strip solve that follows works on the
 // tile in registers: dag_pss)
-// FAST: a task that adds no covariance and writes a workspace slot (every PART but a chain's first) stores its partial
-// sum through a loop of its own (see there).
+#ifdef PSOAP_FAST_STREAM
+#define DAG_FAST_STORE(stream) true
+#else
+#define DAG_FAST_STORE(stream) (!(stream))
+#endif
+// FAST: a task that adds no covariance (every PART but a chain's first, and the final of a chain) stores its tile through a
+// loop of its own (see there).
 template <int C, bool AUG, bool INPLACE = false, bool ROWMAP = false, bool FAST = false>
 __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ dest, size_t ldd, int k0, int j0,
                                                   const double* __restrict__ lw, const GpDev& g, double dsum,
                                                   const double* __restrict__ sigma, int N, double scale,
                                                   int Npad, const DagAug& aug, double* __restrict__ mirror = nullptr,
-                                                  bool to_slot = false)
+                                                  bool plain = false)
 {
     static_assert(INPLACE || !ROWMAP, "tiles that go to memory use the plain accumulator map");
     if constexpr (FAST && !INPLACE) {
-        if (to_slot && scale == 0.0) {
+        if (plain && scale == 0.0) {        // (plain: a workspace slot or a tile of the matrix -- no mirror image)
             // 0 * K - acc, and K >= 0 is finite, so 0.0 - acc is the same value bit for bit: 64 stores back to back, four
             // instructions each.  (In the general routine below such a task jumps over the covariance blocks and still
             // executes ~40 vector instructions per element -- index tests, selects, 64-bit address arithmetic -- each of
@@ -465,7 +470,7 @@ __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ 
                 for (int n = 0; n < 4; ++n)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        dag_st(&dest[(size_t)tile_row(wr, m, lane, r) * NB + (size_t)tile_col(wc, n, lane)], 0.0 - t.acc[m][n][r]);
+                        dag_st(&dest[(size_t)tile_row(wr, m, lane, r) * ldd + (size_t)tile_col(wc, n, lane)], 0.0 - t.acc[m][n][r]);
             return;
         }
     }
@@ -631,7 +636,7 @@ __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ 
             for (int r = 0; r < 4; ++r)
                 if (row_index(m, r) == jj[m]) put(m, m, r, dg[m][r]);
     }
-    (void)to_slot;
+    (void)plain;
 }
 
 // the accumulators as a tile in memory (after dag_store_updated<.., INPLACE>): the same element map and mirror rule
@@ -2034,8 +2039,8 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             // right after the block row above completes; its PARTs ran ahead)
             const bool carries_k = chain ? (is_part ? task.S == 0 : task.S <= 1) : !is_part;
             if (tlog_l && is_part && threadIdx.x == 0) tlog_l[ticket * 8 + 1] = __builtin_amdgcn_s_memrealtime();   // folded
-            dag_store_updated<C, AUG, false, false, !STREAM>(t, dest, ldd, k0, j0, mat.lw, g, dsum, mat.sigma, N, carries_k ? 1.0 : 0.0, Npad, aug,
-                                      mirror, is_part);
+            dag_store_updated<C, AUG, false, false, DAG_FAST_STORE(STREAM)>(t, dest, ldd, k0, j0, mat.lw, g, dsum, mat.sigma, N, carries_k ? 1.0 : 0.0, Npad, aug,
+                                      mirror, !(AUG && ttype == DAG_SCHUR));
         }
         if (tlog_l && !is_part && threadIdx.x == 0) tlog_l[ticket * 8 + 4] = __builtin_amdgcn_s_memrealtime();     // a final's stores issued
         if (is_part) {

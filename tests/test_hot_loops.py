@@ -69,9 +69,11 @@ def test_single_evaluation_kernels_keep_their_chain_phases_in_registers():
     # the kernels for two workgroups per compute unit have 256 registers: their chain phases do spill (recorded, not bounded)
     narrow = {k: v for k, v in res.items() if k.startswith("k_chol_dag") and not k.endswith(",wide>")}
     assert all(v["agpr_count"] == 0 and v["vgpr_count"] == 256 for v in narrow.values()), narrow
-    # ... but the headline kernels (throughput scheme, SB1 / SB2) stay clean
+    # ... but the headline kernels (throughput scheme, SB1 / SB2) stay all but clean (none of it inside a K-loop stage: the
+    # test above; late round 5: 8 VGPRs / 36 B in the SB2 batch kernel, with which it runs 1.1 % FASTER than with 4 / 20 --
+    # profiles/r5_handover.txt)
     for k in ("k_chol_dag<1,false,false>", "k_chol_dag<2,false,false>", "k_chol_dag<1,false,false,stream>", "k_chol_dag<2,false,false,stream>"):
-        assert narrow[k]["vgpr_spill_count"] <= 4 and narrow[k]["private_segment_fixed_size"] <= 32, (k, narrow[k])
+        assert narrow[k]["vgpr_spill_count"] <= 8 and narrow[k]["private_segment_fixed_size"] <= 48, (k, narrow[k])
 
 
 @needs_hipcc
