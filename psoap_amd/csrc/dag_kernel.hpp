@@ -608,6 +608,9 @@ __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ 
     // the diagonal of the matrix: sigma_i^2 + sum of amp^2 (the prior variance for a row of the Schur complement), 1 in
     // the identity padding -- the 16 loads first, then the stores
     if (k0 == j0 && wr == wc) {
+#ifdef PSOAP_DIAG_PASS_WAIT
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the loop's stores are in memory before the pass stores
+#endif
         double dg[4][4];
 #pragma unroll
         for (int m = 0; m < 4; ++m)

@@ -29,7 +29,7 @@ while time.time() < t_end:
                 n_launch += 1
     # streamed evaluation: many matrices through the lanes of one resident launch, two submissions in flight, changing
     # batch sizes -- every result bit-identical to the first of its kind
-    for cfg, B, scheme in ((1, 32, -1), (3, 16, 0), (2, 8, -1), (1, 8, 2)):
+    for cfg, B, scheme in ((1, 32, -1), (3, 16, 0), (2, 8, -1), (1, 8, 1), (5, 8, -1)):
         ch = syn.make_config_chunk(cfg)
         c = ch.n_components
         gps = syn.make_walkers(c, B, seed=cfg)
