@@ -299,7 +299,9 @@ int psoap_chunk_dag_tasklog(psoap_chunk *h, unsigned long long *out, long long m
  * While a stream is open the handle's batch entry points (psoap_batch_*, psoap_lnlike*) are refused -- the matrix
  * workspaces belong to the resident launch -- and other launches on the device wait until it leaves (it does so by
  * itself once nothing has been in flight for PSOAP_STREAM_IDLE_MS, default 20 ms, and comes back on the next submit). */
-/* c: number of components of every submission; scheme: -1 automatic (by lanes and N), 0 throughput, 1 latency, 2 following */
+/* c: number of components of every submission; scheme: -1 automatic (by lanes and N: 0 or 1), 0 throughput, 1 latency.
+ * 2 (following) is refused: through a resident launch it returns a rare wrong value (late round 5, LABNOTES 12); the
+ * launch-per-step entry points keep using it for single evaluations and small batches. */
 int psoap_stream_open(psoap_chunk *h, int c, int lanes, int scheme);
 /* n proposals -- lwl (n, c, N), gp (n, 2c) as psoap_batch_upload -- into n free lanes; tickets[n] identify them.
  * Fails when fewer than n lanes are free. */
