@@ -36,6 +36,20 @@ int psoap_microbench_mix(int device, int mode, int iters_mfma, int iters_valu, d
  * the shipped routine, 1-3 = timing ablations (no in-wave 16 x 16 factorisation / no MFMA phases / no W output). */
 int psoap_microbench_potrf(int device, int ablate, double *usec);
 
+/* Coherence litmus tests between two XCDs of the device (round 6; psoap_amd/csrc/litmus_kernels.hpp, tools/litmus.py):
+ * what a reader wave sees of a 256-byte unit a writer wave on another XCD (same_xcd = 0) or on its own (1) has just
+ * rewritten and announced through returning atomics.  plant_mode: how the reader touched the unit before the write (0 not
+ * at all, 1 sc1 load, 2 plain load, 3 acquire + plain load); writer_mode: 0 sc1 stores, 1 plain stores + release fence,
+ * 2 sc0 sc1 stores; reader_mode: 0 sc1 load, 1 acquire + sc1 load, 2 acquire + plain load, 3 returning atomic, 4 plain
+ * load, 5 acquire + LDS-DMA load, 6 sc0 sc1 load; background != 0: the rest of the launch streams 512 MiB through the
+ * L2s.  out8: iterations, stale plants, stale reads, reads that never turned fresh, longest / summed 100 MHz ticks until
+ * fresh, XCC id of the reader, of the writer. */
+int psoap_litmus_l2(int device, int plant_mode, int writer_mode, int reader_mode, int same_xcd, int iters, int background,
+                    unsigned long long *out8);
+/* Does the write-back of a line one XCD has partly rewritten with plain stores overwrite what another XCD wrote through
+ * to the line's other words meanwhile?  out8[2]: iterations in which it did, out8[1]: in which the plain-stored word was lost. */
+int psoap_litmus_writeback(int device, int iters, unsigned long long *out8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -135,6 +135,8 @@ BENCH_SIGNATURES = {
     "psoap_microbench_potrf": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _dp]),
     "psoap_microbench_hbm": (ctypes.c_int, [ctypes.c_int, _dp, _dp]),
     "psoap_microbench_mix": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp]),
+    "psoap_litmus_l2": (ctypes.c_int, [ctypes.c_int] * 7 + [ctypes.POINTER(ctypes.c_ulonglong)]),
+    "psoap_litmus_writeback": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_ulonglong)]),
 }
 
 _lib = None

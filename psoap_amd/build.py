@@ -21,13 +21,13 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libpsoap_gp.so")
 SOURCES = ["psoap_gp.hip"]
 # (microbench_kernels.hpp belongs to the measurement library below, not to the product)
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp") and f != "microbench_kernels.hpp") + \
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp") and f not in ("microbench_kernels.hpp", "litmus_kernels.hpp")) + \
     [os.path.join("..", "..", "include", "psoap_gp.h")]
 # The measurement library (include/psoap_bench.h): micro-benchmarks and the exp() self-check that bench.py, tools/ and
 # one GPU test load.  Product kernels only in libpsoap_gp.so.
 BENCH_LIB_PATH = os.path.join(CSRC, "libpsoap_bench.so")
 BENCH_SOURCES = ["psoap_bench.hip"]
-BENCH_HEADERS = ["common.hpp", "gemm_core.hpp", "potrf_blocked.hpp", "fill_kernels.hpp", "microbench_kernels.hpp",
+BENCH_HEADERS = ["common.hpp", "gemm_core.hpp", "potrf_blocked.hpp", "fill_kernels.hpp", "microbench_kernels.hpp", "litmus_kernels.hpp",
                  os.path.join("..", "..", "include", "psoap_bench.h")]
 BENCH_HASH_PATH = BENCH_LIB_PATH + ".srchash"
 HASH_PATH = LIB_PATH + ".srchash"                      # JSON: what the library beside it was built from

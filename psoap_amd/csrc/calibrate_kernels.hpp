@@ -139,7 +139,7 @@ inline int calibrate_run(const CalibInputs& in, double* fl_cor, double* X, int* 
     CAL_TRY(hipMalloc(&dK2, sizeof(double) * (size_t)Mpad * ld2));
     CAL_TRY(hipMalloc(&dW, sizeof(double) * NB * NB));
     CAL_TRY(hipMalloc(&dR, sizeof(double) * (size_t)std::max(Npad, Mpad)));
-    CAL_TRY(hipMalloc(&dAcc, sizeof(MatAcc)));
+    CAL_TRY(hipMalloc(&dAcc, sizeof(MatAcc) * (ACC_ROWS + 1)));      // block-row records + their total
     CAL_TRY(hipMalloc(&dVec, sizeof(double) * (size_t)(3 * M + 2 * N)));    // lwl_cal, fl_cal, sigma_cal, fl_fixed, sigma_fixed
     CAL_TRY(hipMalloc(&dMu, sizeof(double) * Mpad));
     CAL_TRY(hipMalloc(&dM0, sizeof(double) * Mpad));
@@ -190,8 +190,9 @@ inline int calibrate_run(const CalibInputs& in, double* fl_cor, double* X, int* 
         // ---- pass 1
         hipLaunchKernelGGL(k_init_rhs, dim3((Npad + 255) / 256, 1), dim3(256), 0, 0, dR, Npad, N, dFlFix, in.mu, dAcc);
         factor_augmented((hipStream_t)0, dK1, ld1, P1, Mpad / NB, dW, dR, Npad, dAcc);
+        hipLaunchKernelGGL(k_acc_total, dim3(1), dim3(1), 0, 0, dAcc, P1, dAcc + ACC_ROWS);
         CAL_TRY(hipGetLastError());
-        CAL_TRY(hipMemcpy(&hacc, dAcc, sizeof(MatAcc), hipMemcpyDeviceToHost));
+        CAL_TRY(hipMemcpy(&hacc, dAcc + ACC_ROWS, sizeof(MatAcc), hipMemcpyDeviceToHost));
         if (hacc.info != 0.0) { *status = 1; goto done; }
         CAL_TRY(hipMemcpy(dM0, m0.data(), sizeof(double) * M, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_gemv_t_partial, dim3((M + 127) / 128, nslab), dim3(256), 0, 0, dK1 + Npad, ld1, Npad, M, dR, dPart);
@@ -205,8 +206,9 @@ inline int calibrate_run(const CalibInputs& in, double* fl_cor, double* X, int* 
         // ---- pass 2
         hipLaunchKernelGGL(k_init_rhs, dim3((Mpad + 255) / 256, 1), dim3(256), 0, 0, dR, Mpad, M, dMu, 0.0, dAcc);
         factor_augmented((hipStream_t)0, dK2, ld2, P2, 1, dW, dR, Mpad, dAcc);
+        hipLaunchKernelGGL(k_acc_total, dim3(1), dim3(1), 0, 0, dAcc, P2, dAcc + ACC_ROWS);
         CAL_TRY(hipGetLastError());
-        CAL_TRY(hipMemcpy(&hacc, dAcc, sizeof(MatAcc), hipMemcpyDeviceToHost));
+        CAL_TRY(hipMemcpy(&hacc, dAcc + ACC_ROWS, sizeof(MatAcc), hipMemcpyDeviceToHost));
         if (hacc.info != 0.0) { *status = 2; goto done; }
         hipLaunchKernelGGL(k_syrk_sub, dim3(1, 1), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dK2 + Mpad, ld2, Mpad, dG, (size_t)NB);
         CAL_TRY(hipGetLastError());

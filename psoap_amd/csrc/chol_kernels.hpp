@@ -30,7 +30,9 @@ __global__ void k_init_rhs(double* __restrict__ R, int Npad, int N, const double
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < Npad) R[(size_t)b * Npad + i] = (i < N) ? (fl[i] - mu) : 0.0;
-    if (i == 0) acc[b] = MatAcc{0.0, 0.0, 0.0, 0.0};
+    // (the per-block records are all written by the factorisation -- common.hpp, MatAcc; only the LAST one is cleared: the
+    // staged path beyond 254 block rows (N > 32640, kernel boundaries between the diagonal blocks) adds the rest up in it)
+    if (i == 0) acc[(size_t)b * ACC_ROWS + ACC_ROWS - 1] = MatAcc{0.0, 0.0, 0.0, 0.0};
 }
 
 // Left-looking update of block row k0 (tiles j0 = k0 + 128*blockIdx.x), K-loop over the k0 finished rows.
@@ -178,9 +180,16 @@ __global__ __launch_bounds__(512, 2) void k_potrf_diag(double* __restrict__ Kbas
             l += red[0][w];
             q += red[1][w];
         }
-        acc[bidx].logdet_half += l;
-        acc[bidx].quad += q;
-        if (anybad) acc[bidx].info = 1.0;
+        // this block's record; blocks beyond the last record share it (consecutive launches: ordered by kernel boundaries)
+        MatAcc* rec = acc + (size_t)bidx * ACC_ROWS;
+        const int qb = k0 / NB;
+        if (qb < ACC_ROWS - 1) {
+            rec[qb] = MatAcc{l, q, anybad ? 1.0 : 0.0, 0.0};
+        } else {
+            rec[ACC_ROWS - 1].logdet_half += l;
+            rec[ACC_ROWS - 1].quad += q;
+            if (anybad) rec[ACC_ROWS - 1].info = 1.0;
+        }
     }
 }
 
@@ -239,13 +248,33 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trsm_strip(double* __restri
     }
 }
 
+// the sums over a matrix's P block records, in block order (the order every path adds them in: results are bit-identical
+// whichever kernel reports them)
+__host__ __device__ inline MatAcc acc_total(const MatAcc* rec, int P)
+{
+    MatAcc a{0.0, 0.0, 0.0, 0.0};
+    if (P > ACC_ROWS) P = ACC_ROWS;
+    for (int q = 0; q < P; ++q) {
+        a.logdet_half += rec[q].logdet_half;
+        a.quad += rec[q].quad;
+        if (rec[q].info != 0.0) a.info = 1.0;
+    }
+    return a;
+}
+
+// one matrix's totals into a record of their own (the callers that only look at `info`: predict, calibration)
+__global__ void k_acc_total(const MatAcc* __restrict__ rec, int P, MatAcc* __restrict__ out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out = acc_total(rec, P);
+}
+
 // lnp = -0.5 * (z^T z + 2 sum log U_ii)   (covariance.py:329-331); -inf when not positive definite
 __global__ void k_finalize(const MatAcc* __restrict__ acc, double* __restrict__ out, int B,
-                           const int* __restrict__ too_fast)
+                           const int* __restrict__ too_fast, int P)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B) {
-        const MatAcc a = acc[b];
+        const MatAcc a = acc_total(acc + (size_t)b * ACC_ROWS, P);
         // too_fast: an orbit proposal with |v| >= c (sample_parallel.py:186-187)
         const bool bad = (a.info != 0.0) || (too_fast != nullptr && too_fast[b] != 0);
         out[b] = bad ? -INFINITY : -0.5 * (a.quad + 2.0 * a.logdet_half);

@@ -186,7 +186,7 @@ constexpr long long DAG_MAX_SPINS = 2000000;  // x (s_sleep + atomic round trip)
 // is served by the polling XCD's L2 and can return the value from before another XCD's sc1 store
 // indefinitely once the line is resident there; a read-modify-write executes at the memory side and
 // always observes the latest value, so the poll is an atomic add of zero.
-__device__ __forceinline__ int dag_peek(int* flag) { return __hip_atomic_fetch_add(flag, 0, PSOAP_RLX_AGENT); }
+__device__ __forceinline__ int dag_peek(int* flag) { return poll_word(flag); }
 
 // A tile element other workgroups will read (the two store routines every tile goes through: dag_store_updated, dag_trsm)
 // is WRITTEN THROUGH (sc0 sc1) instead of left dirty in the writing XCD's L2 for the release fence to write back: what the
@@ -1298,7 +1298,7 @@ __device__ __forceinline__ void stream_take(const StreamArgs& st, int home, DagC
             if (try_cur) {
                 unsigned int t = 0xffffffffu, L = 0;
                 if (l == 0) {
-                    L = __hip_atomic_fetch_add(&st.dev->cur[xcd].lane, 0u, PSOAP_RLX_AGENT);
+                    L = poll_word(&st.dev->cur[xcd].lane);
                     t = __hip_atomic_fetch_add(&st.lanes[L].next, 1u, PSOAP_RLX_AGENT);
                 }
                 t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
@@ -1311,17 +1311,17 @@ __device__ __forceinline__ void stream_take(const StreamArgs& st, int home, DagC
             }
             // what the wake-up word holds BEFORE the scan: an opening between scan and sleep is then not missed
             unsigned int seen = 0;
-            if (l == 0) seen = __hip_atomic_fetch_add(&st.dev->opens, 0u, PSOAP_RLX_AGENT);
+            if (l == 0) seen = poll_word(&st.dev->opens);
             seen = (unsigned int)__builtin_amdgcn_readfirstlane((int)seen);
             unsigned int v = 0xffffffffu;
-            if (l < (int)st.n_lanes) v = __hip_atomic_fetch_add(&st.lanes[l].next, 0u, PSOAP_RLX_AGENT);
+            if (l < (int)st.n_lanes) v = poll_word(&st.lanes[l].next);
             const unsigned long long m = __ballot(v < st.n_tasks);
             if (m != 0ull) {
                 const unsigned long long mine = m & (0x0101010101010101ull << home);
                 if (mine) {
                     // the cursor's lane ran dry (its matrix is handed out): on to the next lane of this XCD that has tickets
                     unsigned int L = 0;
-                    if (l == 0) L = __hip_atomic_fetch_add(&st.dev->cur[home].lane, 0u, PSOAP_RLX_AGENT);
+                    if (l == 0) L = poll_word(&st.dev->cur[home].lane);
                     L = (unsigned int)__builtin_amdgcn_readfirstlane((int)L);
                     const int start = ((int)L + 8) & 63;
                     const unsigned long long rot = start ? ((mine >> start) | (mine << (64 - start))) : mine;
@@ -1336,7 +1336,7 @@ __device__ __forceinline__ void stream_take(const StreamArgs& st, int home, DagC
                     const int pick = (__builtin_ctzll(rot) + start) & 63;
                     xcd = pick & 7;
                     unsigned int L = 0;
-                    if (l == 0) L = __hip_atomic_fetch_add(&st.dev->cur[xcd].lane, 0u, PSOAP_RLX_AGENT);
+                    if (l == 0) L = poll_word(&st.dev->cur[xcd].lane);
                     L = (unsigned int)__builtin_amdgcn_readfirstlane((int)L);
                     if (!((m >> (L & 63u)) & 1ull) && l == 0)
                         __hip_atomic_store(&st.dev->cur[xcd].lane, (unsigned int)pick, PSOAP_RLX_AGENT);
@@ -1350,9 +1350,9 @@ __device__ __forceinline__ void stream_take(const StreamArgs& st, int home, DagC
             for (;;) {
                 unsigned int o = 0, stop = 0, err = 0;
                 if (l == 0) {
-                    stop = __hip_atomic_fetch_add(&st.dev->stop, 0u, PSOAP_RLX_AGENT);
-                    o = __hip_atomic_fetch_add(&st.dev->opens, 0u, PSOAP_RLX_AGENT);
-                    err = __hip_atomic_fetch_or(&ctl->error, 0u, PSOAP_RLX_AGENT);
+                    stop = poll_word(&st.dev->stop);
+                    o = poll_word(&st.dev->opens);
+                    err = poll_word(&ctl->error);
                 }
                 stop = (unsigned int)__builtin_amdgcn_readfirstlane((int)stop);
                 o = (unsigned int)__builtin_amdgcn_readfirstlane((int)o);
@@ -1408,7 +1408,7 @@ __device__ __forceinline__ void stream_next_lane(const StreamArgs& st, int lane)
             pick = cand;
             break;
         }
-        if (__hip_atomic_fetch_add(&st.lanes[cand].next, 0u, PSOAP_RLX_AGENT) >= st.n_tasks) continue;   // nothing to hand out
+        if (poll_word(&st.lanes[cand].next) >= st.n_tasks) continue;   // nothing to hand out
         if (fallback < 0) fallback = cand;
         const unsigned long long last = cand == lane ? now : __hip_atomic_load(&st.lanes[cand].stamp, PSOAP_RLX_AGENT);
         if (now - last >= (unsigned long long)st.gate) {
@@ -1422,11 +1422,37 @@ __device__ __forceinline__ void stream_next_lane(const StreamArgs& st, int lane)
 
 // The matrix of `lane` is complete: lnprob and the submission number go straight to pinned host memory (thread 0 of the
 // workgroup whose task retired last: stream_retire).
-__device__ __forceinline__ void stream_complete(const StreamArgs& st, int lane, MatAcc* acc)
+// The sums over the matrix's P block records in block order (acc_total, chol_kernels.hpp: the same order, the same bits),
+// read by ONE thread inside a running launch: every word through a returning atomic (rmw_read: the value the memory
+// holds -- a load could be served from a line this XCD's L2 still keeps from the lane's previous matrix), eight records
+// in flight at a time.
+__device__ __forceinline__ MatAcc stream_acc_total(MatAcc* rec, int P)
 {
-    const double lh = __hip_atomic_load(&acc->logdet_half, PSOAP_RLX_AGENT);
-    const double qd = __hip_atomic_load(&acc->quad, PSOAP_RLX_AGENT);
-    const double info = __hip_atomic_load(&acc->info, PSOAP_RLX_AGENT);
+    MatAcc a{0.0, 0.0, 0.0, 0.0};
+    for (int q0 = 0; q0 < P; q0 += 8) {
+        unsigned long long w[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            MatAcc* r = rec + (q0 + u < P ? q0 + u : P - 1);
+            w[u][0] = rmw_read(reinterpret_cast<unsigned long long*>(&r->logdet_half));
+            w[u][1] = rmw_read(reinterpret_cast<unsigned long long*>(&r->quad));
+            w[u][2] = rmw_read(reinterpret_cast<unsigned long long*>(&r->info));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (q0 + u < P) {
+                a.logdet_half += __longlong_as_double((long long)w[u][0]);
+                a.quad += __longlong_as_double((long long)w[u][1]);
+                if (__longlong_as_double((long long)w[u][2]) != 0.0) a.info = 1.0;
+            }
+    }
+    return a;
+}
+
+__device__ __forceinline__ void stream_complete(const StreamArgs& st, int lane, MatAcc* acc, int P)
+{
+    const MatAcc tot = stream_acc_total(acc, P);
+    const double lh = tot.logdet_half, qd = tot.quad, info = tot.info;
     const unsigned long long seq = __hip_atomic_load(&st.lanes[lane].seq, PSOAP_RLX_AGENT);
     const unsigned int fast = __hip_atomic_load(&st.lanes[lane].too_fast, PSOAP_RLX_AGENT);
     const unsigned int taint = __hip_atomic_load(&st.lanes[lane].tainted, PSOAP_RLX_AGENT);
@@ -1444,13 +1470,13 @@ __device__ __forceinline__ void stream_complete(const StreamArgs& st, int lane, 
 // tiles over row block by row block, the diagonal task they feed can be through before they have written their own
 // completion words -- and the host, told too early, resubmits to the lane, whose flags the dispatcher then clears under a
 // straggler's late store (seen as a rare wrong lnprob with eight processes sharing one GPU).
-__device__ __forceinline__ void stream_retire(const StreamArgs& st, int lane, MatAcc* acc)
+__device__ __forceinline__ void stream_retire(const StreamArgs& st, int lane, MatAcc* acc, int P)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's completion words are out
     const unsigned int old = __hip_atomic_fetch_add(&st.lanes[lane].retired, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if (old + 1u == st.n_tasks) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        stream_complete(st, lane, acc);
+        stream_complete(st, lane, acc, P);
     }
 }
 
@@ -1468,7 +1494,7 @@ __device__ __forceinline__ void stream_dispatch(const StreamArgs& st, const DagM
         // adds one: long before the word could wrap (2e7 matrices at N = 6000) it is put back.  Only this workgroup opens
         // lanes, so the exchange cannot undo an opening; a worker's add in between makes it fail, and the next sweep retries.
         if ((++sweep & 4095u) == 0u && tid < (int)st.n_lanes) {
-            unsigned int v = __hip_atomic_fetch_add(&st.lanes[tid].next, 0u, PSOAP_RLX_AGENT);
+            unsigned int v = poll_word(&st.lanes[tid].next);
             if (v >= 0x60000000u)
                 (void)__hip_atomic_compare_exchange_strong(&st.lanes[tid].next, &v, 0x40000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                            __HIP_MEMORY_SCOPE_AGENT);
@@ -1476,8 +1502,8 @@ __device__ __forceinline__ void stream_dispatch(const StreamArgs& st, const DagM
         if (tid == 0) {
             box[0] = __hip_atomic_load(&st.host->head, PSOAP_RLX_SYSTEM);
             box[1] = (unsigned long long)__hip_atomic_load(&st.host->close, PSOAP_RLX_SYSTEM);
-            box[2] = __hip_atomic_fetch_add(&st.dev->completed, 0ull, PSOAP_RLX_AGENT);
-            box[3] = (unsigned long long)__hip_atomic_fetch_or(&ctl->error, 0u, PSOAP_RLX_AGENT);
+            box[2] = poll_word(&st.dev->completed);
+            box[3] = (unsigned long long)poll_word(&ctl->error);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1570,7 +1596,7 @@ __device__ __forceinline__ void stream_dispatch(const StreamArgs& st, const DagM
                 }
                 // r = fl - mu (covariance.py:331), padded with zeros; accumulators, flags and arrival counters cleared
                 for (int i = tid; i < mat.Npad; i += GEMM_THREADS) mat.R[i] = (i < mat.N) ? (st.fl[i] - mu) : 0.0;
-                if (tid == 0) *mat.acc = MatAcc{0.0, 0.0, 0.0, 0.0};
+                // (nothing to clear in mat.acc: every block's record is written by its factorisation -- common.hpp, MatAcc)
                 int* fz = reinterpret_cast<int*>(flags + lane);
                 for (int i = tid; i < (int)(sizeof(MatFlags) / sizeof(int)); i += GEMM_THREADS) fz[i] = 0;
                 int* az = arrive + (size_t)lane * st.ctrs_per_lane;
@@ -1650,7 +1676,7 @@ __device__ __forceinline__ void pool_take(const DagTask* __restrict__ tasks, con
         long long spins = 0;
         auto taken_bit = [&](unsigned int d) -> unsigned int {
             unsigned int w = 0u;
-            if (l == 0) w = __hip_atomic_fetch_or(&pool.taken[d >> 5], 0u, PSOAP_RLX_AGENT);
+            if (l == 0) w = poll_word(&pool.taken[d >> 5]);
             return ((unsigned int)__builtin_amdgcn_readfirstlane((int)w) >> (d & 31u)) & 1u;
         };
         for (;;) {
@@ -1670,7 +1696,7 @@ __device__ __forceinline__ void pool_take(const DagTask* __restrict__ tasks, con
                 if (n_all == 0u) continue;
                 // 1. the head final: handed out in list order, and only once the last part of its chain has been taken
                 unsigned int m = 0u;
-                if (l == 0) m = __hip_atomic_fetch_add(&ctl->queue[g].next, 0u, PSOAP_RLX_AGENT);
+                if (l == 0) m = poll_word(&ctl->queue[g].next);
                 m = (unsigned int)__builtin_amdgcn_readfirstlane((int)m);
                 if (m < n_main) {
                     left = true;
@@ -1693,7 +1719,7 @@ __device__ __forceinline__ void pool_take(const DagTask* __restrict__ tasks, con
                 const unsigned int p0 = lo + n_main, p1 = lo + n_all;       // the pool's positions in order[]
                 if (p0 == p1) continue;
                 unsigned int cur = 0u;
-                if (l == 0) cur = __hip_atomic_fetch_add(&ctl->queue[g].fill[0], 0u, PSOAP_RLX_AGENT);
+                if (l == 0) cur = poll_word(&ctl->queue[g].fill[0]);
                 cur = p0 + (unsigned int)__builtin_amdgcn_readfirstlane((int)cur);
                 if (cur >= p1) continue;
                 left = true;
@@ -1705,7 +1731,7 @@ __device__ __forceinline__ void pool_take(const DagTask* __restrict__ tasks, con
                 if (base >= p1) break;
                 unsigned int word = 0xffffffffu;
                 if (l < 2 && base + 32u * (unsigned int)l < p1)
-                    word = __hip_atomic_fetch_or(&pool.taken[(base >> 5) + (unsigned int)l], 0u, PSOAP_RLX_AGENT);
+                    word = poll_word(&pool.taken[(base >> 5) + (unsigned int)l]);
                 const unsigned int w0 = (unsigned int)__builtin_amdgcn_readlane((int)word, 0);
                 const unsigned int w1 = (unsigned int)__builtin_amdgcn_readlane((int)word, 1);
                 const unsigned int pos = base + (unsigned int)l;
@@ -1737,7 +1763,7 @@ __device__ __forceinline__ void pool_take(const DagTask* __restrict__ tasks, con
                     // the predecessor has been taken (it runs, or is through): the part may start, it waits for the
                     // predecessor's tile only when its own update is done
                     const unsigned int pp = pool.dep[pos];
-                    ready = (__hip_atomic_fetch_or(&pool.taken[pp >> 5], 0u, PSOAP_RLX_AGENT) >> (pp & 31u)) & 1u;
+                    ready = (poll_word(&pool.taken[pp >> 5]) >> (pp & 31u)) & 1u;
                 }
                 unsigned long long rdy = __ballot(ready);
                 while (rdy) {
@@ -1761,7 +1787,7 @@ __device__ __forceinline__ void pool_take(const DagTask* __restrict__ tasks, con
             }
             if (got != DAG_NO_TASK || !left) break;
             unsigned int err = 0u;
-            if (l == 0) err = __hip_atomic_fetch_or(&ctl->error, 0u, PSOAP_RLX_AGENT);
+            if (l == 0) err = poll_word(&ctl->error);
             if (__builtin_amdgcn_readfirstlane((int)err) != 0) break;
             __builtin_amdgcn_s_sleep(64);
             if (++spins > DAG_MAX_SPINS) {          // (nothing became ready for seconds: a failed launch, reported)
@@ -1895,7 +1921,7 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             }
             ticket = queues.first[g] + local;
         }
-        if (__hip_atomic_fetch_or(&ctl->error, 0u, PSOAP_RLX_AGENT) != 0u) return;
+        if (poll_word(&ctl->error) != 0u) return;
         // the compute unit this task starts on (compared before it retires: dag_moved_check)
         const unsigned int where0 = dag_where();
         // (ticket and matrix index are loop-carried since round 4 -- a strip solve continues into the next record, a stream
@@ -1987,7 +2013,7 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
             if (threadIdx.x == 0) {
                 dag_moved_check(where0, ctl, STREAM ? &st.lanes[b].tainted : nullptr);
-                if constexpr (STREAM) stream_retire(st, b, mat.acc);
+                if constexpr (STREAM) stream_retire(st, b, mat.acc, mat.P);
             }
             continue;
         }
@@ -1998,7 +2024,7 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
                           tlog_l ? tlog_l + ticket * 8 : nullptr);
             if (threadIdx.x == 0) {
                 dag_moved_check(where0, ctl, STREAM ? &st.lanes[b].tainted : nullptr);
-                if constexpr (STREAM) stream_retire(st, b, mat.acc);
+                if constexpr (STREAM) stream_retire(st, b, mat.acc, mat.P);
             }
             continue;
         }
@@ -2057,7 +2083,7 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
             if (threadIdx.x == 0) {
                 dag_moved_check(where0, ctl, STREAM ? &st.lanes[b].tainted : nullptr);
-                if constexpr (STREAM) stream_retire(st, b, mat.acc);
+                if constexpr (STREAM) stream_retire(st, b, mat.acc, mat.P);
             }
             continue;
         }
@@ -2124,7 +2150,7 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
         if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
         if (threadIdx.x == 0) {
             dag_moved_check(where0, ctl, STREAM ? &st.lanes[b].tainted : nullptr);
-            if constexpr (STREAM) stream_retire(st, b, mat.acc);
+            if constexpr (STREAM) stream_retire(st, b, mat.acc, mat.P);
         }
     }
 }

@@ -422,12 +422,8 @@ __device__ __forceinline__ void potrf_blocked(double* Km, int ld, int k0, double
         const double l = psoap_smem[OFF_RED + 4];
         const double qd = ((psoap_smem[OFF_RED + 0] + psoap_smem[OFF_RED + 1]) + psoap_smem[OFF_RED + 2]) +
                           psoap_smem[OFF_RED + 3];
-        // MatAcc is handed from block row to block row across workgroups: agent-scope accesses only
-        const double l0 = __hip_atomic_load(&acc->logdet_half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double q0 = __hip_atomic_load(&acc->quad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&acc->logdet_half, l0 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&acc->quad, q0 + qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (anybad) __hip_atomic_store(&acc->info, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // this block's record (common.hpp, MatAcc): written, never read here -- no chain from block row to block row
+        acc_store(acc, k0 / NB, l, qd, anybad != 0);
     }
     __syncthreads();   // the LDS scratch is handed back to the tile engine
     if (FUSED && tl && tid == 0) tl[1] = __builtin_amdgcn_s_memrealtime();

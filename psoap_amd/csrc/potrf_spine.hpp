@@ -85,7 +85,7 @@ struct SpineFollow {
 __device__ __forceinline__ int x_steps(int* xa, int* xb, int base, int lane)
 {
     int x = 0x7fffffff;
-    if (lane < 4) x = __hip_atomic_fetch_add((lane < 2 ? xa : xb) + (lane & 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < 4) x = poll_word((lane < 2 ? xa : xb) + (lane & 1));
     x = min(x, __shfl_xor(x, 1, 64));
     x = min(x, __shfl_xor(x, 2, 64));
     return __builtin_amdgcn_readfirstlane(x) - base;
@@ -555,12 +555,8 @@ __device__ __forceinline__ void potrf_spine_fused(double* Km, int ld, int k0, do
     if (threadIdx.x == 0) {
         const double l = sm[pb::OFF_RED + 0];
         const double qd = (sm[pb::OFF_RED + 1] + sm[pb::OFF_RED + 2]) + sm[pb::OFF_RED + 3];
-        // MatAcc is handed from block row to block row across workgroups: agent-scope accesses only
-        const double l0 = __hip_atomic_load(&acc->logdet_half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double q0 = __hip_atomic_load(&acc->quad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&acc->logdet_half, l0 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&acc->quad, q0 + qd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (sm[pb::OFF_RED + 4] != 0.0) __hip_atomic_store(&acc->info, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // this block's record (common.hpp, MatAcc): written, never read here -- no chain from block row to block row
+        acc_store(acc, k0 / NB, l, qd, sm[pb::OFF_RED + 4] != 0.0);
     }
     // (the LDS scratch goes back to the tile engine behind the caller's next barrier: dag_drain)
     if (tl && threadIdx.x == 0) tl[1] = __builtin_amdgcn_s_memrealtime();

@@ -450,7 +450,7 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
     PR_TRY(ws.K.need((size_t)Npad * ld));
     PR_TRY(ws.W.need(WT_STRIDE));
     PR_TRY(ws.R.need(Npad));
-    PR_TRY(ws.Acc.need(1));
+    PR_TRY(ws.Acc.need(ACC_ROWS + 1));      // the records of the block rows + their total (k_acc_total)
     PR_TRY(ws.Lwl.need((size_t)c * N));
     PR_TRY(ws.Pred.need((size_t)c * M));
     PR_TRY(ws.Gp.need(6));
@@ -630,7 +630,9 @@ inline int predict_run(PredictWs& ws, int mode, int c, int N, int M, const doubl
         PR_TRY(hipGetLastError());
     }
     PR_TRY(hipMemcpyAsync(h_mu, dMu, sizeof(double) * Rq, hipMemcpyDeviceToHost, st));
-    PR_TRY(hipMemcpyAsync(h_acc, dAcc, sizeof(MatAcc), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_acc_total, dim3(1), dim3(1), 0, st, dAcc, P, dAcc + ACC_ROWS);
+    PR_TRY(hipGetLastError());
+    PR_TRY(hipMemcpyAsync(h_acc, dAcc + ACC_ROWS, sizeof(MatAcc), hipMemcpyDeviceToHost, st));
 
     bool sigma_direct = false;
     if (Sigma_out) {

@@ -7,6 +7,7 @@
 #include <string>
 
 #include "microbench_kernels.hpp"
+#include "litmus_kernels.hpp"
 
 using namespace psoap;
 
@@ -68,4 +69,21 @@ extern "C" int psoap_microbench_hbm(int device, double* write_gbs, double* copy_
 {
     HIP_TRY(hipSetDevice(device));
     return microbench_hbm(write_gbs, copy_gbs, g_err);
+}
+
+extern "C" int psoap_litmus_l2(int device, int plant_mode, int writer_mode, int reader_mode, int same_xcd, int iters,
+                               int background, unsigned long long* out8)
+{
+    if (!out8 || iters < 1 || plant_mode < 0 || plant_mode > 3 || writer_mode < 0 || writer_mode > 2 || reader_mode < 0 ||
+        reader_mode >= LIT_N_READ)
+        FAIL("psoap_litmus_l2: bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    return litmus_run(plant_mode, writer_mode, reader_mode, same_xcd, iters, background, out8, g_err);
+}
+
+extern "C" int psoap_litmus_writeback(int device, int iters, unsigned long long* out8)
+{
+    if (!out8 || iters < 1) FAIL("psoap_litmus_writeback: bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    return litmus_wb_run(iters, out8, g_err);
 }

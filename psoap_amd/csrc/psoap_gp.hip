@@ -715,7 +715,7 @@ static int chunk_alloc(psoap_chunk* h, const double* fl, const double* sigma)
     HIP_TRY(hipMalloc(&h->dWt, sizeof(double) * nb * WT_STRIDE));       // two Wt tiles + the mailbox per matrix
     HIP_TRY(hipMemset(h->dWt, 0, sizeof(double) * nb * WT_STRIDE));   // the strictly upper part of every W stays zero
     HIP_TRY(hipMalloc(&h->dR, sizeof(double) * nb * h->Npad));
-    HIP_TRY(hipMalloc(&h->dAcc, sizeof(MatAcc) * nb));
+    HIP_TRY(hipMalloc(&h->dAcc, sizeof(MatAcc) * ACC_ROWS * nb));      // per matrix: one record per block row (common.hpp)
     HIP_TRY(hipMalloc(&h->dOut, sizeof(double) * nb));
     HIP_TRY(hipMalloc(&h->dPorb, sizeof(double) * nb * 13));
     HIP_TRY(hipHostMalloc(&h->hPorb, sizeof(double) * nb * 13));
@@ -1257,7 +1257,7 @@ static void fill_mats(const psoap_chunk* h, const BatchSlot& sl, DagMat* out)
         m.lw = sl.dLwl + (size_t)b * sl.C * h->N;
         m.gp = sl.dGp + (size_t)b * 2 * sl.C;
         m.sigma = h->dSigma;
-        m.acc = h->dAcc + b;
+        m.acc = h->dAcc + (size_t)b * ACC_ROWS;
         m.N = h->N;
         m.Npad = h->Npad;
         m.P = h->P;
@@ -1363,6 +1363,18 @@ static int eval_dag(psoap_chunk* h)
     // (flags, arrival counters and -- behind them -- the taken bitmap of the ready-only hand-out: one memset)
     const size_t taken_off = h->arrive_off + sizeof(int) * ((size_t)h->plan_ctrs + 4);
     HIP_TRY(hipMemsetAsync(h->dDag, 0, taken_off + sizeof(unsigned int) * (((size_t)h->plan_tasks + 31) / 32 + 1), s));
+    // PSOAP_DEBUG_POISON (tools/soak_batch_perm.py; bit 0: the matrices, bit 1: the mailboxes, bit 2: the partial-tile
+    // workspace, bit 3: the block records of the accumulators): NaN patterns in whatever the launch must write before it
+    // reads -- a task that reads ahead of its producer then returns NaN instead of the previous launch's (possibly
+    // identical) bits.  Everything poisoned here is written in full by the launch: upper-triangle tiles incl. their
+    // identity padding, the mailbox slots a follower reads, every slot a PART chain uses, one record per block row.
+    static const int poison = getenv("PSOAP_DEBUG_POISON") ? atoi(getenv("PSOAP_DEBUG_POISON")) : 0;
+    if (poison & 1) HIP_TRY(hipMemsetAsync(h->dK, 0xFF, sizeof(double) * h->mat_stride * (size_t)B, s));
+    if (poison & 2)
+        for (int b = 0; b < B; ++b)
+            HIP_TRY(hipMemsetAsync(h->dWt + (size_t)b * WT_STRIDE + (size_t)2 * NB * NB, 0xFF, sizeof(double) * MB_DOUBLES, s));
+    if ((poison & 4) && h->dWs && h->plan_slots) HIP_TRY(hipMemsetAsync(h->dWs, 0xFF, sizeof(double) * NB * NB * (size_t)h->plan_slots, s));
+    if (poison & 8) HIP_TRY(hipMemsetAsync(h->dAcc, 0xFF, sizeof(MatAcc) * ACC_ROWS * (size_t)B, s));
     if (prof_end(h, s)) return 1;
     const long long tasks = h->plan_tasks;
     const int grid_all = (int)(tasks < h->plan_workers ? tasks : h->plan_workers);
@@ -1397,7 +1409,7 @@ static int eval_dag(psoap_chunk* h)
     HIP_TRY(hipGetLastError());
     if (prof_end(h, s)) return 1;
     if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
-    hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, h->dAcc, h->dOut, B, sl.dTooFast);
+    hipLaunchKernelGGL(k_finalize, dim3((B + 63) / 64), dim3(64), 0, s, h->dAcc, h->dOut, B, sl.dTooFast, P);
     HIP_TRY(hipGetLastError());
     if (prof_end(h, s)) return 1;
     HIP_TRY(hipEventRecord(sl.evEval, s));
@@ -1464,7 +1476,7 @@ static int eval_staged(psoap_chunk* h)
         if (prof_end(h, s)) return 1;
         if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
         hipLaunchKernelGGL(k_init_rhs, dim3((h->Npad + 255) / 256, nb), dim3(256), 0, s,
-                           h->dR + (size_t)b0 * h->Npad, h->Npad, N, h->dFl, sl.mu, h->dAcc + b0);
+                           h->dR + (size_t)b0 * h->Npad, h->Npad, N, h->dFl, sl.mu, h->dAcc + (size_t)b0 * ACC_ROWS);
         HIP_TRY(hipGetLastError());
         if (prof_end(h, s)) return 1;
     }
@@ -1485,7 +1497,7 @@ static int eval_staged(psoap_chunk* h)
             }
             if (prof_begin(h, s, PSOAP_K_POTRF, 0.0, 0.0)) return 1;
             hipLaunchKernelGGL(k_potrf_diag, dim3(nb), dim3(512), 0, s, Kg, h->mat_stride, h->ld, k0,
-                               h->dWt + (size_t)b0 * WT_STRIDE, h->dR + (size_t)b0 * h->Npad, h->Npad, h->dAcc + b0,
+                               h->dWt + (size_t)b0 * WT_STRIDE, h->dR + (size_t)b0 * h->Npad, h->Npad, h->dAcc + (size_t)b0 * ACC_ROWS,
                                (size_t)WT_STRIDE);
             HIP_TRY(hipGetLastError());
             if (prof_end(h, s)) return 1;
@@ -1504,8 +1516,8 @@ static int eval_staged(psoap_chunk* h)
         hipStream_t s = h->streams[g];
         const int b0 = gb0[g], nb = gb0[g + 1] - gb0[g];
         if (prof_begin(h, s, PSOAP_K_MISC, 0.0, 0.0)) return 1;
-        hipLaunchKernelGGL(k_finalize, dim3((nb + 63) / 64), dim3(64), 0, s, h->dAcc + b0, h->dOut + b0, nb,
-                           sl.dTooFast + b0);
+        hipLaunchKernelGGL(k_finalize, dim3((nb + 63) / 64), dim3(64), 0, s, h->dAcc + (size_t)b0 * ACC_ROWS, h->dOut + b0, nb,
+                           sl.dTooFast + b0, P);
         HIP_TRY(hipGetLastError());
         if (prof_end(h, s)) return 1;
         if (g != 0) {
@@ -1786,7 +1798,7 @@ static int group_eval_locked(psoap_group* g, bool promote)
     HIP_TRY(hipGetLastError());
     for (psoap_chunk* h : g->hs) {
         const BatchSlot& sl = h->slot[h->act];
-        hipLaunchKernelGGL(k_finalize, dim3((sl.B + 63) / 64), dim3(64), 0, s, h->dAcc, h->dOut, sl.B, sl.dTooFast);
+        hipLaunchKernelGGL(k_finalize, dim3((sl.B + 63) / 64), dim3(64), 0, s, h->dAcc, h->dOut, sl.B, sl.dTooFast, h->P);
         HIP_TRY(hipEventRecord(sl.evEval, s));
         HIP_TRY(hipEventRecord(h->evLast, s));
         h->last_recorded = true;
@@ -1963,7 +1975,7 @@ static int stream_open_impl(psoap_chunk* h, int c, int lanes, int scheme)
         m.lw = h->slot[0].dLwl + (size_t)b * c * h->N;       // the lane's device copy of its proposal (the dispatcher fills it)
         m.gp = h->slot[0].dGp + (size_t)b * 2 * c;
         m.sigma = h->dSigma;
-        m.acc = h->dAcc + b;
+        m.acc = h->dAcc + (size_t)b * ACC_ROWS;
         m.N = h->N;
         m.Npad = h->Npad;
         m.P = h->P;
