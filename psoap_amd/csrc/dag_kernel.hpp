@@ -192,12 +192,18 @@ __device__ __forceinline__ int dag_peek(int* flag) { return poll_word(flag); }
 // is WRITTEN THROUGH (sc0 sc1) instead of left dirty in the writing XCD's L2 for the release fence to write back: what the
 // consumer reads is in memory when the storing wave's vmcnt reaches zero, wherever the workgroup is when its release
 // fence runs (round 5; measured performance-neutral in round 4: 848.1 against 847.3 evals/s).  -DPSOAP_NO_WT_STORES: plain.
+// WT = false: a plain store -- the tiles of a matrix that ONE workgroup factors by itself (solo_kernel.hpp: nobody else reads
+// them inside the launch, and what stays in the L2 is what that workgroup reads next).
+template <bool WT = true>
 __device__ __forceinline__ void dag_st(double* p, double v)
 {
 #ifdef PSOAP_NO_WT_STORES
     *p = v;
 #else
-    __hip_atomic_store((__attribute__((address_space(1))) double*)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if constexpr (WT)
+        __hip_atomic_store((__attribute__((address_space(1))) double*)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else
+        *p = v;
 #endif
 }
 
@@ -444,7 +450,7 @@ struct DagMat {
 #endif
 // FAST: a task that adds no covariance (every PART but a chain's first, and the final of a chain) stores its tile through a
 // loop of its own (see there).
-template <int C, bool AUG, bool INPLACE = false, bool ROWMAP = false, bool FAST = false>
+template <int C, bool AUG, bool INPLACE = false, bool ROWMAP = false, bool FAST = false, bool WT = true>
 __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ dest, size_t ldd, int k0, int j0,
                                                   const double* __restrict__ lw, const GpDev& g, double dsum,
                                                   const double* __restrict__ sigma, int N, double scale,
@@ -470,7 +476,7 @@ __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ 
                 for (int n = 0; n < 4; ++n)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        dag_st(&dest[(size_t)tile_row(wr, m, lane, r) * ldd + (size_t)tile_col(wc, n, lane)], 0.0 - t.acc[m][n][r]);
+                        dag_st<WT>(&dest[(size_t)tile_row(wr, m, lane, r) * ldd + (size_t)tile_col(wc, n, lane)], 0.0 - t.acc[m][n][r]);
             return;
         }
     }
@@ -573,7 +579,7 @@ __device__ __forceinline__ void dag_store_updated(Tile& t, double* __restrict__ 
             }
             return;
         }
-        dag_st(&dest[(size_t)ic * ldd + (size_t)jc], out);
+        dag_st<WT>(&dest[(size_t)ic * ldd + (size_t)jc], out);
     };
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -716,7 +722,7 @@ __device__ __forceinline__ void dag_sub_partials(Tile& t, const double* __restri
 // BAL: the row blocks are dealt to the waves by work (tile_gemm_tn_lower_balanced and its accumulator map)
 // VP: how the two 128-entry LDS vectors are addressed (double* inside a kernel, lds_double* inside dag_diag_fast);
 // SM: how the tile engine's LDS array is reached (gemm_core.hpp)
-template <bool BAL = false, class VP = double*, class SM = SmemKernel>
+template <bool BAL = false, class VP = double*, class SM = SmemKernel, bool WT = true>
 __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, int j0, const double* Wm, double* Rv,
                                          int Npad, VP zk, VP colsum, SM sm = SM())
 {
@@ -739,7 +745,7 @@ __device__ __forceinline__ void dag_trsm(Tile& t, double* Km, int ld, int k0, in
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const double x = t.acc[m][n][r];
-                dag_st(&Km[(size_t)(k0 + row) * ld + j0 + tile_col(wc, n, lane)], x);
+                dag_st<WT>(&Km[(size_t)(k0 + row) * ld + j0 + tile_col(wc, n, lane)], x);
                 part[n] = fma(x, z, part[n]);
             }
         }

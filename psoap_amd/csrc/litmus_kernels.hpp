@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64) void k_litmus(u64* unit, unsigned int* sync, in
         if (!lit_read_fresh(reader_mode, unit, lane, want, lds)) {
             ++read_stale;
             bool fresh = false;
-            for (int k = 0; k < 200000 && !fresh; ++k) fresh = lit_read_fresh(reader_mode, unit, lane, want, lds);
+            for (int k = 0; k < 4000 && !fresh; ++k) fresh = lit_read_fresh(reader_mode, unit, lane, want, lds);      // (~ 4 ms)
             const u64 dt = __builtin_amdgcn_s_memrealtime() - t0;
             if (!fresh) {
                 ++never;

@@ -27,6 +27,7 @@
 
 #include "chol_kernels.hpp"
 #include "dag_kernel.hpp"
+#include "solo_kernel.hpp"
 #include "fill_kernels.hpp"
 #include "orbit_kernels.hpp"
 #include "predict_kernels.hpp"
@@ -407,17 +408,41 @@ static bool share_detect_only()
     static const bool on = getenv("PSOAP_SHARE_DETECT_ONLY") && getenv("PSOAP_SHARE_DETECT_ONLY")[0] == '1';
     return on;
 }
+// The decision is taken ONCE per entry into the library and kept for the whole call (DeviceScope below): the process count
+// is re-read four times a second, and a call that asked twice -- once to decide whether it needs the device lock, once to
+// choose the path -- could get two answers: a persistent launch issued WITHOUT the lock (review of round 5).
+static thread_local int g_share_decision_depth = 0;       // > 0: inside an entry point
+static thread_local std::map<int, bool>* g_share_decision = nullptr;
+static bool share_wants_staged_now(int device);
 static bool share_wants_staged(int device)
+{
+    if (g_share_decision_depth > 0 && g_share_decision) {
+        auto it = g_share_decision->find(device);
+        if (it != g_share_decision->end()) return it->second;
+        const bool v = share_wants_staged_now(device);
+        (*g_share_decision)[device] = v;
+        return v;
+    }
+    return share_wants_staged_now(device);
+}
+static void share_warn_unsafe_regime(int procs, bool pinned_dag);
+static bool share_wants_staged_now(int device)
 {
     static const int pinned = [] {
         const char* e = getenv("PSOAP_SHARE_POLICY");
         return !e ? 0 : (!strcmp(e, "dag") ? 1 : (!strcmp(e, "staged") ? 2 : 0));
     }();
-    if (pinned) return pinned == 2;
+    if (pinned) {
+        if (pinned == 1) share_warn_unsafe_regime(share_procs(device), true);
+        return pinned == 2;
+    }
     const int procs = share_procs(device);
     if (procs <= 1) return false;
     if (!device_lock_enabled()) return true;            // nobody keeps two persistent launches apart
-    if (procs <= share_dag_max()) return false;
+    if (procs <= share_dag_max()) {
+        share_warn_unsafe_regime(procs, false);
+        return false;
+    }
     static std::atomic<bool> hinted{false};
     if (!hinted.exchange(true) && !(getenv("PSOAP_QUIET") && getenv("PSOAP_QUIET")[0] == '1'))
         fprintf(stderr,
@@ -435,11 +460,42 @@ static bool share_inject_taint()
     return every > 0 && (++n % every) == 0;
 }
 
+// Persistent launches among MORE than 8 process contexts are outside what was measured clean: a user who pins
+// them there (PSOAP_SHARE_POLICY=dag, PSOAP_SHARE_DAG_MAX > 8) or asks for tainted values (PSOAP_SHARE_DETECT_ONLY=1) is told
+// so, once.
+static void share_warn_unsafe_regime(int procs, bool pinned_dag)
+{
+    static std::atomic<bool> warned{false};
+    const bool beyond = procs > 8 && (pinned_dag || share_dag_max() > 8);
+    if (!(beyond || share_detect_only()) || warned.exchange(true)) return;
+    if (getenv("PSOAP_QUIET") && getenv("PSOAP_QUIET")[0] == '1') return;
+    if (share_detect_only())
+        fprintf(stderr, "psoap: PSOAP_SHARE_DETECT_ONLY=1: evaluations that reported a moved workgroup are handed out as they are "
+                        "(an experiment's setting: such values may be wrong).\n");
+    if (beyond)
+        fprintf(stderr, "psoap: %d processes share this GPU and the persistent kernel was pinned there (PSOAP_SHARE_POLICY=dag or "
+                        "PSOAP_SHARE_DAG_MAX > 8): the moved-workgroup check was measured clean only up to 8 processes; beyond, "
+                        "the staged path or PSOAP_GPU_SERVER=auto is the supported route.\n", procs);
+}
+
 struct DeviceScope {
     int dev;
     bool ok, took = false;
-    explicit DeviceScope(int d) : dev(d) { ok = device_lock_acquire(d, &took) == 0; }
-    ~DeviceScope() { if (took) device_lock_release(dev); }
+    std::map<int, bool> decisions;          // share_wants_staged per device, fixed for the duration of this call
+    bool outermost = false;
+    explicit DeviceScope(int d) : dev(d)
+    {
+        if (g_share_decision_depth++ == 0) {
+            g_share_decision = &decisions;
+            outermost = true;
+        }
+        ok = device_lock_acquire(d, &took) == 0;
+    }
+    ~DeviceScope()
+    {
+        if (took) device_lock_release(dev);
+        if (--g_share_decision_depth == 0 && outermost) g_share_decision = nullptr;
+    }
     DeviceScope(const DeviceScope&) = delete;
     DeviceScope& operator=(const DeviceScope&) = delete;
 };
@@ -447,6 +503,9 @@ struct DeviceScope {
 #define DEVICE_SCOPE(d)      \
     DeviceScope scope_(d);   \
     if (!scope_.ok) return 2
+// the destroy entry points: the resources go whether or not the lock could be had (a time-out there must not leak device
+// memory, nor make the caller's close() raise: hipDeviceSynchronize + hipFree disturb nobody's persistent launch)
+#define DEVICE_SCOPE_DESTROY(d) DeviceScope scope_(d)
 
 // Owning device / pinned-host pointer: early returns free whatever was allocated so far.
 template <class T>
@@ -669,6 +728,9 @@ static int configure_kernels(int device)
     PSOAP_SET_LDS(k_chol_dag<1, false, true, false, 1>);
     PSOAP_SET_LDS(k_chol_dag<2, false, true, false, 1>);
     PSOAP_SET_LDS(k_chol_dag<3, false, true, false, 1>);
+    PSOAP_SET_LDS(k_chol_solo<1>);
+    PSOAP_SET_LDS(k_chol_solo<2>);
+    PSOAP_SET_LDS(k_chol_solo<3>);
     PSOAP_SET_LDS(k_chol_dag<1, false, false, true>);
     PSOAP_SET_LDS(k_chol_dag<2, false, false, true>);
     PSOAP_SET_LDS(k_chol_dag<3, false, false, true>);
@@ -797,7 +859,7 @@ extern "C" int psoap_stream_close(psoap_chunk* h);
 extern "C" int psoap_chunk_destroy(psoap_chunk* h)
 {
     if (!h) return 0;
-    DEVICE_SCOPE(h->device);
+    DEVICE_SCOPE_DESTROY(h->device);
     (void)hipSetDevice(h->device);
     if (h->stream.open) (void)psoap_stream_close(h);
     (void)hipDeviceSynchronize();
@@ -1346,6 +1408,27 @@ static int dag_prepare(psoap_chunk* h)
     return 0;
 }
 
+// Many small matrices: one workgroup per matrix (solo_kernel.hpp) instead of the dependency graph.  PSOAP_SOLO=1 / 0 forces /
+// forbids it; otherwise from PSOAP_SOLO_MIN matrices on (default: solo_min_default, from the measured table of round 6)
+// while the largest matrix has at most PSOAP_SOLO_MAX_P block rows.
+static bool solo_wanted(int n_mats, int Pmax)
+{
+    // (read at every launch: the tests and tools switch it inside one process)
+    const char* e = getenv("PSOAP_SOLO");
+    if (e && e[0] == '1') return true;
+    if (e && e[0] == '0') return false;
+    const int min_mats = getenv("PSOAP_SOLO_MIN") ? atoi(getenv("PSOAP_SOLO_MIN")) : 0x7fffffff;
+    const int max_p = getenv("PSOAP_SOLO_MAX_P") ? atoi(getenv("PSOAP_SOLO_MAX_P")) : 24;
+    return n_mats >= min_mats && Pmax <= max_p;
+}
+template <class... Args>
+static void launch_solo(int C, int grid, hipStream_t s, Args... args)
+{
+    if (C == 1) hipLaunchKernelGGL(k_chol_solo<1>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, args...);
+    else if (C == 2) hipLaunchKernelGGL(k_chol_solo<2>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, args...);
+    else hipLaunchKernelGGL(k_chol_solo<3>, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, s, args...);
+}
+
 // One persistent launch for the whole batched factorisation (dag_kernel.hpp).
 static int eval_dag(psoap_chunk* h)
 {
@@ -1382,7 +1465,10 @@ static int eval_dag(psoap_chunk* h)
     double fl = 0.0;
     for (int q = 0; q < P; ++q) fl += 2.0 * NB * NB * ((double)q * NB * (P - q) + (double)NB * (P - q - 1));
     if (prof_begin(h, s, PSOAP_K_DAG, fl * B, 0.0)) return 1;
-    {
+    if (solo_wanted(B, P)) {
+        const int grid = B < h->dag_grid ? B : h->dag_grid;
+        launch_solo(C, grid, s, (const DagMat*)sl.dMats, (const unsigned int*)nullptr, B, reinterpret_cast<SoloCtl*>(h->dDag));
+    } else {
         MatFlags* fl_ = reinterpret_cast<MatFlags*>(h->dDag + sizeof(DagCtl));
         DagCtl* ctl_ = reinterpret_cast<DagCtl*>(h->dDag);
 #define PSOAP_LAUNCH_DAG(CC, LAT, WPE)                                                                           \
@@ -1622,7 +1708,7 @@ extern "C" int psoap_group_create(psoap_group** out, psoap_chunk* const* handles
 extern "C" int psoap_group_destroy(psoap_group* g)
 {
     if (!g) return 0;
-    DEVICE_SCOPE(g->device);
+    DEVICE_SCOPE_DESTROY(g->device);
     (void)hipSetDevice(g->device);
     (void)hipDeviceSynchronize();
     {   // (a member's fetch must not come back to a group that is gone: settle_evaluation asks the registry)
@@ -1772,7 +1858,12 @@ static int group_eval_locked(psoap_group* g, bool promote)
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(g->dDag, 0, g->dag_bytes, s));
-    {
+    int Pmax_g = 0;
+    for (psoap_chunk* h : g->hs) Pmax_g = h->P > Pmax_g ? h->P : Pmax_g;
+    if (solo_wanted(total, Pmax_g)) {
+        const int grid = total < g->hs[0]->dag_grid ? total : g->hs[0]->dag_grid;
+        launch_solo(C, grid, s, (const DagMat*)g->dMats, (const unsigned int*)nullptr, total, reinterpret_cast<SoloCtl*>(g->dDag));
+    } else {
         const int workers = (g->scheme >= 1 && g->workers > 2 * g->hs[0]->n_cus) ? 2 * g->hs[0]->n_cus : g->workers;
         const int grid = (int)(g->n_tasks < workers ? g->n_tasks : workers);
         MatFlags* fl_ = reinterpret_cast<MatFlags*>(g->dDag + sizeof(DagCtl));
@@ -2677,7 +2768,7 @@ extern "C" int psoap_predictor_create(psoap_predictor** out, int device)
 extern "C" int psoap_predictor_destroy(psoap_predictor* p)
 {
     if (!p) return 0;
-    DEVICE_SCOPE(p->device);
+    DEVICE_SCOPE_DESTROY(p->device);
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
     delete p;

@@ -19,6 +19,7 @@ What /root/reference/psoap/sample_parallel.py does with one forked process per c
 from __future__ import annotations
 
 import argparse
+import json
 import os
 import shutil
 
@@ -251,7 +252,11 @@ def run(config, chunks, run_index=0, n_chains=1, seed=None, world=1, rank=0, dev
         n_iter = int(config["samples"] if iterations is None else iterations)
         # stream: None = automatic (want_stream), True / False force it.  Streamed, the chains' iterations go through one
         # resident launch per GPU in two halves (samplers.sample_streamed: the loop of sample_parallel.py:434-438 with the
-        # gather of :378-387 per half); the chains are the same either way.
+        # gather of :378-387 per half).  The two modes draw the same proposals and apply the same accept rule, so they give
+        # the same chains GIVEN THE SAME lnprob values -- and a stream lane sums a matrix in another order than a batch
+        # launch does: the values agree to ~1e-14 relative, not bit for bit, so a fixed-seed run can part ways with the
+        # other mode's at the first accept decision that falls inside that margin.  Which mode a run used is recorded in its
+        # output directory (evaluation.json); PSOAP_FIXED_PLAN=1 makes the batch path sum like a lane (bit-identical modes).
         use_stream = want_stream(post, chunks, n_chains) if stream is None else bool(stream)
         sampler.streamed = use_stream
         if use_stream:
@@ -265,8 +270,11 @@ def run(config, chunks, run_index=0, n_chains=1, seed=None, world=1, rank=0, dev
             if verbose and rank == 0 and (i + 1) % 20 == 0:
                 print("Iteration", i + 1)
     finally:
-        post.stream_close()
-        post.close()
+        # (a failing stream_close must neither hide the exception that brought us here nor skip post.close())
+        try:
+            post.stream_close()
+        finally:
+            post.close()
     if rank == 0:
         if verbose:
             print("Acceptance fraction", sampler.acceptance_fraction)
@@ -276,6 +284,9 @@ def run(config, chunks, run_index=0, n_chains=1, seed=None, world=1, rank=0, dev
             os.makedirs(routdir)
             if config_path is not None and os.path.exists(config_path):
                 shutil.copy(config_path, routdir + "config.yaml")
+            with open(routdir + "evaluation.json", "w") as fh:
+                json.dump({"stream": bool(use_stream), "world": int(world), "chains": int(n_chains),
+                           "fixed_plan": os.environ.get("PSOAP_FIXED_PLAN", "0") == "1"}, fh)
             np.save(routdir + "lnprob.npy", sampler.lnprobability[b])
             np.save(routdir + "flatchain.npy", sampler.chain[b])
     return sampler

@@ -33,6 +33,7 @@ import numpy as np
 
 _HDR = struct.Struct("<Q")
 WINDOW_S = 0.002          # how long a request waits for the others of its iteration (only while others are expected)
+FRAME_TIMEOUT_S = 5.0       # a frame that does not arrive whole within this time: the client is dropped
 RECENT_S = 2.0            # a client counts as "expected" while its last request is at most this old (an idle one costs the others WINDOW_S)
 
 
@@ -102,9 +103,20 @@ class GpuServer:
         self.last_request = {}           # socket -> time of its last lnlike request
         self.next_id = 1
         self.stats = {"requests": 0, "launches": 0, "grouped_launches": 0, "largest_group": 0, "clients_seen": 0}
+        self.pending = {}                # socket -> its request waiting for the next launch
         self.sel = selectors.DefaultSelector()
         if os.path.exists(path):
-            os.unlink(path)
+            # a socket file left by a server that died is replaced; one a LIVE server listens on is not stolen
+            probe = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            probe.settimeout(1.0)
+            try:
+                probe.connect(path)
+            except OSError:
+                os.unlink(path)
+            else:
+                raise RuntimeError(f"a GPU server is already listening on {path}")
+            finally:
+                probe.close()
         self.listener = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
         old = os.umask(0o177)
         try:
@@ -121,6 +133,7 @@ class GpuServer:
         for cid in [c for c, s in self.owner.items() if s is sock]:
             self._close_chunk(cid)
         self.last_request.pop(sock, None)
+        self.pending.pop(sock, None)     # (its request must not reach the next launch: the chunk is gone)
         try:
             self.sel.unregister(sock)
         except Exception:
@@ -193,7 +206,9 @@ class GpuServer:
     # -- evaluation -------------------------------------------------------------------------------
     def _evaluate(self, pending):
         by_c = {}
-        for sock, req in pending.items():
+        for sock, req in list(pending.items()):
+            if req[0] not in self.chunks:           # its client went away between the request and the launch
+                continue
             by_c.setdefault(req[1], []).append((sock, req))
         for c, reqs in by_c.items():
             reqs.sort(key=lambda r: r[1][0])
@@ -226,7 +241,7 @@ class GpuServer:
     # -- main loop --------------------------------------------------------------------------------
     def serve(self):
         idle_since = time.monotonic()
-        pending = {}
+        pending = self.pending
         first = 0.0
         try:
             while not self.quit:
@@ -236,7 +251,7 @@ class GpuServer:
                     left = first + self.window_s - now
                     if len(pending) >= expected or left <= 0.0:
                         self._evaluate(pending)
-                        pending = {}
+                        pending.clear()
                         continue
                     timeout = left
                 else:
@@ -244,7 +259,9 @@ class GpuServer:
                 for key, _ in self.sel.select(timeout):
                     if key.data == "accept":
                         conn, _ = self.listener.accept()
-                        conn.setblocking(True)
+                        # (frames are read whole inside the one-threaded loop: a client that stops in the middle of one
+                        # holds everybody up for at most this long, then it is dropped)
+                        conn.settimeout(FRAME_TIMEOUT_S)
                         self.sel.register(conn, selectors.EVENT_READ, "client")
                         self.stats["clients_seen"] += 1
                     else:

@@ -183,3 +183,40 @@ def test_drop_in_call_goes_through_the_server(tmp_path, monkeypatch):
     from psoap_amd._lib import PsoapError
     with pytest.raises(PsoapError, match="no server answers"):
         server.connect_chunk(ch.fl, ch.sigma, device=0)
+
+
+def test_a_worker_that_dies_with_a_request_pending_fails_nobody_else(tmp_path):
+    """Three workers are expected (a long window); one sends its request and dies before the launch: its request is
+    dropped with it, the other two get their values (round 5's review: the dead worker's entry stayed in `pending` and the
+    launch then failed for everybody with the same component count).  A second server on a live socket is refused."""
+    import struct
+    import oracle
+    path, be, srv, th = _start(tmp_path, window_s=0.5)
+    chs = [syn.make_chunk(2, 3, 30 + 4 * k, seed=70 + k) for k in range(3)]
+    gp = syn.GP_BASE[2]
+    rcs = [server.RemoteChunk(c.fl, c.sigma, path) for c in chs]
+    for rc, c in zip(rcs, chs):           # everybody has asked once: all three count as "expected" from now on
+        assert rc.lnlike(c.lwls, gp) == oracle.lnlike(c.lwls, c.fl, c.sigma, list(gp))
+    with pytest.raises(RuntimeError):
+        server.GpuServer(path, _Backend(), idle_exit_s=0)
+    dead, c0 = rcs[0], chs[0]
+    server._send(dead.sock, b"L" + struct.pack("<qqd", dead.cid, 2, 1.0) + np.asarray(gp, dtype="<f8").tobytes()
+                 + np.ascontiguousarray(c0.lwls, dtype="<f8").tobytes())
+    time.sleep(0.05)
+    dead.sock.close()
+    dead.sock = None
+    out = {}
+
+    def ask(k):
+        out[k] = rcs[k].lnlike(chs[k].lwls, gp)
+
+    ts = [threading.Thread(target=ask, args=(k,)) for k in (1, 2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=20)
+    for k in (1, 2):
+        assert out[k] == oracle.lnlike(chs[k].lwls, chs[k].fl, chs[k].sigma, list(gp))
+    server._send(rcs[1].sock, b"Q")
+    assert server._recv(rcs[1].sock) == b"q"
+    th.join(timeout=5)
