@@ -1426,63 +1426,84 @@ __device__ __forceinline__ void stream_next_lane(const StreamArgs& st, int lane)
     __hip_atomic_store(&st.dev->cur[lane & 7].lane, (unsigned int)pick, PSOAP_RLX_AGENT);
 }
 
-// The matrix of `lane` is complete: lnprob and the submission number go straight to pinned host memory (thread 0 of the
-// workgroup whose task retired last: stream_retire).
-// The sums over the matrix's P block records in block order (acc_total, chol_kernels.hpp: the same order, the same bits),
-// read by ONE thread inside a running launch: every word through a returning atomic (rmw_read: the value the memory
-// holds -- a load could be served from a line this XCD's L2 still keeps from the lane's previous matrix), eight records
-// in flight at a time.
-__device__ __forceinline__ MatAcc stream_acc_total(MatAcc* rec, int P)
+// The matrix of `lane` is complete: lnprob and the submission number go straight to pinned host memory.  Called by ALL
+// 64 lanes of wave 0 of the workgroup whose task retired last (dag_task_end).
+// The sums over the matrix's P block records (common.hpp, MatAcc) in block order -- acc_total's order (chol_kernels.hpp),
+// so a stream returns the bits a launch per step returns for the same task list: lane l fetches record l (l + 64, ...)
+// with returning atomics (rmw_read: the value the MEMORY holds -- a load could be served from a line this XCD's L2 keeps
+// from an earlier matrix of the lane), then the records are added one after the other, each broadcast with v_readlane.
+// Six registers per lane: the version of this that ONE thread ran with eight records in flight cost the stream kernels
+// 13-20 more spilled registers.
+__device__ __forceinline__ double stream_bcast(unsigned long long w, int k)
 {
-    MatAcc a{0.0, 0.0, 0.0, 0.0};
-    for (int q0 = 0; q0 < P; q0 += 8) {
-        unsigned long long w[8][3];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            MatAcc* r = rec + (q0 + u < P ? q0 + u : P - 1);
-            w[u][0] = rmw_read(reinterpret_cast<unsigned long long*>(&r->logdet_half));
-            w[u][1] = rmw_read(reinterpret_cast<unsigned long long*>(&r->quad));
-            w[u][2] = rmw_read(reinterpret_cast<unsigned long long*>(&r->info));
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)w, k);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(w >> 32), k);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ void stream_complete(const StreamArgs& st, int lane, MatAcc* rec, int P)
+{
+    const int l = hw_lane();
+    double lh = 0.0, qd = 0.0;
+    int bad = 0;
+    for (int q0 = 0; q0 < P; q0 += 64) {
+        unsigned long long wl = 0ull, wq = 0ull, wi = 0ull;
+        if (q0 + l < P) {
+            MatAcc* r = rec + q0 + l;
+            wl = rmw_read(reinterpret_cast<unsigned long long*>(&r->logdet_half));
+            wq = rmw_read(reinterpret_cast<unsigned long long*>(&r->quad));
+            wi = rmw_read(reinterpret_cast<unsigned long long*>(&r->info));
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (q0 + u < P) {
-                a.logdet_half += __longlong_as_double((long long)w[u][0]);
-                a.quad += __longlong_as_double((long long)w[u][1]);
-                if (__longlong_as_double((long long)w[u][2]) != 0.0) a.info = 1.0;
-            }
+        const int n = P - q0 < 64 ? P - q0 : 64;
+        for (int k = 0; k < n; ++k) {            // (wave-uniform: every lane ends with the same sums)
+            lh += stream_bcast(wl, k);
+            qd += stream_bcast(wq, k);
+            bad |= stream_bcast(wi, k) != 0.0 ? 1 : 0;
+        }
     }
-    return a;
+    if (l == 0) {
+        const unsigned long long seq = __hip_atomic_load(&st.lanes[lane].seq, PSOAP_RLX_AGENT);
+        const unsigned int fast = __hip_atomic_load(&st.lanes[lane].too_fast, PSOAP_RLX_AGENT);
+        const unsigned int taint = __hip_atomic_load(&st.lanes[lane].tainted, PSOAP_RLX_AGENT);
+        StreamResult* res = &st.host->result[seq % STREAM_RING];
+        __hip_atomic_store(&res->lnp, stream_lnp(lh, qd, bad != 0 || fast != 0u), PSOAP_RLX_SYSTEM);
+        __hip_atomic_store(&res->tainted, (unsigned long long)taint, PSOAP_RLX_SYSTEM);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&res->seq1, seq + 1ull, PSOAP_RLX_SYSTEM);
+        __hip_atomic_fetch_add(&st.dev->completed, 1ull, PSOAP_RLX_AGENT);
+    }
 }
 
-__device__ __forceinline__ void stream_complete(const StreamArgs& st, int lane, MatAcc* acc, int P)
-{
-    const MatAcc tot = stream_acc_total(acc, P);
-    const double lh = tot.logdet_half, qd = tot.quad, info = tot.info;
-    const unsigned long long seq = __hip_atomic_load(&st.lanes[lane].seq, PSOAP_RLX_AGENT);
-    const unsigned int fast = __hip_atomic_load(&st.lanes[lane].too_fast, PSOAP_RLX_AGENT);
-    const unsigned int taint = __hip_atomic_load(&st.lanes[lane].tainted, PSOAP_RLX_AGENT);
-    StreamResult* res = &st.host->result[seq % STREAM_RING];
-    __hip_atomic_store(&res->lnp, stream_lnp(lh, qd, info != 0.0 || fast != 0u), PSOAP_RLX_SYSTEM);
-    __hip_atomic_store(&res->tainted, (unsigned long long)taint, PSOAP_RLX_SYSTEM);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&res->seq1, seq + 1ull, PSOAP_RLX_SYSTEM);
-    __hip_atomic_fetch_add(&st.dev->completed, 1ull, PSOAP_RLX_AGENT);
-}
-
-// A task of the matrix in `lane` has retired (thread 0, behind the task's last store).  The result is reported by whoever
-// retires LAST, not by the last diagonal task: in the latency schemes the tasks that FOLLOW a factorisation hand their
-// tiles over row block by row block, the diagonal task they feed can be through before they have written their own
-// completion words -- and the host, told too early, resubmits to the lane, whose flags the dispatcher then clears under a
-// straggler's late store (seen as a rare wrong lnprob with eight processes sharing one GPU).
-__device__ __forceinline__ void stream_retire(const StreamArgs& st, int lane, MatAcc* acc, int P)
+// A task of the matrix in `lane` has retired (thread 0, behind the task's last store): true for the task that retires
+// LAST.  The result is reported by that one, not by the last diagonal task: in the latency schemes the tasks that FOLLOW a
+// factorisation hand their tiles over row block by row block, the diagonal task they feed can be through before they have
+// written their own completion words -- and the host, told too early, resubmits to the lane, whose flags the dispatcher
+// then clears under a straggler's late store (seen as a rare wrong lnprob with eight processes sharing one GPU).
+__device__ __forceinline__ bool stream_retire(const StreamArgs& st, int lane)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's completion words are out
     const unsigned int old = __hip_atomic_fetch_add(&st.lanes[lane].retired, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1u == st.n_tasks) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        stream_complete(st, lane, acc, P);
+    if (old + 1u != st.n_tasks) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+
+// The end of every task: thread 0 checks whether the workgroup moved (dag_moved_check) and, in a stream, counts the task as
+// retired; wave 0 of the workgroup whose task was the matrix's last then reports the result (stream_complete).
+// wave_s: the wave index as a scalar (the branch on it is a scalar branch, not an exec-masked region).
+template <bool STREAM>
+__device__ __forceinline__ void dag_task_end(const StreamArgs& st, int b, MatAcc* acc, int P, unsigned int where0, DagCtl* ctl,
+                                             int wave_s)
+{
+    int last = 0;
+    if (threadIdx.x == 0) {
+        dag_moved_check(where0, ctl, STREAM ? &st.lanes[b].tainted : nullptr);
+        if constexpr (STREAM) last = stream_retire(st, b) ? 1 : 0;
+    }
+    if constexpr (STREAM) {
+        if (wave_s == 0) {
+            if (__builtin_amdgcn_readfirstlane(last) != 0) stream_complete(st, b, acc, P);
+        }
     }
 }
 
@@ -2017,10 +2038,7 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
                 dag_special<C, AUG, WPE>((lds_special_args*)(uintptr_t)aa);
             }
             if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-            if (threadIdx.x == 0) {
-                dag_moved_check(where0, ctl, STREAM ? &st.lanes[b].tainted : nullptr);
-                if constexpr (STREAM) stream_retire(st, b, mat.acc, mat.P);
-            }
+            dag_task_end<STREAM>(st, b, mat.acc, mat.P, where0, ctl, wave_s);
             continue;
         }
 #else
@@ -2028,10 +2046,7 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             dag_diag_fast(Km, ld, k0, Wm, Rv, mat.acc, prev, Npad, f, ctl, q, ntasks_row, (task.type & DAG_FUSED) != 0,
                           &arrive_l[task.ctr], n_wait, dag_opaque_lds(psoap_smem), dag_opaque_lds(vec1), dag_opaque_lds(vec2),
                           tlog_l ? tlog_l + ticket * 8 : nullptr);
-            if (threadIdx.x == 0) {
-                dag_moved_check(where0, ctl, STREAM ? &st.lanes[b].tainted : nullptr);
-                if constexpr (STREAM) stream_retire(st, b, mat.acc, mat.P);
-            }
+            dag_task_end<STREAM>(st, b, mat.acc, mat.P, where0, ctl, wave_s);
             continue;
         }
 #endif
@@ -2087,10 +2102,7 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
                 __hip_atomic_fetch_add(&arrive_l[task.ctr], 1, PSOAP_RLX_AGENT);
             }
             if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-            if (threadIdx.x == 0) {
-                dag_moved_check(where0, ctl, STREAM ? &st.lanes[b].tainted : nullptr);
-                if constexpr (STREAM) stream_retire(st, b, mat.acc, mat.P);
-            }
+            dag_task_end<STREAM>(st, b, mat.acc, mat.P, where0, ctl, wave_s);
             continue;
         }
         if (AUG && ttype == DAG_SCHUR) {             // nobody inside the launch reads Sigma: no drain, no counter
@@ -2154,10 +2166,7 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             if constexpr (CONT) cont = (task.type & DAG_FUSED) != 0;
         }
         if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-        if (threadIdx.x == 0) {
-            dag_moved_check(where0, ctl, STREAM ? &st.lanes[b].tainted : nullptr);
-            if constexpr (STREAM) stream_retire(st, b, mat.acc, mat.P);
-        }
+        dag_task_end<STREAM>(st, b, mat.acc, mat.P, where0, ctl, wave_s);
     }
 }
 

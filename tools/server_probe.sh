@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5: the reference's worker-per-chunk model through ONE process that owns the GPU (psoap_amd/server.py) against the same
 # workers each with its own GPU context (the staged path without the lock beyond 8 of them).
-out=gpurun_out/r5_server; mkdir -p $out
+out=gpurun_out/server_probe; mkdir -p $out
 python -m pytest tests/test_gpu_server.py -q -m gpu 2>&1 | tail -5 | tee $out/gputest.txt
 for W in 8 16 32; do for cfg in 1 3; do
   echo "== $W workers cfg $cfg through the server" | tee -a $out/probe.txt

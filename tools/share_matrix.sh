@@ -2,7 +2,7 @@
 # The review's sharing matrix once more, with the FINAL library of round 5 (its kernels changed after profiles/r5_share_probes.txt):
 # 16 / 32 workers x 1500 calls, N = 2000 and 6000, lock on and off; 8 workers x 2000 under the lock.  SHORT=1: without the two
 # 32-worker N = 6000 runs (11 minutes).
-out=gpurun_out/r5_share_final; mkdir -p $out; rm -f $out/*.txt
+out=gpurun_out/share_matrix; mkdir -p $out; rm -f $out/*.txt
 sha256sum psoap_amd/csrc/libpsoap_gp.so | tee $out/all.txt
 run() { name=$1; shift; echo "== $name: $*" | tee -a $out/all.txt; ( time timeout ${TMO:-1500} env "$@" ) > $out/$name.txt 2>&1; grep -v "^$\|^psoap: " $out/$name.txt | tail -6 | cut -c1-900 | tee -a $out/all.txt; }
 R=${R:-1500}
