@@ -9,14 +9,13 @@ RCCL and summed in fixed chunk order (the gather-and-sum of psoap/sample_paralle
 So `value` INCLUDES the per-step H2D of c*N doubles per proposal and the D2H of the results (BASELINE.md
 section 4).
 
-Round 4, default `--mode stream`: the K timed steps run through ONE resident launch of the persistent kernel
-(psoap_stream_*: include/psoap_gp.h), the ensemble as two half-ensembles in flight -- the proposals of a half
-depend on that half's previous results only, as in a red / black ensemble move or with independent chains, so a
-half is fetched and its successor submitted while the other half keeps the device busy (the back-to-back
-iterations of psoap/sample_parallel.py:434-438).  The timed region starts with nothing in flight and no launch
-resident, and ends when the last result is back and the launch has left.  `--mode dag` is rounds 1-3's path,
-one launch of the kernel per step (next step's proposals uploaded under it); its rate is reported beside the
-headline in the same run (`launch_per_step`).
+Default `--mode dag` (rounds 1-3, and again from round 6 on): one launch of the persistent kernel per step, the next
+step's proposals uploaded under it.  `--mode stream` (round 4) runs the K timed steps through ONE resident launch
+(psoap_stream_*: include/psoap_gp.h), the ensemble as two half-ensembles in flight -- a half is fetched and its successor
+submitted while the other half keeps the device busy (the back-to-back iterations of psoap/sample_parallel.py:434-438); the
+timed region then starts with nothing in flight and no launch resident and ends when the last result is back and the
+launch has left.  Whichever mode is `value`, the other is measured beside it in the same run (`stream_beside` /
+`launch_per_step`): since round 5 the two tie (N = 6000: 0.99-1.005 x), so the simple one is the default.
 Chunks are independent, so per-GPU work is fixed as N grows ("weak"); at 8 GPUs a step is exactly
 the 32-walker x 8-chunk ensemble of configs[3].  The same run also times configs[3] AS NAMED -- the fixed
 8-chunk x 32-walker ensemble, chunk k on rank k mod G, 256 evaluations per step at every G -- and reports
@@ -255,7 +254,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.mode is None:
-        args.mode = "stream" if world == 1 else "dag"
+        # Round 6: one launch per step IS the headline path on every number of GPUs.  The resident launch (round 4) ties
+        # with it since the batch kernels' round-5 gains (N = 6000: 0.99-1.005 x, N = 8192: 1.002 x, below N = 5000 slower:
+        # profiles/r5_stream_table.jsonl, r6_stream_table.jsonl), needs ~1,500 lines of protocol, and cannot run beside a
+        # device collective; it stays an opt-in (--mode stream) and is measured BESIDE the headline in every default run
+        # (`stream_beside`), so that the choice is re-made from data each round.
+        args.mode = "dag"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if args.backend == "gloo":       # dry run: several ranks may share one GPU
@@ -353,7 +357,10 @@ def main():
         return time.perf_counter() - t0, table, total, (state["k"] - 1) & 1
 
     stream_info = None
-    if args.mode == "stream":
+
+    def measure_stream(n_warm, n_steps):
+        """n_steps ensemble steps through ONE resident launch, from nothing in flight to nothing in flight and no launch
+        resident: (seconds, table, total, last proposal set, the launch's own account)"""
         if B % args.stream_groups:
             raise SystemExit("--walkers must be a multiple of --stream-groups")
         pipe = StreamPipeline(h, c, B, args.stream_groups)
@@ -370,43 +377,46 @@ def main():
             half["table"][:, rows] = t
             half["total"][rows] = sum_over_chunks(t)
 
-        def run_stream_shared(n_steps):
+        def run_stream_shared(n):
             """the dry-run form: a step's sub-ensembles go through the stream together and the resident launch leaves
             before the gather -- the same entry points, no overlap (the device belongs to one rank at a time)"""
-            for k in range(n_steps):
+            for k in range(n):
                 with gpu:
                     pipe.start(*sets[k & 1], stagger=0.0)
                     lnp = pipe.drain()
                     h.stream_pause()
                 table, total = gather(lnp)
-            return table, total, (n_steps - 1) & 1
+            return table, total, (n - 1) & 1
 
-        def run_stream(n_steps):
-            """n_steps ensemble steps through one resident launch; from nothing in flight to nothing in flight"""
+        def run_stream(n):
             if shared_gpu:
-                return run_stream_shared(n_steps)
+                return run_stream_shared(n)
             pipe.start(*sets[0])
-            for k in range(1, n_steps):
+            for k in range(1, n):
                 # per sub-ensemble: results of step k - 1 -> gather over the ranks -> proposals of step k submitted
                 pipe.step(*sets[k & 1], between=gather_half)
             pipe.drain(between=gather_half)
             h.stream_pause()                           # the resident launch leaves: the device is free again
-            return half["table"].copy(), half["total"].copy(), (n_steps - 1) & 1
+            return half["table"].copy(), half["total"].copy(), (n - 1) & 1
 
-        if args.warmup > 0:
+        if n_warm > 0:
             # the warm-up steps also give the period the timed region's start-up stagger is set from (they start in
             # lock-step themselves: the pipeline knows no period yet)
             tw = time.perf_counter()
-            run_stream(args.warmup)
-            pipe.period = (time.perf_counter() - tw) / args.warmup
+            run_stream(n_warm)
+            pipe.period = (time.perf_counter() - tw) / n_warm
         fence_nohandle()
         t0 = time.perf_counter()
-        table, total, last_set = run_stream(args.steps)
+        table, total, last_set = run_stream(n_steps)
         fence_nohandle()
         dt = time.perf_counter() - t0
-        stream_info = dict(h.stream_last_launch(), **h.stream_stats())
+        info = dict(h.stream_last_launch(), **h.stream_stats())
         with gpu:
             pipe.close()
+        return dt, table, total, last_set, info
+
+    if args.mode == "stream":
+        dt, table, total, last_set, stream_info = measure_stream(args.warmup, args.steps)
     else:
         dt, table, total, last_set = run_launch_per_step(args.warmup, args.steps)
     if world > 1:
@@ -456,6 +466,19 @@ def main():
                              f"streamed {table[:, bad].tolist()} (rank {rank})")
         per_step = {"evals_per_s": evals / dps, "ms_per_step": 1e3 * dps / args.steps,
                     "what": "rounds 1-3: one launch of the persistent kernel per step, next step's proposals uploaded under it"}
+
+    # ---- the resident launch beside the launch-per-step headline (same run, same box; never `value` in dag mode): what
+    # keeps the default an informed one (verdict of round 5: the stream has to earn its place with >= 1.02 x)
+    stream_beside = None
+    if args.mode == "dag" and world == 1 and not shared_gpu and not args.no_extras:
+        dss, tss, totss, lsss, info_s = measure_stream(min(args.warmup, 2), args.steps)
+        if lsss == 1:
+            totss = np.roll(totss, -1)
+        require(close(totss, total), "the resident launch vs the launch-per-step headline on the same proposals")
+        stream_beside = {"evals_per_s": evals / dss, "ms_per_step": 1e3 * dss / args.steps,
+                         "ratio_to_value": (evals / dss) / value, "scheme": info_s.get("scheme"),
+                         "launch_ms": info_s.get("ms"), "matrices": info_s.get("matrices"),
+                         "what": f"the same {args.steps} steps through ONE resident launch, {args.stream_groups} sub-ensembles in flight (--mode stream)"}
 
     # ---- proposals-resident rate (the round-1 headline; never `value`): eval + fetch + gather only
     with gpu:
@@ -566,6 +589,7 @@ def main():
             "library": library,
             "launch_per_step": per_step,
             "stream": stream_info,
+            "stream_beside": stream_beside,
             "resident_evals_per_s": resident_value,
             "inclusive_over_resident": value / resident_value,
             "roofline": {"bound": "mfma", "kernel": dom_name,

@@ -286,6 +286,54 @@ __device__ __forceinline__ void dag_wait_ge2(int* fa, int* fb, int target, DagCt
     __syncthreads();
 }
 
+// -DPSOAP_CHAOS (a test build, tools/build_variant.py chaos -DPSOAP_CHAOS): one task in sixteen -- chosen by a hash of its
+// ticket, its matrix's submission number and the place -- sleeps ~100 us at its start, or between its last output and its
+// publications.  A protocol whose every dependency is an explicit hand-off returns the same bits whatever a task's timing;
+// one that leans on "that task is always through by then" does not: round 6 found two such places in the following scheme
+// (the accumulator chain, the in-order progress words) through the rare wrong values they produced, and this is the
+// instrument that shows there is no third (tools/soak_stream.py under the chaos build; -DPSOAP_NO_INORDER brings the
+// second one back, to show that the instrument sees it).
+__device__ __forceinline__ void dag_chaos(unsigned int key, unsigned int place)
+{
+#ifdef PSOAP_CHAOS
+    unsigned int h = (key ^ (place * 0x9E3779B9u)) * 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    if ((h & 15u) == 0u)
+        for (int i = 0; i < 30; ++i) __builtin_amdgcn_s_sleep(127);
+#else
+    (void)key; (void)place;
+#endif
+}
+
+// thread 0 only, no fence, no barrier: until a progress word has reached `target` -- the IN-ORDER publication of the words
+// whose readers take "value >= q + 1" to mean "everything up to q": potrf_done and rows_done.  Their producers -- the
+// diagonal tasks, the last finishers of the block rows -- normally end in order; in the following scheme (second level)
+// only TIME said so (diagonal task q + 1 still has a block to factor when task q writes its outputs), and a producer that
+// is late by a factorisation's length -- a preempted workgroup on a shared device -- let its successor's larger value
+// satisfy waits for its own unfinished outputs (round 6; the accumulator records of common.hpp close the silent half of
+// that hole, this closes the rest).  The predecessor holds a smaller ticket: it runs or is through.
+__device__ __forceinline__ void dag_spin_ge(int* flag, int target, DagCtl* ctl, unsigned int code)
+{
+#ifdef PSOAP_NO_INORDER            // (A/B of the chaos build only: rounds 3-5's publication, ordered by time alone)
+    (void)flag; (void)target; (void)ctl; (void)code;
+    return;
+#endif
+    long long spins = 0;
+    while (dag_peek(flag) < target) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > DAG_MAX_SPINS) {
+            if (__hip_atomic_fetch_or(&ctl->error, 1u, PSOAP_RLX_AGENT) == 0u) {
+                __hip_atomic_store(&ctl->pad[0], code, PSOAP_RLX_AGENT);
+                __hip_atomic_store(&ctl->pad[1], (unsigned int)target, PSOAP_RLX_AGENT);
+                __hip_atomic_store(&ctl->pad[2], (unsigned int)dag_peek(flag), PSOAP_RLX_AGENT);
+            }
+            break;
+        }
+    }
+}
+
 // producer side, part 1 (all threads): drain own stores, meet at the barrier
 __device__ __forceinline__ void dag_drain()
 {
@@ -303,7 +351,7 @@ __device__ __forceinline__ void dag_release_fence()
 // a task of block row q of this matrix is complete (thread 0, after dag_release_fence)
 // (M3: three counters in turn -- scheme 0, whose diagonal tasks run up to two block rows ahead of the strip solves)
 template <bool M3 = false>
-__device__ __forceinline__ void dag_task_done(MatFlags* f, int q, int ntasks_row, int n = 1)
+__device__ __forceinline__ void dag_task_done(MatFlags* f, int q, int ntasks_row, int n = 1, DagCtl* ctl = nullptr)
 {
     int* cnt = M3 ? (q % 3 == 2 ? &f->cnt3 : &f->cnt[q % 3]) : &f->cnt[q & 1];
     const int old = __hip_atomic_fetch_add(cnt, n, PSOAP_RLX_AGENT);
@@ -315,6 +363,8 @@ __device__ __forceinline__ void dag_task_done(MatFlags* f, int q, int ntasks_row
         // cnt: drain the reset, then publish the row with a release store (two relaxed stores are unordered)
         __hip_atomic_store(cnt, 0, PSOAP_RLX_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (rows are published in order: "rows_done >= q + 1" has to mean rows 0 .. q -- dag_spin_ge)
+        if (ctl && q > 0) dag_spin_ge(&f->rows_done, q, ctl, 11u);
         __hip_atomic_store(&f->rows_done, q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -804,7 +854,8 @@ PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double*
                                                         const double* prev, int Npad, MatFlags* f, DagCtl* ctl, int q,
                                                         int ntasks_row, bool fused, int* chain_ctr, int chain_len,
                                                         lds_double* smem, lds_double* zk, lds_double* colsum,
-                                                        unsigned long long* tl, bool xfollow = false, bool two_panels = false)
+                                                        unsigned long long* tl, bool xfollow = false, bool two_panels = false,
+                                                        unsigned int chaos = 0u)
 {
     const auto sm = PSOAP_DIAG_SMEM(smem);
     // the wait for the tile's PART chain (it ran ahead: normally no wait at all) happens in here, not in front of the
@@ -832,10 +883,12 @@ PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double*
                                                 two_panels ? Km + (size_t)(k0 - 2 * NB) * ld + k0 : nullptr}
                               : ps::SpineFollow{nullptr, nullptr, 0, nullptr, nullptr});
 #endif
+    dag_chaos(chaos, 1u);        // (the tail of a diagonal task: its outputs are issued, nothing is published yet)
     dag_drain();
     if (tl && threadIdx.x == 0) tl[2] = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x == 0) {
         dag_release_fence();
+        if (q > 0) dag_spin_ge(&f->potrf_done, q, ctl, 12u);        // (in order: dag_spin_ge)
         __hip_atomic_store(&f->potrf_done, q + 1, PSOAP_RLX_AGENT);
     }
     if (fused) {
@@ -846,10 +899,10 @@ PSOAP_DIAG_FN void dag_diag_fast(double* Km, int ld, int k0, double* Wm, double*
         if (threadIdx.x == 0) {
             dag_release_fence();
             __hip_atomic_store(&f->next_done, q + 1, PSOAP_RLX_AGENT);
-            dag_task_done(f, q, ntasks_row, 2);
+            dag_task_done(f, q, ntasks_row, 2, ctl);
         }
     } else if (threadIdx.x == 0) {
-        dag_task_done(f, q, ntasks_row);
+        dag_task_done(f, q, ntasks_row, 1, ctl);
     }
     __builtin_amdgcn_s_setprio(0);
     if (tl && threadIdx.x == 0) tl[3] = __builtin_amdgcn_s_memrealtime();
@@ -1075,6 +1128,7 @@ struct DagSpecialArgs {
     int xlink;                     // diagonal task: the strip above arrives row block by row block (SpineFollow);
                                    // following strip solve: it delivers its tile that way (dag_pss, xpub)
     int xfirst;                    // the first block row whose strip solves follow
+    unsigned int chaos;            // -DPSOAP_CHAOS: the task's key (dag_chaos)
 };
 
 // The record travels through LDS (round 4; rounds 2-3: through the caller's stack frame, i.e. 288 B of scratch memory per
@@ -1090,7 +1144,7 @@ __device__ __attribute__((noinline, not_tail_called)) void dag_special(lds_speci
     if (a->mode == 0) {
         dag_diag_fast(a->Km, a->ld, a->k0, a->Wm, a->Rv, a->acc, a->prev, a->Npad, a->f, a->ctl, a->q, a->ntasks_row,
                       a->fused != 0, a->chain_ctr, a->chain_len, a->smem, a->zk, a->colsum, a->tl, a->xlink != 0,
-                      a->pb - a->pa == 2);
+                      a->pb - a->pa == 2, a->chaos);
         return;
     }
     // the whole task: the tile so far (covariance - the running sum of its chain), the left-looking update over the
@@ -1165,12 +1219,13 @@ __device__ __attribute__((noinline, not_tail_called)) void dag_special(lds_speci
     dag_pss<C, AUG>(t, Km, ld, k0, j0, mbq, f, q, ctl, Rv, Npad, smem, a->zk, a->colsum, xlink, xlink && pubnext,
                     q > si(a->xfirst));
     if (tl && threadIdx.x == 0) tl[6] = __builtin_amdgcn_s_memrealtime();
+    dag_chaos(a->chaos, 2u);     // (the tail of a following strip solve)
     dag_drain();
     if (threadIdx.x == 0) {
         dag_release_fence();
         if (pubnext) __hip_atomic_store(&f->next_done, q + 1, PSOAP_RLX_AGENT);   // tile (q, q+1) is final
         __hip_atomic_store(&f->rvrow[j0 / NB], q + 1, PSOAP_RLX_AGENT);           // ... and the right-hand side block j has its share
-        dag_task_done(f, q, ntasks_row);
+        dag_task_done(f, q, ntasks_row, 1, ctl);
     }
 }
 #endif
@@ -1993,6 +2048,13 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             tlog_l[ticket * 8 + 7] = ((unsigned long long)(unsigned int)home << 32) |
                                    (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));
         }
+        unsigned int chaos_key = 0u;
+#ifdef PSOAP_CHAOS
+        chaos_key = ticket * 2654435761u;
+        if constexpr (STREAM) chaos_key ^= (unsigned int)__hip_atomic_load(&st.lanes[b].seq, PSOAP_RLX_AGENT) * 40503u;
+        else chaos_key ^= (unsigned int)__builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_s_memrealtime()) & 0xffffff00u;
+        dag_chaos(chaos_key, 0u);        // (a task that starts late)
+#endif
         const int ttype = task.type & DAG_TYPE_MASK;
         const bool chain = (task.type & DAG_CHAIN) != 0;
         const bool is_part = (ttype == DAG_PART);
@@ -2031,6 +2093,7 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             // DAG_FUSED on a strip solve (it delivers its tile row block by row block, and follows the row above likewise)
             args.xlink = fast_diag ? ((task.type & DAG_NOSOLVE) != 0) : ((task.type & DAG_FUSED) != 0);
             args.xfirst = (int)queues.follow_first;
+            args.chaos = chaos_key;
             __syncthreads();
             {
                 unsigned int aa = (unsigned int)(uintptr_t)(__attribute__((address_space(3))) DagSpecialArgs*)&args;
@@ -2095,6 +2158,7 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
         if (tlog_l && !is_part && threadIdx.x == 0) tlog_l[ticket * 8 + 4] = __builtin_amdgcn_s_memrealtime();     // a final's stores issued
         if (is_part) {
             if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 2] = __builtin_amdgcn_s_memrealtime();              // stores issued
+            dag_chaos(chaos_key, 3u);
             dag_drain();
             if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 4] = __builtin_amdgcn_s_memrealtime();              // drained
             if (threadIdx.x == 0) {
@@ -2120,10 +2184,12 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             // (no branch around the poll: rows_done >= 0 always holds)
             if constexpr (CONT) dag_wait_ge(&f->rows_done, q >= 3 ? q - 2 : 0, ctl, 9u);
             potrf_blocked(Km, ld, k0, Wm, Rv, mat.acc);
+            dag_chaos(chaos_key, 4u);
             dag_drain();
             if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 2] = __builtin_amdgcn_s_memrealtime();
             if (threadIdx.x == 0) {
                 dag_release_fence();
+                if (q > 0) dag_spin_ge(&f->potrf_done, q, ctl, 12u);        // (in order: dag_spin_ge)
                 __hip_atomic_store(&f->potrf_done, q + 1, PSOAP_RLX_AGENT);
             }
             if (task.type & DAG_FUSED) {
@@ -2136,10 +2202,10 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
                 if (threadIdx.x == 0) {
                     dag_release_fence();
                     __hip_atomic_store(&f->next_done, q + 1, PSOAP_RLX_AGENT);
-                    dag_task_done(f, q, ntasks_row, 2);
+                    dag_task_done(f, q, ntasks_row, 2, ctl);
                 }
             } else if (threadIdx.x == 0) {
-                dag_task_done<CONT>(f, q, ntasks_row);
+                dag_task_done<CONT>(f, q, ntasks_row, 1, ctl);
             }
             __builtin_amdgcn_s_setprio(0);
         } else if (task.type & DAG_NOSOLVE) {
@@ -2151,12 +2217,13 @@ __global__ __launch_bounds__(GEMM_THREADS, WPE) void k_chol_dag(const DagMat* __
             dag_wait_ge(&f->potrf_done, q + 1, ctl, 3u + 16u * (unsigned int)q + 4096u * (unsigned int)b);
             if (tlog_l && threadIdx.x == 0) tlog_l[ticket * 8 + 2] = __builtin_amdgcn_s_memrealtime();
             dag_trsm<true>(t, Km, ld, k0, j0, Wm, Rv, Npad, vec1, vec2);
+            dag_chaos(chaos_key, 5u);
             dag_drain();
             if (threadIdx.x == 0) {
                 dag_release_fence();
                 // (counted BEFORE the tile is announced: whatever reads the tile belongs to a later row, so a row is
                 // complete -- rows_done -- in row order)
-                dag_task_done<CONT>(f, q, ntasks_row);
+                dag_task_done<CONT>(f, q, ntasks_row, 1, ctl);
                 // tile (q, j) is final and its share of the right-hand side block j applied
                 if constexpr (CONT) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

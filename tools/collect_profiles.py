@@ -22,6 +22,7 @@ KERNEL = "k_chol_dag"
 # round 4: the dominant kernel is the RESIDENT launch, k_chol_dag<2, false, false, true> (STREAM); bench.py --steps 5
 # --warmup 5 gives it 160 evaluations per dispatch
 EVALS_PER_DISPATCH = 160
+MODE = "stream"
 
 
 def is_stream(name):
@@ -77,6 +78,9 @@ for name in ("sq", "fetch", "write"):
     keep = [r for r in rows if KERNEL in r["Kernel_Name"]]
     stream_rows = [r for r in keep if is_stream(r["Kernel_Name"])]
     dominant = stream_rows if stream_rows else keep
+    if not stream_rows:
+        # round 6: the headline is one launch of k_chol_dag<2, false, false, false, 2> per step, 32 evaluations per dispatch
+        MODE, EVALS_PER_DISPATCH = "dag", 32
     with open(os.path.join(dst, f"{tag}_pmc_{name}.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         w.writeheader()
@@ -86,12 +90,13 @@ for name in ("sq", "fetch", "write"):
 fetch_kb = sum(means["FETCH_SIZE"]) / len(means["FETCH_SIZE"])
 write_kb = sum(means["WRITE_SIZE"]) / len(means["WRITE_SIZE"])
 tpath = os.path.join(dst, f"{tag}_traffic.json")
-old = json.load(open(tpath)) if os.path.exists(tpath) else {
+old = json.load(open(tpath)) if os.path.exists(tpath) and json.load(open(tpath)).get("workload", {}).get("mode") == MODE else {
     "round": int(tag[1:]) if tag[1:].isdigit() else tag,
     "source": f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, "
               "bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-extras --no-strong)",
-    "kernel": "k_chol_dag<2, false, false, true, 2> (the resident launch of bench.py --mode stream)",
-    "workload": {"N": 6000, "components": 2, "walkers": 32, "mode": "stream", "evaluations_per_launch": EVALS_PER_DISPATCH},
+    "kernel": ("k_chol_dag<2, false, false, true, 2> (the resident launch of bench.py --mode stream)" if MODE == "stream" else
+               "k_chol_dag<2, false, false, false, 2> (one launch per step: bench.py's default --mode dag)"),
+    "workload": {"N": 6000, "components": 2, "walkers": 32, "mode": MODE, "evaluations_per_launch": EVALS_PER_DISPATCH},
     "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of 16 B/lane coalesced reads); "
             "WRITE_SIZE taken as is"}
 old.update(fetch_size_kb_raw=fetch_kb, write_size_kb_raw=write_kb, fetch_correction=2.0,
