@@ -37,7 +37,9 @@
  *     moved between compute units while a task ran (the one disturbance its
  *     hand-off protocol does not survive): such an evaluation is
  *     run again (PSOAP_SHARE_RETRIES, 3; bit-identical when clean), then by the
- *     staged path (kernel boundaries only).  A result is never silently wrong;
+ *     staged path (kernel boundaries only).  Measured clean up to 8 processes per device
+ *     (0 wrong in 246,000 evaluations, rounds 4-5); the check sees a workgroup that is
+ *     somewhere else at the end of a task than at its start, not one that moved and came back;
  *   - with PSOAP_DEVICE_LOCK=0 and several processes on the device, or more
  *     than PSOAP_SHARE_DAG_MAX (8) of them, evaluations take the staged path
  *     from the start and without the lock (kernel boundaries only: immune, and
@@ -299,9 +301,9 @@ int psoap_chunk_dag_tasklog(psoap_chunk *h, unsigned long long *out, long long m
  * While a stream is open the handle's batch entry points (psoap_batch_*, psoap_lnlike*) are refused -- the matrix
  * workspaces belong to the resident launch -- and other launches on the device wait until it leaves (it does so by
  * itself once nothing has been in flight for PSOAP_STREAM_IDLE_MS, default 20 ms, and comes back on the next submit). */
-/* c: number of components of every submission; scheme: -1 automatic (by lanes and N: 0 or 1), 0 throughput, 1 latency.
- * 2 (following) is refused: through a resident launch it returns a rare wrong value (late round 5, LABNOTES 12); the
- * launch-per-step entry points keep using it for single evaluations and small batches. */
+/* c: number of components of every submission; scheme: -1 automatic (by lanes and N, as for a batch of `lanes` matrices),
+ * 0 throughput, 1 latency, 2 following (refused in late round 5 for a rare wrong value; round 6 removed its cause --
+ * LABNOTES 14 -- and all three run here). */
 int psoap_stream_open(psoap_chunk *h, int c, int lanes, int scheme);
 /* n proposals -- lwl (n, c, N), gp (n, 2c) as psoap_batch_upload -- into n free lanes; tickets[n] identify them.
  * Fails when fewer than n lanes are free. */

@@ -2002,12 +2002,6 @@ static int stream_free(psoap_chunk* h)
     return 0;
 }
 
-static bool stream_allows_scheme2()
-{
-    const char* e = getenv("PSOAP_STREAM_ALLOW_SCHEME2");
-    return e && e[0] == '1';
-}
-
 static int stream_open_impl(psoap_chunk* h, int c, int lanes, int scheme)
 {
     StreamState& st = h->stream;
@@ -2017,7 +2011,6 @@ static int stream_open_impl(psoap_chunk* h, int c, int lanes, int scheme)
     if (scheme < 0) {
         const char* e = getenv("PSOAP_STREAM_SCHEME");
         scheme = e ? atoi(e) : dag_auto_scheme(all);
-        if (scheme == 2 && !stream_allows_scheme2()) scheme = 1;       // (see psoap_stream_open)
     }
     // every lane runs the task list of ONE matrix, cut as if `lanes` matrices shared the workers (one workgroup dispatches)
     // (PSOAP_STREAM_BURSTS=0: the lanes ticket by ticket in turn instead of a block row at a time -- experiments)
@@ -2096,13 +2089,10 @@ extern "C" int psoap_stream_open(psoap_chunk* h, int c, int lanes, int scheme)
     if (scheme < -1 || scheme > 2) FAIL("psoap_stream_open: scheme must be -1 (automatic), 0, 1 or 2");
     if (h->P > 255) FAIL("psoap_stream_open: N too large for the persistent kernel (N <= 32640)");
     if (h->stream.open) FAIL("psoap_stream_open: the handle already has an open stream");
-    // The following scheme (2) is not used in streams (late round 5): through a resident launch it returns a wrong value
-    // about once in 20,000 (N = 8192) ... 150,000 (N = 4096) matrices -- tools/soak_stream.py; the launch-per-step path with
-    // the same task lists: 0 in 333,000, schemes 0 and 1 in streams: 0 in 100,000 each and in every soak of the headline.
-    // Cause not found; PSOAP_STREAM_ALLOW_SCHEME2=1 keeps it reachable for that search.
-    if (scheme == 2 && !stream_allows_scheme2())
-        FAIL("psoap_stream_open: the following scheme (2) is not available in streams (rare wrong values through a resident "
-             "launch, LABNOTES 12): use -1 (automatic), 0 or 1");
+    // (Late round 5 refused the following scheme (2) here: through a resident launch it returned a wrong value once in 20,000
+    // ... 150,000 matrices.  Round 6 found the cause -- an unordered read-modify-write chain on the per-matrix accumulator
+    // record and two progress words published out of order, both in the second level of following, neither specific to
+    // streams -- and removed it (common.hpp MatAcc; dag_kernel.hpp dag_spin_ge; LABNOTES 14): all three schemes run here.)
     // the dispatcher keeps 3 x n_epochs velocities, 16 parameters and one flag per lane in the tile engine's LDS array
     if (h->n_epochs > 0 && (3 * (size_t)h->n_epochs + 16) * sizeof(double) + sizeof(int) * (size_t)lanes > GEMM_LDS_BYTES)
         FAIL("psoap_stream_open: too many epochs for the dispatcher's staging (3 n_epochs + 16 doubles + one int per lane must "

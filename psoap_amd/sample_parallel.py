@@ -182,21 +182,23 @@ class Posterior:
             self._streaming = False
 
 
-# Where the resident launch pays (profiles/r4_stream_table.jsonl, r5): from N ~ 5000 on with at least 16 chains; below, the
-# launch-per-step path is 1-5 % ahead.
-STREAM_MIN_N = 5000
+# Round 6: the automatic rule never streams.  The resident launch ties with one launch per step since the batch kernels'
+# round-5 gains (N = 6000: 0.99-1.005 x, N = 8192: 1.002 x, 1-7 % slower below N = 5000: profiles/r5_stream_table.jsonl,
+# r6_*), cannot run beside a device collective, and holds the device while it has results outstanding: it has to be asked
+# for (`--stream on`, `run(stream=True)`).  bench.py measures it beside the headline in every default run (`stream_beside`).
+STREAM_MIN_N = 5000            # (where a forced stream is at least level: below, the launch-per-step path is 1-7 % ahead)
 STREAM_MIN_CHAINS = 16
 
 
 def want_stream(post, chunks, n_chains) -> bool:
-    """the automatic rule of ``run(stream=None)``: ONE rank with one chunk, an even number of >= 16 chains, chunks of >= 5000
-    pixels; and only one process on the GPU (a resident launch holds the device while it has results outstanding)"""
+    """the automatic rule of ``run(stream=None)``: False (round 6; see above).  ``PSOAP_STREAM_AUTO=1`` brings round 5's rule
+    back for experiments: ONE rank with one chunk, an even number of >= 16 chains, chunks of >= 5000 pixels, one process on
+    the GPU."""
+    if os.environ.get("PSOAP_STREAM_AUTO", "0") != "1":
+        return False
     if not post.can_stream() or n_chains < STREAM_MIN_CHAINS or n_chains % 2:
         return False
     if post.world > 1:
-        # every half-ensemble waits for its gather before it is resubmitted: ~2 ms on the host with half the device idle
-        # (a device collective waits for the resident launch to leave altogether) -- more than the resident launch gains
-        # (profiles/r5_gather_beside_stream.txt); several ranks keep the launch-per-step path unless told otherwise
         return False
     if not isinstance(post.device_lock, _NoLock):
         return False
@@ -302,7 +304,7 @@ def main(argv=None):
     parser.add_argument("--prefix", default="", help="Directory prefix of the chunk files.")
     parser.add_argument("--overwrite", action="store_true", help="Replace existing run directories.")
     parser.add_argument("--stream", choices=("auto", "on", "off"), default="auto",
-                        help="Iterations through one resident launch per GPU (auto: one chunk per GPU, >= 16 chains, N >= 5000).")
+                        help="Iterations through one resident launch per GPU (auto = off since round 6: it ties with one launch per step).")
     args = parser.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -113,7 +113,9 @@ for a, b in ((f"latency_{tag}.jsonl", f"{tag}_latency_table.jsonl"), (f"bench_{t
              (f"shared_gpu_probe_{tag}.txt", f"{tag}_shared_gpu_probe.txt"), (f"evidence_status_{tag}.txt", f"{tag}_evidence_status.txt"),
              (f"predict_timeline_{tag}.txt", f"{tag}_predict_timeline.txt"), (f"part_wait_share_{tag}.txt", f"{tag}_part_wait_share.txt"),
              (f"sampler_stream_{tag}.txt", f"{tag}_sampler_stream_same_call.txt"),
-             (f"gather_beside_stream_{tag}.txt", f"{tag}_gather_beside_stream_same_call.txt")):
+             (f"gather_beside_stream_{tag}.txt", f"{tag}_gather_beside_stream_same_call.txt"),
+             (f"small_{tag}.jsonl", f"{tag}_small_matrices_same_call.jsonl"), (f"soak_perm_{tag}.txt", f"{tag}_soak_perm.txt"),
+             (f"chaos_{tag}.txt", f"{tag}_chaos_same_call.txt")):
     p = os.path.join(ROOT, "gpurun_out", a)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, b))

@@ -34,20 +34,23 @@ step profile bash -c "tools/profile_round.sh $TAG > gpurun_out/profile_round_$TA
 step latency bash -c "timeout 900 python tools/latency_quick.py 1,2,3,5 1,2,4,8,16,32 > gpurun_out/latency_$TAG.jsonl 2>/dev/null"
 step stream_table bash -c "timeout 900 python tools/stream_table.py > gpurun_out/stream_table_$TAG.jsonl 2>/dev/null"
 step timeline bash -c "timeout 300 python tools/dag_timeline.py 3 32 2>&1 | grep -v amdgpu.ids > gpurun_out/timeline_launch_per_step_$TAG.txt"
-step stream_timeline bash -c "PSOAP_STREAM_IDLE_MS=50 timeout 300 python tools/stream_timeline.py 3 32 2 8 2>&1 | grep -v amdgpu.ids > gpurun_out/timeline_$TAG.txt"
 step fill bash -c "timeout 300 python tools/fill_bench.py 2>/dev/null > gpurun_out/fill_$TAG.jsonl"
-step follow_table bash -c "tools/follow_table.sh 1,2,4,8,16,32 > gpurun_out/follow_table_$TAG.txt 2>&1"
 step row_periods bash -c "{ timeout 120 python tools/row_periods.py 3 1; timeout 120 python tools/row_periods.py 5 1; } 2>&1 | grep -v amdgpu.ids > gpurun_out/row_periods_$TAG.txt"
 step predict_timeline bash -c "timeout 300 python tools/predict_timeline.py 1000 2>&1 | grep -v amdgpu.ids > gpurun_out/predict_timeline_$TAG.txt"
-step part_wait_share bash -c "{ timeout 120 python tools/part_wait_share.py 3 1; timeout 120 python tools/part_wait_share.py 3 8; timeout 120 python tools/part_wait_share.py 5 1; timeout 120 python tools/part_wait_share.py 1 32; } 2>&1 | grep -v amdgpu.ids > gpurun_out/part_wait_share_$TAG.txt"
 step sampler_stream bash -c "timeout 300 python tools/sampler_stream_bench.py 30 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/sampler_stream_$TAG.txt"
 step gather bash -c "python -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node=1 tools/gather_beside_stream.py 12 device,host,per-step 2>&1 | grep RESULT > gpurun_out/gather_beside_stream_$TAG.txt"
-step wg_occupancy bash -c "timeout 120 python tools/wg_occupancy.py 3 1 200 2>&1 | grep -v amdgpu.ids > gpurun_out/wg_occupancy_$TAG.txt"
-step scheme_table bash -c "timeout 600 python tools/scheme_table.py 2>&1 | grep -v amdgpu.ids > gpurun_out/scheme_table_$TAG.txt"
-step queue_sweep bash -c "timeout 600 python tools/queue_sweep.py 3 9,10,12,13,17,20,25,31,32 2>&1 | grep -v amdgpu.ids > gpurun_out/queue_sweep_final_$TAG.txt"
-# several processes on this one GPU (round 5: no wrong value and no time-out with the library's lock on OR off, 8 and 16 workers;
-# the step fails on a single wrong value)
-step shared_gpu bash -c "{ for a in '8 300 3 2' '8 200 3 0' '16 300 3 2' '16 200 3 0' '16 300 1 2'; do timeout 600 python tools/shared_gpu_probe.py \$a || exit 1; done; } 2>&1 | grep -v amdgpu.ids > gpurun_out/shared_gpu_probe_$TAG.txt"
+# (round 6) many small matrices in one group launch: the reference's chunk sizes (N = 1008, 2000) x 8 chunks x 32 walkers
+step small bash -c "{ timeout 300 python tools/small_bench.py 2 12 84 8 32 0; timeout 300 python tools/small_bench.py 2 10 200 8 32 0; timeout 300 python tools/small_bench.py 2 10 200 1 32 0; } 2>/dev/null | grep '^{' > gpurun_out/small_$TAG.jsonl"
+# (round 6) the launch-per-step path with a different proposal in every workspace at every launch, NaN-poisoned workspaces
+step soak_perm bash -c "PSOAP_DEBUG_POISON=15 timeout 200 python tools/soak_batch_perm.py 2 8 60 2>&1 | grep -v amdgpu.ids > gpurun_out/soak_perm_$TAG.txt"
+# (round 6) the chaos build (ab_libs/chaos.so = tools/build_variant.py chaos -DPSOAP_CHAOS of the same sources): one task in
+# sixteen ~100 us late -- the three schemes through streams, bit-identical to the product library's values or the step fails
+if [ -f ab_libs/chaos.so ]; then
+  step chaos bash -c "rm -f gpurun_out/soakref*.npy; export PSOAP_SOAK_REF=\$PWD/gpurun_out/soakref; { for a in '2 8 2' '2 8 0' '2 8 1'; do timeout 200 python tools/soak_stream.py \$a 10; done; for a in '2 8 2' '2 8 0' '2 8 1'; do PSOAP_GP_LIB=\$PWD/ab_libs/chaos.so timeout 300 python tools/soak_stream.py \$a 60; done; } 2>&1 | grep -v amdgpu.ids > gpurun_out/chaos_$TAG.txt; ! grep -q ' [1-9][0-9]* mismatching' gpurun_out/chaos_$TAG.txt"
+fi
+# several processes on this one GPU (no wrong value and no time-out with the library's lock on OR off, 8 and 16 workers; the
+# step fails on a single wrong value)
+step shared_gpu bash -c "{ for a in '8 300 3 2' '16 300 3 2' '16 200 3 0'; do timeout 600 python tools/shared_gpu_probe.py \$a || exit 1; done; } 2>&1 | grep -v amdgpu.ids > gpurun_out/shared_gpu_probe_$TAG.txt"
 cat $STATUS
 if [ $FAILED -ne 0 ]; then echo "evidence INCOMPLETE: at least one step failed"; exit 5; fi
 echo "evidence complete"
