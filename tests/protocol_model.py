@@ -349,3 +349,193 @@ class Model:
             if len(out) >= limit:
                 break
         return out
+
+
+class Model01(Model):
+    """The same check for the task lists of scheme 1 (latency: the row-to-row chain inside fused diagonal tasks) and scheme 0
+    (throughput: tile-level dependencies, the strip solve of tile (q, q+1) continuing into diagonal task q+1), whose tasks run
+    the kernel's generic path (dag_update / dag_store_updated / potrf_blocked / dag_trsm) or, for scheme 1's chained diagonal
+    tasks, dag_diag_fast with its fused strip solve.  A tile has two versions here: 0 = updated (in memory between the update
+    and the strip solve), 1 = final."""
+
+    def __init__(self, P: int, scheme: int, inorder: bool = True):
+        self.scheme = scheme
+        self.P, self.inorder, self.acc_chain, self.rv_wait = P, inorder, False, True
+        self.g = Graph()
+        self.tasks = lane_plan(P, scheme)
+        self.flags = self.tasks["type"].copy()
+        self.kind = self.tasks["type"] & TYPE_MASK
+        self.pubs, self.adds, self.waits = defaultdict(list), defaultdict(list), []
+        self.writes, self.reads, self.last = defaultdict(dict), [], {}
+        self.launch = self.g.node("launch")
+        self.build01()
+
+    def read_final(self, s, rows, cols):
+        for r in rows:
+            for c in set(cols):
+                s.read(("tile", r, c), 1)
+
+    def update(self, s, q, j, pa, pb, wait_next=False):
+        """dag_update: rows < pb - 1 first, the last panel behind its own wait (scheme 0: the two column tiles' progress words
+        instead of whole rows)"""
+        if pb <= pa:
+            return
+        td = self.scheme == 0
+
+        def wait(v):
+            if td:
+                s.wait(("rvrow", q), v)
+                if j != q:
+                    s.wait(("rvrow", j), v)
+            else:
+                s.wait("next_done" if wait_next else "rows_done", v)
+        if pb - pa > 1:
+            if td:
+                s.wait(("rvrow", q), pb - 1)
+                if j != q:
+                    s.wait(("rvrow", j), pb - 1)
+            else:
+                s.wait("rows_done", pb - 1)
+            self.read_final(s, range(pa, pb - 1), (q, j))
+        wait(pb)
+        self.read_final(s, (pb - 1,), (q, j))
+
+    def build01(self):
+        P, tasks, flags, sch = self.P, self.tasks, self.flags, self.scheme
+        row_members = defaultdict(list)
+        counts_two = set()
+        prev_end = None
+        n_parts = defaultdict(int)
+        for t, k in enumerate(tasks):
+            if self.kind[t] == PART:
+                n_parts[int(k["ctr"])] += 1
+        for t, k in enumerate(tasks):
+            q, j, S, pa, pb = int(k["q"]), int(k["j"]), int(k["S"]), int(k["pa"]), int(k["pb"])
+            ctr, slot = int(k["ctr"]), int(k["slot"])
+            f = int(flags[t])
+            chain = bool(f & CHAIN)
+            wt = ("wt", q % 3 if sch == 0 else q & 1)
+            wt_v = q // 3 if sch == 0 else q // 2
+            if self.kind[t] == PART:
+                s = self.Seq(self, t, f"PART({q},{j})#{S if chain else slot}")
+                self.update(s, q, j, pa, pb)
+                if chain:
+                    if S > 0:
+                        s.wait(("arrive", ctr), S, counter=True)
+                        s.read(("slot", ctr, (S - 1) & 1), S - 1)
+                    s.write(("slot", ctr, S & 1), S)
+                else:
+                    s.write(("gslot", slot), 0)
+                s.add(("arrive", ctr))
+                self.last[t] = s.cur
+                prev_end = s.cur
+                continue
+            n_wait = S - 1
+            preload = chain and n_wait > 0
+
+            def gather(s):
+                if n_wait > 0:
+                    s.wait(("arrive", ctr), n_wait, counter=True)
+                    if chain:
+                        s.read(("slot", ctr, (n_wait - 1) & 1), n_wait - 1)
+                    else:
+                        for u in range(n_wait):
+                            s.read(("gslot", slot + u), 0)
+
+            def factor(s):
+                """potrf_blocked / potrf_spine_fused outputs + the in-order publication"""
+                s.write(("tile", q, q), 1)
+                s.write(wt, wt_v)
+                s.write(("rv", q), q + 1)                        # z_q
+                s.write(("acc", q), 0)
+                if self.inorder and q > 0:
+                    s.wait("potrf_done", q)
+                s.publish("potrf_done", q + 1)
+
+            def trsm(s, jj):
+                """dag_trsm on tile (q, jj): W, the updated tile, z_q; the solved tile; the right-hand side block jj"""
+                s.read(wt, wt_v)
+                s.read(("tile", q, jj), 0)
+                s.read(("rv", q), q + 1)
+                s.write(("tile", q, jj), 1)
+                s.read(("rv", jj), q)
+                s.write(("rv", jj), q + 1)
+
+            if self.kind[t] == DIAG:
+                s = self.Seq(self, t, f"DIAG({q})")
+                if sch == 0 and (f & NOSOLVE):
+                    # owned: run by the workgroup that ran the strip solve of tile (q-1, q), right behind it (k_chol_dag, CONT)
+                    assert prev_end is not None and int(tasks[t - 1]["q"]) == q - 1 and int(tasks[t - 1]["j"]) == q
+                    self.g.edge(prev_end, s.cur)
+                fast = sch == 1 and preload and (f & WAITNEXT) and pb - pa == 1
+                if fast:
+                    # dag_diag_fast, xfollow = false: the chain's sum, then next_done, then the strip above
+                    gather(s)
+                    s.wait("next_done", q)
+                    s.read(("rv", q), q)
+                    self.read_final(s, (q - 1,), (q,))
+                else:
+                    if preload:
+                        gather(s)
+                    self.update(s, q, q, pa, pb, wait_next=bool(f & WAITNEXT))
+                    if not preload:
+                        gather(s)
+                    s.write(("tile", q, q), 0)
+                    if sch == 0:
+                        s.wait("rows_done", q - 2 if q >= 3 else 0)
+                    s.read(("tile", q, q), 0)
+                    s.read(("rv", q), q)
+                factor(s)
+                if sch == 1 and (f & FUSED):
+                    s.wait("off1_ready", q + 1)
+                    trsm(s, q + 1)
+                    s.publish("next_done", q + 1)
+                    counts_two.add(t)
+                self.last[t] = s.cur
+                row_members[q].append(t)
+                prev_end = s.cur
+                continue
+            s = self.Seq(self, t, f"OFF({q},{j})")
+            if preload:
+                gather(s)
+            self.update(s, q, j, pa, pb)
+            if not preload:
+                gather(s)
+            s.write(("tile", q, j), 0)
+            if sch == 1 and (f & NOSOLVE):
+                s.publish("off1_ready", q + 1)                     # update only: the fused diagonal task solves it
+                self.last[t] = s.cur
+                prev_end = s.cur
+                continue
+            s.wait("potrf_done", q + 1)
+            trsm(s, j)
+            self.last[t] = s.cur
+            row_members[q].append(t)
+            s_end = s.cur
+            if sch == 0:
+                s.publish(("rvrow", j), q + 1)                     # (behind the row's count: see k_chol_dag)
+            prev_end = s.cur
+            self.last[t] = s_end
+        g = self.g
+        for q in range(P):
+            members = [self.last[t] for t in row_members[q]]
+            assert len(members) + sum(1 for t in row_members[q] if t in counts_two) == P - q, (q, len(members))
+            n = g.node(f"rows_done={q + 1}")
+            for mbr in members:
+                g.edge(mbr, n)
+            if self.inorder and q > 0:
+                g.edge(self.pubs["rows_done"][-1][1], n)
+            self.pubs["rows_done"].append((q + 1, n))
+        rep = g.node("report")
+        for ev in self.last.values():
+            g.edge(ev, rep)
+        for q in range(P):
+            self.reads.append((("acc", q), 0, rep, "report"))
+        self.wait_nodes = []
+        for flag, target, ev, counter in self.waits:
+            cands = self.adds[flag] if counter else [e for v, e in self.pubs[flag] if v >= target]
+            assert len(cands) >= (target if counter else 1), f"nobody ever brings {flag} to {target}"
+            n = g.node(f"{flag}>={target}")
+            g.edge(n, ev)
+            self.wait_nodes.append([n, ev, set(cands), target if counter else 0])
+        self.refine()

@@ -3,7 +3,7 @@ task lists -- every read of a shared object ordered after its write and before t
 and the proof that the check SEES the two holes round 6 closed (it fails when either is put back)."""
 import pytest
 
-from protocol_model import Model
+from protocol_model import Model, Model01
 
 
 @pytest.mark.parametrize("P", [1, 2, 3, 5, 8, 11])
@@ -33,3 +33,30 @@ def test_the_model_sees_a_missing_right_hand_side_wait():
     of the right-hand side with nothing between them"""
     races = Model(5, rv_wait=False).races()
     assert races and any("('rv'," in r for r in races)
+
+
+@pytest.mark.parametrize("scheme,P", [(1, 1), (1, 2), (1, 4), (1, 7), (1, 10), (0, 1), (0, 2), (0, 4), (0, 7), (0, 10)])
+def test_schemes_0_and_1_are_ordered_by_hand_offs_alone(scheme, P):
+    """... and without the in-order publication too: in these schemes every publisher of potrf_done / rows_done depends, through
+    its data, on its predecessor's publication (the hole of round 6 was specific to the second level of following)"""
+    assert Model01(P, scheme).races() == []
+    assert Model01(P, scheme, inorder=False).races() == []
+
+
+@pytest.mark.parametrize("scheme,P,drop,where,seen", [
+    (0, 8, "rows_done", "DIAG", "'wt'"),          # the wait ahead of potrf in scheme 0: it keeps the W tile of block q - 3 for its readers
+    (1, 6, "off1_ready", "DIAG", "'tile', 0, 1"),  # the fused diagonal task would solve a tile that is not updated yet
+    (0, 6, "potrf_done", "OFF", "'rv', 0"),        # a strip solve without its wait for the factorisation
+])
+def test_the_model_notices_a_wait_that_is_taken_away(monkeypatch, scheme, P, drop, where, seen):
+    """the clean results above are not vacuous: remove one wait of the kernel from the model and the pair it ordered shows up"""
+    import protocol_model as pm
+    orig = pm.Model.Seq.wait
+
+    def wait(self, flag, target, counter=False):
+        if flag == drop and where in self.label:
+            return
+        return orig(self, flag, target, counter)
+    monkeypatch.setattr(pm.Model.Seq, "wait", wait)
+    races = Model01(P, scheme).races()
+    assert races and any(seen in r for r in races), races[:3]
