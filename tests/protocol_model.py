@@ -34,8 +34,22 @@ import numpy as np
 
 TASK = np.dtype([("type", "u1"), ("q", "u1"), ("j", "u1"), ("S", "u1"), ("b", "<u2"), ("pa", "u1"), ("pb", "u1"),
                  ("slot", "<u4"), ("ctr", "<u4")])
-PART, DIAG, OFF = 0, 1, 2
+PART, DIAG, OFF, SCHUR = 0, 1, 2, 3
 TYPE_MASK, CHAIN, NOSOLVE, WAITNEXT, FUSED = 0x0F, 0x10, 0x20, 0x40, 0x80
+
+
+def aug_plan(P: int, Mt: int, Ms: int, scheme: int = 2):
+    """the task list of predict's launch: one matrix of P block rows with Mt appended column tiles and the Ms x Ms upper tiles
+    of their Schur complement (psoap_dag_plan_aug)"""
+    from psoap_amd import _lib
+    L = _lib.load()
+    n, slots, ctrs = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+    first = (ctypes.c_uint32 * 9)()
+    assert L.psoap_dag_plan_aug(P, Mt, Ms, 512, scheme, None, 0, ctypes.byref(n), ctypes.byref(slots), ctypes.byref(ctrs), first) == 0
+    tasks = np.zeros(n.value, dtype=TASK)
+    assert L.psoap_dag_plan_aug(P, Mt, Ms, 512, scheme, tasks.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n),
+                                ctypes.byref(slots), ctypes.byref(ctrs), first) == 0
+    return tasks
 
 
 def lane_plan(P: int, scheme: int = 2):
@@ -102,10 +116,11 @@ class Graph:
 
 
 class Model:
-    def __init__(self, P: int, inorder: bool = True, acc_chain: bool = False, rv_wait: bool = True):
+    def __init__(self, P: int, inorder: bool = True, acc_chain: bool = False, rv_wait: bool = True, Mt: int = 0, Ms: int = 0):
         self.P, self.inorder, self.acc_chain, self.rv_wait = P, inorder, acc_chain, rv_wait
+        self.Pt = P + Mt               # column tiles: the matrix's + the appended ones (predict: [B | Cx^T])
         self.g = Graph()
-        self.tasks = lane_plan(P, 2)
+        self.tasks = aug_plan(P, Mt, Ms, 2) if Mt else lane_plan(P, 2)
         self.flags = self.tasks["type"].copy()
         self.kind = self.tasks["type"] & TYPE_MASK
         self.pubs = defaultdict(list)        # flag name -> [(value, event)]
@@ -190,6 +205,19 @@ class Model:
                 self.last[t] = s.cur
                 continue
             n_wait = S - 1
+            if self.kind[t] == SCHUR:
+                # a tile of Sigma = A - W^T W (the generic path: the chain's sum, the last panel behind rows_done, the store
+                # into DagAug::S; nobody inside the launch reads it, it is not counted in any row)
+                s = self.Seq(self, t, f"SCHUR({q},{j})")
+                if n_wait > 0:
+                    s.wait(("arrive", ctr), n_wait, counter=True)
+                    s.read(("slot", ctr, (n_wait - 1) & 1), n_wait - 1)
+                assert pb - pa == 1 and pb == P
+                s.wait("rows_done", pb)
+                self.read_tiles(s, (pb - 1,), (q, j))
+                s.write(("sigma", q, j), 0)
+                self.last[t] = s.cur
+                continue
             if self.kind[t] == DIAG:
                 # dag_special mode 0 -> dag_diag_fast -> potrf_spine_fused (spine / worker, SpinePub, SpineFollow)
                 assert chain and (f & WAITNEXT) and n_wait >= 1 and not (f & FUSED)
@@ -258,9 +286,10 @@ class Model:
                     s.wait(("rvrow", j), q)
                 v = self.rv_version_before(q, q)
                 s.read(("rv", q), v + 1)                                     # z_q
-                vj = self.rv_version_before(q, j)
-                s.read(("rv", j), vj)
-                s.write(("rv", j), vj + 1)
+                if j < P:                                                    # (an appended column has no right-hand side block)
+                    vj = self.rv_version_before(q, j)
+                    s.read(("rv", j), vj)
+                    s.write(("rv", j), vj + 1)
             if pubnext:
                 s.publish("next_done", q + 1)
             s.publish(("rvrow", j), q + 1)
@@ -271,7 +300,7 @@ class Model:
         g = self.g
         for q in range(P):
             members = [self.last[t] for t in row_members[q]]
-            assert len(members) == P - q
+            assert len(members) == self.Pt - q
             # (a JOIN: the publication comes after ALL of them, so it comes after whichever one an event precedes)
             n = g.node(f"rows_done={q + 1}")
             for mbr in members:

@@ -60,3 +60,10 @@ def test_the_model_notices_a_wait_that_is_taken_away(monkeypatch, scheme, P, dro
     monkeypatch.setattr(pm.Model.Seq, "wait", wait)
     races = Model01(P, scheme).races()
     assert races and any(seen in r for r in races), races[:3]
+
+
+@pytest.mark.parametrize("P,Mt", [(1, 1), (3, 2), (6, 3), (9, 2)])
+def test_the_augmented_launch_of_predict_is_ordered_by_hand_offs_alone(P, Mt):
+    """[B | Cx^T] factored by one launch with the prediction columns as extra column tiles and Sigma's tiles as Schur tasks"""
+    assert Model(P, Mt=Mt, Ms=Mt).races() == []
+    assert Model(P, Mt=Mt, Ms=Mt, inorder=False).races() != [] or P < 3
