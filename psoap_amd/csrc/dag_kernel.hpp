@@ -182,10 +182,11 @@ constexpr long long DAG_MAX_SPINS = 2000000;  // x (s_sleep + atomic round trip)
 
 #define PSOAP_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-// Poll of a flag word.  Measured on gfx950 (ROCm 7.2): a relaxed agent-scope LOAD (global_load sc1)
-// is served by the polling XCD's L2 and can return the value from before another XCD's sc1 store
-// indefinitely once the line is resident there; a read-modify-write executes at the memory side and
-// always observes the latest value, so the poll is an atomic add of zero.
+// Poll of a flag word (poll_word, common.hpp).  Rounds 1-5 wrote this as an atomic add of zero in the belief that an agent-scope
+// LOAD could be served stale from the polling XCD's L2 "indefinitely"; hipcc compiled every such add to exactly that load
+// (`flat_load_dword ... sc1`) all along, and the litmus tests of round 6 (tools/litmus.py, profiles/r6_litmus.txt) show sc1 loads
+// coherent between XCDs -- line planted in the reader's L2 or not, idle or under L2 pressure, 0 stale in 20,000 rounds per
+// combination.  -DPSOAP_RMW_POLL makes the polls the returning atomics they were meant to be (1 % slower; not needed).
 __device__ __forceinline__ int dag_peek(int* flag) { return poll_word(flag); }
 
 // A tile element other workgroups will read (the two store routines every tile goes through: dag_store_updated, dag_trsm)
