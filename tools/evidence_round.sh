@@ -47,6 +47,7 @@ step soak_perm bash -c "PSOAP_DEBUG_POISON=15 timeout 200 python tools/soak_batc
 # sixteen ~100 us late -- the three schemes through streams, bit-identical to the product library's values or the step fails
 if [ -f ab_libs/chaos.so ]; then
   step chaos bash -c "rm -f gpurun_out/soakref*.npy; export PSOAP_SOAK_REF=\$PWD/gpurun_out/soakref; { for a in '2 8 2' '2 8 0' '2 8 1'; do timeout 200 python tools/soak_stream.py \$a 10; done; for a in '2 8 2' '2 8 0' '2 8 1'; do PSOAP_GP_LIB=\$PWD/ab_libs/chaos.so timeout 300 python tools/soak_stream.py \$a 60; done; } 2>&1 | grep -v amdgpu.ids > gpurun_out/chaos_$TAG.txt; ! grep -q ' [1-9][0-9]* mismatching' gpurun_out/chaos_$TAG.txt"
+  step chaos_tests bash -c "PSOAP_GP_LIB=\$PWD/ab_libs/chaos.so timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullshape.py tests/test_gpu_group.py tests/test_gpu_stream.py tests/test_gpu_retrieve.py tests/test_gpu_pipeline.py tests/test_gpu_calibration.py -q -m gpu 2>&1 | grep -v amdgpu.ids | tail -3 >> gpurun_out/chaos_$TAG.txt"
 fi
 # several processes on this one GPU (no wrong value and no time-out with the library's lock on OR off, 8 and 16 workers; the
 # step fails on a single wrong value)
