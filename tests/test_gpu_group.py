@@ -154,3 +154,24 @@ def test_staged_mode_back_to_back_evals_with_changing_batch_size():
             got_big = h.fetch()
             assert np.allclose(got_small, want_small, rtol=LNP_RTOL, atol=0.0)
             assert np.allclose(got_big, want_big, rtol=LNP_RTOL, atol=0.0)
+
+
+def test_group_launch_at_the_reference_chunk_sizes(oracle):
+    """The reference's own regime: chunks of ~80 pixels x 12 epochs (scripts/psoap_generate_chunks.py:8-9, 73-96 -> N ~ 1000),
+    many chunks x the walkers of one ensemble step in ONE launch (256 matrices: the throughput scheme, 32 per queue): every
+    chunk's first and last walker against the oracle, the whole table bit-identical on a second launch."""
+    from psoap_amd.ensemble import EnsembleEvaluator
+    n_chunks, B = 8, 32
+    chunks = [syn.make_chunk(2, 12, 84, seed=7400 + k) for k in range(n_chunks)]        # N = 1008
+    gps = syn.make_walkers(2, B, seed=7401)
+    props = {k: (syn.walker_lwls(chunks[k], syn.make_walker_velocities(chunks[k], B, seed=7410 + k)), gps) for k in range(n_chunks)}
+    ev = EnsembleEvaluator.from_chunks(chunks, max_batch=B)
+    try:
+        total = ev.lnprob(props)
+        assert np.array_equal(total, ev.lnprob(props))
+        want = np.zeros(B)
+        for w in (0, B - 1):
+            want[w] = sum(oracle.lnlike(props[k][0][w], chunks[k].fl, chunks[k].sigma, list(gps[w])) for k in range(n_chunks))
+            assert abs(total[w] - want[w]) <= LNP_RTOL * max(1.0, abs(want[w])), (w, total[w], want[w])
+    finally:
+        ev.close()
