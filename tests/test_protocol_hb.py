@@ -6,7 +6,7 @@ import pytest
 from protocol_model import Model, Model01
 
 
-@pytest.mark.parametrize("P", [1, 2, 3, 5, 8, 11])
+@pytest.mark.parametrize("P", [1, 2, 3, 5, 8, 10])
 def test_following_scheme_is_ordered_by_hand_offs_alone(P):
     m = Model(P)
     assert m.races() == []
@@ -62,7 +62,7 @@ def test_the_model_notices_a_wait_that_is_taken_away(monkeypatch, scheme, P, dro
     assert races and any(seen in r for r in races), races[:3]
 
 
-@pytest.mark.parametrize("P,Mt", [(1, 1), (3, 2), (6, 3), (9, 2)])
+@pytest.mark.parametrize("P,Mt", [(1, 1), (3, 2), (6, 3), (8, 2)])
 def test_the_augmented_launch_of_predict_is_ordered_by_hand_offs_alone(P, Mt):
     """[B | Cx^T] factored by one launch with the prediction columns as extra column tiles and Sigma's tiles as Schur tasks"""
     assert Model(P, Mt=Mt, Ms=Mt).races() == []
