@@ -193,7 +193,7 @@ def scan_hot_loops(text: str):
     out = {}
     i = 0
     while i < len(lines):
-        m = re.match(r"^(_ZN5psoap(?:10k_chol_dag|11dag_special)\w+):", lines[i])
+        m = re.match(r"^(_ZN5psoap(?:10k_chol_dag|11dag_special|11k_chol_solo)\w+):", lines[i])
         if not m:
             i += 1
             continue
