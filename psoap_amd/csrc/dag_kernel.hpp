@@ -2655,7 +2655,11 @@ inline void dag_build_pool(DagPlan& plan)
 // B = 8: 17.6 -> 12.9 ms, B = 24: 31.1 -> 30.8 ms; N = 2000, B = 32: 3.9 -> 3.1 ms), or when no queue holds
 // more than one matrix; throughput beyond (N = 6000, B = 32: 39.2 vs 39.9 ms; N = 8192, B = 32: 95.0 vs 96.1).
 // (Readiness ordering was also tried for the throughput scheme: 800 -> 776 evals/s, not adopted.)
-constexpr int DAG_LATENCY_QUEUE_ROWS = 150;
+// (Round 6, after the round-5 kernel work: tools/latency_quick.py under PSOAP_DAG_SCHEME=0 / 1, ms per batch, scheme 1 / 0 --
+//   N = 6000: 10 matrices 13.03 / 13.50, 12: 15.31 / 15.48, 16: 19.94 / 19.47, 24: 29.14 / 28.37; N = 8192: 12: 36.21 / 35.81, 16:
+//   47.86 / 46.81; N = 4096: 20: 8.49 / 8.67, 24: 9.91 / 9.94, 28: 11.41 / 11.35, 32: 12.98 / 12.61; N = 2000: 32: 2.44 / 2.78
+// -- the throughput scheme is ahead from about 740 block rows in the launch on (was 1200): 92 per queue.)
+constexpr int DAG_LATENCY_QUEUE_ROWS = 92;
 // How many of the 8 ticket queues a batch uses (matrix b goes to queue b mod that number; the workgroups of an XCD whose own
 // queue is empty spread evenly over the queues in use -- k_chol_dag's steal0).  A queue's matrices share its workgroups, so a
 // batch is through when its FULLEST queue is: 12 matrices on 8 queues are 2 + 1 per queue and cost what 16 do, 9 cost

@@ -45,14 +45,14 @@ def test_plan_is_complete_and_deadlock_free(B, P, workers):
     Ps = [P] * B if np.ndim(P) == 0 else list(P)
     n_tiles = sum(p * (p + 1) // 2 for p in Ps)
     assert TASK.itemsize == 16
-    # latency scheme (chained partial sums) while the fullest queue holds at most ~150 block rows or a
+    # latency scheme (chained partial sums) while the fullest queue holds at most ~92 block rows (round 6; 150 before) or a
     # single matrix; gathered otherwise
     # (queues in use, dag_queue_count: of 8, 4, 2, 1 the one that leaves the fullest queue relatively emptiest -- 12 matrices:
     # 4 x 3, 9 matrices: one list -- the larger on a tie; up to 8 matrices a queue each)
     nq = 8 if B <= 8 else min((8, 4, 2, 1), key=lambda n: ((B + n - 1) // n * n, -n))
     q_rows = [sum(Ps[g::nq]) for g in range(nq)]
     q_count = [len(Ps[g::nq]) for g in range(nq)]
-    want_chain = max(q_rows) * nq <= 150 * 8 or max(q_count) <= 1
+    want_chain = max(q_rows) * nq <= 92 * 8 or max(q_count) <= 1
     # ... and within that, the following scheme (scheme 2) for up to eight matrices (24 small ones): the strip solves follow the
     # factorisation (DAG_WAITNEXT on OFF finals), the diagonal task solves nothing
     following = want_chain and (B <= 8 or (B <= 24 and max(Ps) <= 20))
